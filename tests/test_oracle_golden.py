@@ -1,0 +1,144 @@
+"""CPU: the committed restatement (oracle/renet_oracle.py) against fixtures that were produced by
+RUNNING THE UNMODIFIED REFERENCE (tools/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import O, fixtures, load_golden, train_case, global_shapes
+
+RTOL, ATOL = 2e-4, 2e-5      # fp32 path, different summation order than the reference
+
+
+@pytest.mark.parametrize('name', ['tiny', 'small'])
+def test_history_construction_matches_reference_script(name):
+    """oracle.build_histories / build_graph_dict vs data/ICEWS18/get_history_graph.py run as a script."""
+    gold = load_golden('prep_%s.npz' % name)
+    cfg, tr, va, te = fixtures.split_dataset(name)
+    state = None
+    for split, q in (('train', tr), ('valid', va), ('test', te)):
+        (sh, sht), (oh, oht), state = O.build_histories(q, cfg['num_ent'], state=state)
+        for tag, mine in (('s', (sh, sht)), ('o', (oh, oht))):
+            ref = fixtures.unflatten_histories(gold['%s_%s_seq_ptr' % (split, tag)], gold['%s_%s_step_t' % (split, tag)],
+                                               gold['%s_%s_nbr_ptr' % (split, tag)], gold['%s_%s_nbr' % (split, tag)])
+            assert fixtures.histories_equal(mine, ref), (split, tag)
+    gd = O.build_graph_dict(tr, cfg['num_rels'])
+    assert list(gd.keys()) == gold['graph_t'].tolist()
+    for k, t in enumerate(gd):
+        g = gd[t]
+        e0, e1 = gold['graph_edge_ptr'][k], gold['graph_edge_ptr'][k + 1]
+        n0, n1 = gold['graph_node_ptr'][k], gold['graph_node_ptr'][k + 1]
+        assert np.array_equal(g.ent, gold['graph_ent'][n0:n1])
+        assert np.array_equal(g.src, gold['graph_src'][e0:e1])
+        assert np.array_equal(g.dst, gold['graph_dst'][e0:e1])
+        assert np.array_equal(g.type_s, gold['graph_type_s'][e0:e1])
+        assert np.array_equal(g.type_o, gold['graph_type_o'][e0:e1])
+        assert np.array_equal(g.norm(), gold['graph_norm'][n0:n1])
+
+
+@pytest.mark.parametrize('d', [100, 200, 400])
+def test_rgcn_layer_matches_reference(d):
+    gold = load_golden('rgcn_%d.npz' % d)
+    n, num_rels = int(gold['n']), int(gold['num_rels'])
+    p = fixtures.make_params(200 + d, {'weight': (2 * num_rels, d * d // 100), 'loop_weight': (d, d),
+                                       'h': (n, d), 'gout': (n, d)}, scale=0.5)
+    for relu in (0, 1):
+        for reverse in (0, 1):
+            h = torch.from_numpy(p['h']).clone().requires_grad_(True)
+            w = torch.from_numpy(p['weight']).clone().requires_grad_(True)
+            lw = torch.from_numpy(p['loop_weight']).clone().requires_grad_(True)
+            et = gold['type_o'] if reverse else gold['type_s']
+            y = O.rgcn_layer(h, gold['src'], gold['dst'], et, gold['norm'], w, lw, relu=bool(relu))
+            (y * torch.from_numpy(p['gout'])).sum().backward()
+            tag = 'relu%d_rev%d_' % (relu, reverse)
+            np.testing.assert_allclose(y.detach().numpy(), gold[tag + 'out'], rtol=RTOL, atol=ATOL)
+            np.testing.assert_allclose(h.grad.numpy(), gold[tag + 'dh'], rtol=RTOL, atol=ATOL)
+            for key, g in (('dweight', w.grad), ('dloop', lw.grad)):
+                ok, err, how = fixtures.check_packed(gold, tag + key, g.numpy(), RTOL, ATOL * 10)
+                assert ok, (tag + key, err, how)
+
+
+@pytest.mark.parametrize('name,d', [('tiny', 100), ('tiny', 200), ('small', 200)])
+def test_training_forward_backward_matches_reference(name, d):
+    """model.RENet.forward x2 directions + backward (reference) vs renet_forward_loss (oracle)."""
+    c = train_case(name, d)
+    gold, cfg = c['gold'], c['cfg']
+    params = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in c['params'].items()}
+    gd = O.build_graph_dict(c['train'], cfg['num_rels'])
+    ge = {t: torch.from_numpy(v) for t, v in c['global_emb'].items()}
+    total = 0
+    for tag, subject in (('s', True), ('o', False)):
+        hist, hist_t = c['hists'][tag]
+        loss, parts = O.renet_forward_loss(params, c['batch'], hist, hist_t, gd, ge, cfg['num_rels'],
+                                           c['seq_len'], subject=subject, return_parts=True)
+        assert abs(loss.item() - float(gold['loss_' + tag])) < 1e-4 * max(1.0, abs(float(gold['loss_' + tag])))
+        bg = parts['bg']
+        b = len(c['batch'])
+        nnz = len(bg.lens)
+        assert bg.num_nodes == int(gold[tag + '_graph_nodes'])
+        for key, val in (('h_n', parts['s_h']), ('q_n', parts['s_q'])):
+            full = np.zeros((b, d), np.float32)
+            full[bg.perm] = val.detach().numpy()
+            np.testing.assert_allclose(full, gold['%s_%s' % (tag, key)], rtol=RTOL, atol=ATOL)
+        logits = np.zeros((b, cfg['num_ent']), np.float32)
+        logits[bg.perm] = parts['ob_pred'].detach().numpy()
+        np.testing.assert_allclose(logits, gold[tag + '_logits'], rtol=RTOL, atol=ATOL * 5)
+        rows = parts['h2'][torch.as_tensor(bg.subj_row)].detach().numpy()
+        per_seq = np.split(rows, np.cumsum(bg.lens)[:-1]) if nnz else []
+        byorig = {int(bg.perm[i]): per_seq[i] for i in range(nnz)}
+        mine = np.concatenate([byorig[i] for i in sorted(byorig)])
+        np.testing.assert_allclose(mine, gold[tag + '_subj_rows'], rtol=RTOL, atol=ATOL)
+        total = total + loss
+    total.backward()
+    for k, p in params.items():
+        g = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+        ok, err, how = fixtures.check_packed(gold, 'grad.' + k, g, 1e-3, 2e-5)
+        assert ok, (k, err, how)
+
+
+@pytest.mark.parametrize('name,d,maxpool', [('tiny', 100, 1), ('tiny', 200, 0), ('small', 200, 1)])
+def test_global_model_matches_reference(name, d, maxpool):
+    gold = load_golden('global_%s_%d_max%d.npz' % (name, d, maxpool))
+    cfg, tr, va, te = fixtures.split_dataset(name)
+    seq_len = int(gold['seq_len'])
+    p = fixtures.make_params(int(gold['param_seed']), global_shapes(cfg['num_ent'], cfg['num_rels'], d))
+    params = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in p.items()}
+    gd = O.build_graph_dict(tr, cfg['num_rels'])
+    times = np.unique(tr[:, 3])
+    loss = O.global_forward_loss(params, times, gold['true_o'], gd, seq_len, subject=True, maxpool=maxpool)
+    assert abs(loss.item() - float(gold['loss'])) < 1e-4 * max(1.0, abs(float(gold['loss'])))
+    loss.backward()
+    for k, prm in params.items():
+        if ('grad.' + k) in gold or ('grad.' + k + '__samp') in gold:
+            ok, err, how = fixtures.check_packed(gold, 'grad.' + k, prm.grad.numpy(), 1e-3, 2e-5)
+            assert ok, (k, err, how)
+    with torch.no_grad():
+        for k, t in enumerate(gold['predict_t']):
+            for subj in (True, False):
+                emb, logits = O.global_predict(params, int(t), gd, seq_len, subject=subj, maxpool=maxpool)
+                tag = 'predict%d_%s_' % (k, 's' if subj else 'o')
+                np.testing.assert_allclose(emb.numpy(), gold[tag + 'emb'], rtol=RTOL, atol=ATOL)
+                np.testing.assert_allclose(logits.numpy(), gold[tag + 'logits'], rtol=RTOL, atol=ATOL)
+
+
+def test_gru_restatement_matches_torch_gru():
+    """gru_last_state vs torch.nn.GRU + pack_padded_sequence on CPU (the third-party op, model.py:28,86)."""
+    torch.manual_seed(3)
+    b, l, i, h = 9, 6, 20, 12
+    gru = torch.nn.GRU(i, h, batch_first=True)
+    lens = [6, 6, 5, 4, 4, 2, 1, 1, 1]
+    x = torch.randn(b, l, i)
+    for k, n in enumerate(lens):
+        x[k, n:] = 0
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x, lens, batch_first=True)
+    _, hn = gru(packed)
+    mine = O.gru_last_state(x, lens, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)
+    np.testing.assert_allclose(mine.detach().numpy(), hn[0].detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_filtered_rank_tie_rule():
+    pred = np.array([0.1, 2.0, 2.0, -1.0, 2.0, 3.0], dtype=np.float32)
+    # label 1 ties with 2 and 4; entity 5 is a known true completion and is filtered out
+    assert O.filtered_rank(pred, 1, [5]) == 0 + (3 - 1.0) / 2 + 1
+    assert O.filtered_rank(pred, 1, []) == 1 + (3 - 1.0) / 2 + 1
+    m = O.mrr_hits([1, 2, 4, 20])
+    assert abs(m['mrr'] - (1 + .5 + .25 + .05) / 4) < 1e-12 and m['hits@3'] == 0.5 and m['hits@10'] == 0.75
