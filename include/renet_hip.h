@@ -1,0 +1,183 @@
+/*
+ * renet_hip.h -- C ABI of librenet_hip.so: the MI355X (gfx950) kernels behind RE-Net's
+ * RENet / RGCNAggregator Python API.
+ *
+ * The reference (INK-USC/RE-Net) has NO native code and NO FFI: its boundary for this path is the
+ * Python class API (RGCN.py, Aggregator.py, model.py, global_model.py) and everything below that is
+ * third-party (DGL 0.4 + torch 1.6 CUDA kernels).  Each entry point below therefore names the
+ * reference lines whose device work it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm tensors: tensor.data_ptr());
+ *     the library allocates nothing and keeps no global mutable state (re-entrant);
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); every
+ *     call only enqueues work on it and never synchronises;
+ *   - fp32 row-major contiguous matrices, int32 indices;
+ *   - D (n_hidden) must be 100, 200 or 400 (the reference hard-codes num_bases = 100, model.py:36,
+ *     so the relation blocks are 1x1, 2x2, 4x4); other values return RENET_ERR_UNSUPPORTED;
+ *   - return value: 0 = ok, <0 = argument error (below), >0 = hipError_t from the launch.
+ */
+#ifndef RENET_HIP_H
+#define RENET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RENET_OK 0
+#define RENET_ERR_BADARG (-1)
+#define RENET_ERR_UNSUPPORTED (-2)
+#define RENET_ERR_WORKSPACE (-3)
+
+#define RENET_ABI_VERSION 1
+int renet_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row gather / deterministic segmented scatter-add.
+ * renet_gather_rows : out[i,:] = table[idx[i],:]              (utils.py:239 h0 = ent_embeds[id];
+ *                                                              Aggregator.py:139-140 subject rows)
+ * renet_segment_add : for u in [0,U): dst[seg_target[u],:] += sum_{k in [seg_ptr[u],seg_ptr[u+1])}
+ *                     src[order[k],:]   -- the backward of renet_gather_rows with the index sorted on
+ *                     the host (no atomics => bit-reproducible).
+ * ---------------------------------------------------------------------------------------------- */
+int renet_gather_rows(const float* table, const int32_t* idx, int n, int D, float* out, void* stream);
+int renet_segment_add(const float* src, const int32_t* order, const int32_t* seg_ptr,
+                      const int32_t* seg_target, int U, int D, float* dst, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RGCN block-diagonal gather-SpMM  (RGCN.py:79-94 msg_func + fn.sum + apply_func, fused with the
+ * epilogue of RGCN.py:42-50).
+ *
+ *   out[v,:] = act( scale[v] * sum_{e in [row_ptr[v],row_ptr[v+1])} blockmul(x[col[e],:], W[tau(e)])
+ *                   + addend[v,:] * dropmask )
+ *   tau(e)   = (etype[e] + type_shift) mod T                       (T = 2 * num_rels)
+ *   blockmul : x viewed [nb=100, si], W[tau] viewed [nb, si, so] row-major (RGCN.py:81-87):
+ *              transpose_w == 0: y[b,j] = sum_i x[b,i] W[b,i,j]     (forward message)
+ *              transpose_w == 1: y[b,i] = sum_j x[b,j] W[b,i,j]     (backward wrt h through W^T)
+ *   scale    : per-destination 1/in-degree (`norm`, utils.py:126-127) or NULL (= 1)
+ *   addend   : the self-loop message h @ W_loop (RGCN.py:34-37) or NULL; may alias `out`.
+ *              drop_p > 0 applies inverted dropout to the addend with the counter-based mask
+ *              keep(seed, v*D+c) (RGCN.py:36-37); the same (seed) regenerates the mask in backward.
+ *   relu     : 1 = ReLU epilogue (rgcn1, Aggregator.py:119-120), 0 = identity (rgcn2)
+ *
+ * The graph is CSR by destination (row_ptr[N+1], col[E] = source row, etype[E]).
+ * The backward wrt x uses the same CSR: RE-Net graphs hold both directions of every fact with paired
+ * types (utils.py:74-76), so the transposed graph is the same structure with type_shift = num_rels.
+ * ---------------------------------------------------------------------------------------------- */
+int renet_rgcn_gather(const float* x, int D, const int32_t* row_ptr, const int32_t* col,
+                      const int32_t* etype, const float* scale, const float* W, int T, int type_shift,
+                      int transpose_w, const float* addend, float drop_p, uint64_t seed, int relu,
+                      float* out, int N, void* stream);
+
+/* Backward prologue of one RGCN layer (element-wise, RGCN.py:42-50 + :93-94 reversed):
+ *   g_pre = g_out * (relu ? out > 0 : 1);  gn = g_pre * norm[v];  g_loop = g_pre * dropmask       */
+int renet_rgcn_bwd_prep(const float* g_out, const float* out, const float* norm, int relu,
+                        float drop_p, uint64_t seed, int N, int D, float* gn, float* g_loop,
+                        void* stream);
+
+/* Gradient of the relation weights (RGCN.py:81-87 backward):
+ *   dW[tau, b, i, j] = sum_{e: tau(e) == tau} x[src[e], b*si+i] * gn[dst[e], b*so+j]
+ * Edges are pre-sorted by type and cut into chunks of one type each (host side):
+ *   chunk c covers sorted edges [chunk_ptr[c], chunk_ptr[c+1]) , all of type chunk_type[c];
+ *   type_chunk_ptr[T+1] lists, per type, its range of chunks; the stored type t accumulates into
+ *   dW[(t + type_shift) mod T] (same convention as renet_rgcn_gather).  Two deterministic passes:
+ *   per-chunk partial sums into `workspace` (n_chunks * D*D/100 floats), then a per-type reduction. */
+size_t renet_rgcn_bwd_w_workspace(int n_chunks, int D);
+int renet_rgcn_bwd_w(const float* x, const float* gn, const int32_t* e_src, const int32_t* e_dst,
+                     const int32_t* chunk_ptr, const int32_t* chunk_type, int n_chunks,
+                     const int32_t* type_chunk_ptr, int T, int type_shift, int D, float* dW,
+                     float* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp32 GEMM on the f32-input MFMA (exact fp32, v_mfma_f32_32x32x2_f32):
+ *   C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] (+ bias[N]) (+ beta * C)
+ *   ta == 0: A is [M,K] row-major (lda = K-stride);  ta == 1: A is stored [K,M] (A^T)
+ *   tb == 0: B is [K,N] row-major;                    tb == 1: B is stored [N,K] (B^T)
+ * Replaces torch.mm (RGCN.py:35), the GRU input projection inside nn.GRU (model.py:86,94), nn.Linear
+ * (model.py:89-90,98-99) and their autograd backward GEMMs.
+ * split_k > 1 runs the deterministic two-pass split-K (partials in `workspace`,
+ * renet_gemm_workspace bytes) for the tall-skinny weight-gradient shapes.
+ * ---------------------------------------------------------------------------------------------- */
+size_t renet_gemm_workspace(int M, int N, int split_k);
+int renet_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
+                   const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
+                   int split_k, float* workspace, size_t workspace_bytes, void* stream);
+
+/* column sums: out[n] = sum_m X[m,n]  (bias gradients) */
+int renet_colsum(const float* X, int M, int N, int ldx, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sequence assembly (Aggregator.py:142-165): builds the GRU inputs directly in PACKED time-major
+ * layout (the .data of the PackedSequence the reference returns), with the dropout of
+ * Aggregator.py:157-158 fused.  Row p of the packed layout belongs to sequence seq[p] (position in
+ * the length-sorted batch):
+ *   X [p,:] = drop([ h2[subj_row[p]] | ent[s[seq[p]]] | rel[r[seq[p]]] | glob[glob_row[p]] ])   (4D)
+ *   Xr[p,:] = drop([ h2[subj_row[p]] | ent[s[seq[p]]] |                  glob[glob_row[p]] ])   (3D)
+ * Masks are counter-based: keep(seed_x, p*4D+c), keep(seed_xr, p*3D+c).
+ * Backward: dRows[p,:]  = grad wrt the gathered h2 row (X and Xr parts),
+ *           dEntSeq[p,:], dRelSeq[p,:] = grad wrt ent[s] / rel[r] contributed by row p
+ *           (the caller reduces them per sequence / entity with renet_segment_add).
+ * ---------------------------------------------------------------------------------------------- */
+int renet_seq_assemble_fwd(const float* h2, const float* ent, const float* rel, const float* glob,
+                           const int32_t* subj_row, const int32_t* row_ent, const int32_t* row_rel,
+                           const int32_t* glob_row, int S, int D, float drop_p, uint64_t seed_x,
+                           uint64_t seed_xr, float* X, float* Xr, void* stream);
+int renet_seq_assemble_bwd(const float* dX, const float* dXr, int S, int D, float drop_p,
+                           uint64_t seed_x, uint64_t seed_xr, float* dRows, float* dEntRow,
+                           float* dRelRow, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GRU over the packed <= seq_len window (torch.nn.GRU semantics, 1 layer, h0 = 0, gate order r,z,n;
+ * model.py:28-29,86,94; global_model.py:25,49).  Gi = X @ W_ih^T + b_ih is computed by the caller
+ * with renet_gemm_f32; these entry points run the recurrence.
+ *   Gi      [S, 3H]  packed time-major (step j occupies rows [off[j], off[j+1]), sequence i of the
+ *                    length-sorted batch is row off[j]+i; batch_sizes non-increasing)
+ *   step_off[L+1]    HOST array of row offsets (off[0] = 0, off[L] = S)
+ *   Whh [3H,H], bhh[3H]
+ *   h_last  [B,H]    state of every sequence after its own last step (h_n of nn.GRU), B = off[1]
+ *   saved   [S, 5H]  per packed row: r, z, n, (W_hn h + b_hn), h_prev   (consumed by backward)
+ * Backward: given dh_last[B,H] produces dGi[S,3H], dGh[S,3H] (caller forms dW_ih, dW_hh, biases,
+ * dX with renet_gemm_f32 / renet_colsum) ; `dh_work`[B,H] is scratch.
+ * ---------------------------------------------------------------------------------------------- */
+size_t renet_gru_workspace(int B, int H);
+int renet_gru_fwd(const float* Gi, const int32_t* step_off, int L, int H, const float* Whh,
+                  const float* bhh, float* h_last, float* saved, float* workspace,
+                  size_t workspace_bytes, void* stream);
+int renet_gru_bwd(const float* dh_last, const int32_t* step_off, int L, int H, const float* Whh,
+                  const float* saved, float* dGi, float* dGh, float* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Score head (model.py:89-91, 98-100).
+ * renet_concat3_fwd/bwd : feat[b,:] = drop([ a[ia[b]] | hmid[b] | c[ic[b]] ])   (c may be NULL: 2 parts)
+ * renet_softmax_ce      : per-row loss_b = logsumexp(logits[b,:]) - logits[b,target[b]];
+ *                         loss_sum += sum_b loss_b (one float, zeroed by the caller);
+ *                         if dlogits != NULL: dlogits = (softmax - onehot) * grad_scale  (may alias logits)
+ * ---------------------------------------------------------------------------------------------- */
+int renet_concat3_fwd(const float* a, const int32_t* ia, const float* hmid, const float* c,
+                      const int32_t* ic, int B, int D, float drop_p, uint64_t seed, float* feat,
+                      void* stream);
+int renet_concat3_bwd(const float* dfeat, int B, int D, int parts, float drop_p, uint64_t seed,
+                      float* da_rows, float* dhmid, float* dc_rows, void* stream);
+/* y = x * keepmask(seed) / (1 - p) on float4 groups (n % 4 == 0); its own backward (apply to dy).
+ * Used for the dropout of Aggregator.py:69 (global model sequence tensor). */
+int renet_dropout(const float* x, size_t n, float drop_p, uint64_t seed, float* y, void* stream);
+int renet_softmax_ce(const float* logits, const int32_t* target, int B, int C, int ld,
+                     float grad_scale, float* row_loss, float* dlogits, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-graph readout of the global model (Aggregator.py:58-61 dgl.max_nodes / mean_nodes):
+ *   out[g,:] = max / mean over rows [seg_ptr[g], seg_ptr[g+1]) of h; argmax[g,:] saved for backward. */
+int renet_segment_pool_fwd(const float* h, const int32_t* seg_ptr, int G, int D, int is_max,
+                           float* out, int32_t* argmax, void* stream);
+int renet_segment_pool_bwd(const float* dout, const int32_t* seg_ptr, const int32_t* argmax, int G,
+                           int D, int is_max, int N, float* dh, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RENET_HIP_H */

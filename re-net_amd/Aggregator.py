@@ -1,0 +1,200 @@
+"""Neighbourhood aggregators with the reference's class names and call signatures
+(reference Aggregator.py:9-237), rebuilt on the DGL-free batch builder (graph.py) and the HIP
+kernels.  Mean/Attn aggregators of the reference are dead code there (model.py:36 always builds
+RGCNAggregator) and are not provided.
+
+What differs from the reference internally (results are the same):
+  * the batch graph is built by a few vectorised numpy passes instead of ~T_b DGL subgraph calls;
+  * the per-sequence `# Slow!!!` scatter loop (Aggregator.py:148-155) and pack_padded_sequence are
+    one kernel that writes the PackedSequence data directly (time-major), dropout fused;
+  * the length sort is computed once (stable) and shared with the caller through `last_batch`.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils.rnn import PackedSequence
+
+import graph as G
+import ops
+from RGCN import RGCNBlockLayer as RGCNLayer
+
+
+def _host_ints(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy().astype(np.int64).reshape(-1)
+    return np.asarray(x, dtype=np.int64).reshape(-1)
+
+
+class GlobalEmbTable(object):
+    """Device matrix view of the `global_emb` dict (t -> tensor[1,1,D], train.py:64-66): rows in
+    ascending time + a searchsorted index.  Rebuilt when the dict's size changes or on invalidate()."""
+
+    def __init__(self):
+        self._key = None
+        self.times = None
+        self.mat = None
+
+    def get(self, global_emb, dim, device):
+        key = (id(global_emb), len(global_emb), str(device))
+        if key != self._key:
+            ts = sorted(int(t) for t in global_emb.keys())
+            self.times = np.asarray(ts, dtype=np.int64)
+            if ts:
+                rows = [torch.as_tensor(global_emb[t]).detach().reshape(dim).float().cpu() for t in ts]
+                self.mat = torch.stack(rows).to(device)
+            else:
+                self.mat = torch.zeros(1, dim, device=device)
+            self._key = key
+        return self
+
+    def invalidate(self):
+        self._key = None
+
+    def index(self, t):
+        t = np.asarray(t, dtype=np.int64)
+        p = np.searchsorted(self.times, t)
+        if len(t) and (np.any(p >= len(self.times)) or np.any(self.times[np.minimum(p, len(self.times) - 1)] != t)):
+            raise KeyError('timestamp without a global embedding')
+        return p
+
+
+class RGCNAggregator(nn.Module):
+    def __init__(self, h_dim, dropout, num_nodes, num_rels, num_bases, model, seq_len=10):
+        super().__init__()
+        self.h_dim = h_dim
+        self.drop_p = float(dropout or 0.0)
+        self.dropout = nn.Dropout(dropout)       # kept for attribute compatibility; the mask is fused
+        self.seq_len = seq_len
+        self.num_rels = num_rels
+        self.num_nodes = num_nodes
+        self.model = model
+        self.rgcn1 = RGCNLayer(h_dim, h_dim, 2 * num_rels, num_bases, activation=F.relu, self_loop=True,
+                               dropout=dropout)
+        self.rgcn2 = RGCNLayer(h_dim, h_dim, 2 * num_rels, num_bases, activation=None, self_loop=True,
+                               dropout=dropout)
+        self.glob_table = GlobalEmbTable()
+        self.last_batch = None
+
+    # ------------------------------------------------------------------------------------------
+    def build(self, s_hist, s, r, ent_embeds, graph_dict, global_emb, sort):
+        """Host side of utils.py:209-283: returns the device batch graph (or None if every history
+        is empty)."""
+        s_np, r_np = _host_ints(s), _host_ints(r)
+        fh = s_hist if isinstance(s_hist, G.FlatHistory) else G.FlatHistory.from_lists(s_hist[0], s_hist[1])
+        if fh.seq_ptr[-1] == 0:
+            return None
+        table = self.glob_table.get(global_emb, self.h_dim, ent_embeds.device)
+        hb = G.build_batch(G.store_for(graph_dict), self.num_nodes, self.num_rels, s_np, r_np, fh, sort=sort,
+                           glob_index=table.index)
+        if hb.L > self.seq_len:
+            raise ValueError('history longer than seq_len (%d > %d)' % (hb.L, self.seq_len))
+        g = G.DeviceGraph(hb, ent_embeds.device)
+        g.glob = table.mat
+        return g
+
+    def encode(self, g, ent_embeds, rel_embeds, reverse):
+        """Device side: h0 gather, two RGCN layers, packed sequence assembly (Aggregator.py:136-165)."""
+        g.ndata['h'] = ops.GatherRowsFn.apply(ent_embeds, g.node_ent, g.plan_node_ent)      # utils.py:239
+        self.rgcn1(g, reverse)
+        self.rgcn2(g, reverse)
+        h2 = g.ndata.pop('h')
+        p = self.drop_p if self.training else 0.0
+        sx, sxr = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
+        return ops.SeqAssembleFn.apply(h2, ent_embeds, rel_embeds, g.glob, g, p, sx, sxr)
+
+    def _run(self, s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse, sort):
+        g = self.build(s_hist, s, r, ent_embeds, graph_dict, global_emb, sort)
+        self.last_batch = g
+        if g is None:
+            return None, None
+        x, xr = self.encode(g, ent_embeds, rel_embeds, reverse)
+        bs = torch.from_numpy(g.host.batch_sizes)
+        return PackedSequence(x, bs), PackedSequence(xr, bs)
+
+    def forward(self, s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse):
+        """Aggregator.py:124-167.  Returns (PackedSequence[., 4h], PackedSequence[., 3h]) for the
+        length-sorted non-empty sequences, or (None, None) when every history is empty."""
+        return self._run(s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse, True)
+
+    def predict_batch(self, s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse):
+        """Aggregator.py:169-214: same, sequences kept in the given order."""
+        return self._run(s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse, False)
+
+    def predict(self, s_history, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse):
+        """Aggregator.py:218-237: one sequence -> (inp[len, 4h], inp_r[len, 3h])."""
+        hist, hist_t = s_history
+        px, pxr = self._run(([hist], [hist_t]), _host_ints(s)[:1], _host_ints(r)[:1], ent_embeds, rel_embeds,
+                            graph_dict, global_emb, reverse, False)
+        return px.data, pxr.data
+
+
+class RGCNAggregator_global(nn.Module):
+    def __init__(self, h_dim, dropout, num_nodes, num_rels, num_bases, model, seq_len=10, maxpool=1):
+        super().__init__()
+        self.h_dim = h_dim
+        self.drop_p = float(dropout or 0.0)
+        self.dropout = nn.Dropout(dropout)
+        self.seq_len = seq_len
+        self.num_rels = num_rels
+        self.num_nodes = num_nodes
+        self.model = model
+        self.maxpool = maxpool
+        self.rgcn1 = RGCNLayer(h_dim, h_dim, 2 * num_rels, num_bases, activation=F.relu, self_loop=True,
+                               dropout=dropout)
+        self.rgcn2 = RGCNLayer(h_dim, h_dim, 2 * num_rels, num_bases, activation=None, self_loop=True,
+                               dropout=dropout)
+
+    def pooled(self, times, ent_embeds, graph_dict, reverse):
+        """Batch the FULL graphs of `times`, two RGCN layers, per-graph max/mean readout
+        (Aggregator.py:44-61 / 87-105) -> [len(times), h]."""
+        hb = G.build_full_graphs(graph_dict, times)
+        g = G.DeviceGraph(hb, ent_embeds.device)
+        g.ndata['h'] = ops.GatherRowsFn.apply(ent_embeds, g.node_ent, g.plan_node_ent)
+        self.rgcn1(g, reverse)
+        self.rgcn2(g, reverse)
+        h2 = g.ndata.pop('h')
+        return ops.SegmentPoolFn.apply(h2, g.seg_ptr, hb.G, 1 if self.maxpool == 1 else 0)
+
+    def forward(self, t_list, ent_embeds, graph_dict, reverse):
+        """Aggregator.py:27-73.  t_list: timestamps sorted descending (global_model.py:45); zeros (no
+        history) are dropped.  Returns the PackedSequence of pooled graph embeddings [., h]."""
+        times = np.asarray(list(graph_dict.keys()), dtype=np.int64)
+        time_unit = int(times[1] - times[0])
+        t_np = _host_ints(t_list)
+        t_np = t_np[:int(np.count_nonzero(t_np))]
+        length = t_np // time_unit
+        lens = np.minimum(length, self.seq_len)
+        starts = length - lens
+        win = G.ragged_arange(starts, lens)                      # positions in the timeline, sequence-major
+        uniq_pos, inv = np.unique(win, return_inverse=True)
+        pooled = self.pooled(times[uniq_pos], ent_embeds, graph_dict, reverse)
+        n = len(lens)
+        L = int(lens[0]) if n else 0
+        bs = (lens[None, :] > np.arange(L)[:, None]).sum(axis=1) if L else np.zeros(0, np.int64)
+        off = np.concatenate(([0], np.cumsum(bs)))
+        seq = np.repeat(np.arange(n), lens)
+        j = np.arange(len(win)) - np.repeat(np.cumsum(lens) - lens, lens)
+        packed_of_k = off[j] + seq
+        rows = np.empty(len(win), dtype=np.int64)
+        rows[packed_of_k] = inv
+        plan = G.SegPlan.host(rows)
+        dev = ent_embeds.device
+        for f in ('order', 'seg_ptr', 'target'):
+            setattr(plan, f, torch.from_numpy(getattr(plan, f)).to(dev))
+        idx = torch.from_numpy(rows.astype(np.int32)).to(dev)
+        x = ops.GatherRowsFn.apply(pooled, idx, plan)            # Aggregator.py:64-67
+        if self.training and self.drop_p > 0:
+            x = ops.DropoutFn.apply(x, self.drop_p, ops.next_seed())      # Aggregator.py:69
+        return PackedSequence(x, torch.from_numpy(bs.astype(np.int64)))
+
+    def predict(self, t, ent_embeds, graph_dict, reverse):
+        """Aggregator.py:75-107: pooled embeddings of the <= seq_len graphs strictly before t."""
+        times = list(graph_dict.keys())
+        pos = 0
+        for tt in times:
+            if tt >= t:
+                break
+            pos += 1
+        win = times[max(0, pos - self.seq_len):pos]
+        return self.pooled(win, ent_embeds, graph_dict, reverse)

@@ -1,0 +1,67 @@
+// Shared device/host helpers for librenet_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/renet_hip.h"
+
+#define RENET_LAUNCH_CHECK()                      \
+    do {                                          \
+        hipError_t e__ = hipGetLastError();       \
+        if (e__ != hipSuccess) return (int)e__;   \
+    } while (0)
+
+static inline bool renet_dim_ok(int D) { return D == 100 || D == 200 || D == 400; }
+
+// ---- counter-based dropout ------------------------------------------------------------------
+// One splitmix64 draw per group of 4 consecutive elements (every dropout site works on float4
+// groups); element j of group g is kept iff bits [16j, 16j+16) of the draw are >= p * 65536.
+// The same (seed, g) regenerates the mask in the backward pass: no mask tensor is stored.
+__device__ __forceinline__ uint64_t renet_mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+struct DropCfg {
+    uint32_t thresh;   // keep iff draw16 >= thresh ; 0 => keep everything
+    float scale;       // 1 / (1 - p)
+    uint64_t seed;
+};
+
+static inline DropCfg make_drop(float p, uint64_t seed) {
+    DropCfg d;
+    if (p <= 0.f) { d.thresh = 0; d.scale = 1.f; }
+    else { d.thresh = (uint32_t)(p * 65536.f + 0.5f); d.scale = 1.f / (1.f - p); }
+    d.seed = seed;
+    return d;
+}
+
+// returns the 4 multipliers (0 or scale) of group g
+__device__ __forceinline__ float4 renet_drop4(const DropCfg& d, uint64_t g) {
+    if (d.thresh == 0) return make_float4(1.f, 1.f, 1.f, 1.f);
+    uint64_t r = renet_mix64(d.seed * 0xD1342543DE82EF95ull + g);
+    float4 m;
+    m.x = ((uint32_t)(r) & 0xFFFFu) >= d.thresh ? d.scale : 0.f;
+    m.y = ((uint32_t)(r >> 16) & 0xFFFFu) >= d.thresh ? d.scale : 0.f;
+    m.z = ((uint32_t)(r >> 32) & 0xFFFFu) >= d.thresh ? d.scale : 0.f;
+    m.w = ((uint32_t)(r >> 48) & 0xFFFFu) >= d.thresh ? d.scale : 0.f;
+    return m;
+}
+
+__device__ __forceinline__ float4 f4_mul(float4 a, float4 b) {
+    return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 f4_scale(float4 a, float s) {
+    return make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
+}
+
+// XCD-aware virtual block id: the dispatcher places block b on XCD b % 8 (observed, speed only);
+// remapping gives every XCD one contiguous slice of the row space so that neighbouring rows
+// (same member graph => shared source rows) hit the same per-XCD L2.
+__device__ __forceinline__ int renet_xcd_block(int b, int nb) {
+    return (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+}

@@ -1,0 +1,263 @@
+// fp32 GEMM on the f32-input matrix cores of gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, i.e. a
+// k-ordered fmaf chain, at the 157 TF/s vector-equivalent rate).  128x128x32 workgroup tile, 4 waves
+// in a 2x2 arrangement, each wave 2x2 MFMA tiles of 32x32 (64 accumulator registers per lane).
+// Operands are staged global -> registers -> LDS in a k-major image As[k][m] / Bs[k][n] so that the
+// MFMA operand fetch (lane l reads element [k = l>>5][i = l&31]) is a conflict-free ds_read_b32 of
+// 32 consecutive floats per half-wave, whatever the storage order of A and B.  The global loads for
+// tile t+1 are issued before the MFMAs of tile t (register double buffer).
+//
+// Used for: the RGCN self-loop h @ W_loop (RGCN.py:35), the GRU input projections (inside nn.GRU,
+// model.py:86,94), the score heads (model.py:89-90,98-99) and all their backward GEMMs
+// (dX = dY W, dW = dY^T X with deterministic split-K).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDS_LD = BM + 1;          // +1: conflict-free transposing ds_write_b32 (see header)
+constexpr int THREADS = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int M, N, K, lda, ldb, ldc;
+    float alpha, beta;
+    int k_tiles_per_split;      // in units of BK
+    int split_k;
+    float* partial;             // [split_k, M, N] when split_k > 1
+};
+
+// Loads one BM(or BN) x BK operand tile into 4 float4 registers per thread.
+//  CONTIG_K = true : storage is [rows, K] (k contiguous): float4 along k; thread f -> row f/8, kq f%8
+//  CONTIG_K = false: storage is [K, rows] (row index contiguous): float4 along rows; f -> k f/32, rq f%32
+template <bool CONTIG_K>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int rows, int K, int row0,
+                                          int k0, int tid, bool vec_ok, float4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + THREADS * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (CONTIG_K) {
+            const int row = row0 + (f >> 3), k = k0 + ((f & 7) << 2);
+            if (row < rows) {
+                const float* p = P + (size_t)row * ld + k;
+                if (vec_ok && k + 3 < K) v = *reinterpret_cast<const float4*>(p);
+                else {
+                    if (k < K) v.x = p[0];
+                    if (k + 1 < K) v.y = p[1];
+                    if (k + 2 < K) v.z = p[2];
+                    if (k + 3 < K) v.w = p[3];
+                }
+            }
+        } else {
+            const int k = k0 + (f >> 5), row = row0 + ((f & 31) << 2);
+            if (k < K) {
+                const float* p = P + (size_t)k * ld + row;
+                if (vec_ok && row + 3 < rows) v = *reinterpret_cast<const float4*>(p);
+                else {
+                    if (row < rows) v.x = p[0];
+                    if (row + 1 < rows) v.y = p[1];
+                    if (row + 2 < rows) v.z = p[2];
+                    if (row + 3 < rows) v.w = p[3];
+                }
+            }
+        }
+        r[i] = v;
+    }
+}
+
+template <bool CONTIG_K>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const float4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + THREADS * i;
+        if constexpr (CONTIG_K) {
+            const int row = f >> 3, k = (f & 7) << 2;
+            S[(k + 0) * LDS_LD + row] = r[i].x;
+            S[(k + 1) * LDS_LD + row] = r[i].y;
+            S[(k + 2) * LDS_LD + row] = r[i].z;
+            S[(k + 3) * LDS_LD + row] = r[i].w;
+        } else {
+            const int k = f >> 5, row = (f & 31) << 2;
+            S[k * LDS_LD + row + 0] = r[i].x;
+            S[k * LDS_LD + row + 1] = r[i].y;
+            S[k * LDS_LD + row + 2] = r[i].z;
+            S[k * LDS_LD + row + 3] = r[i].w;
+        }
+    }
+}
+
+// TA: A stored [K,M] (A^T);  TB: B stored [N,K] (B^T)
+template <bool TA, bool TB>
+__global__ __launch_bounds__(THREADS) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ float As[BK * LDS_LD];
+    __shared__ float Bs[BK * LDS_LD];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+    const int kt0 = z * g.k_tiles_per_split;
+    const int kt_total = (g.K + BK - 1) / BK;
+    const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
+
+    // A is k-contiguous when NOT transposed; B ([K,N] row-major) is n-contiguous when NOT transposed.
+    constexpr bool A_CK = !TA;
+    constexpr bool B_CK = TB;
+    const bool a_vec = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+    const bool b_vec = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[4], rb[4];
+    if (kt0 < kt1) {
+        load_tile<A_CK>(g.A, g.lda, g.M, g.K, m0, kt0 * BK, tid, a_vec, ra);
+        load_tile<B_CK>(g.B, g.ldb, g.N, g.K, n0, kt0 * BK, tid, b_vec, rb);
+    }
+    const int arow = wm * 64 + (lane & 31);
+    const int brow = wn * 64 + (lane & 31);
+    const int ksel = lane >> 5;
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+        __syncthreads();                       // previous tile fully consumed
+        store_tile<A_CK>(As, tid, ra);
+        store_tile<B_CK>(Bs, tid, rb);
+        __syncthreads();
+        if (kt + 1 < kt1) {                    // prefetch next tile while the MFMAs run
+            load_tile<A_CK>(g.A, g.lda, g.M, g.K, m0, (kt + 1) * BK, tid, a_vec, ra);
+            load_tile<B_CK>(g.B, g.ldb, g.N, g.K, n0, (kt + 1) * BK, tid, b_vec, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = As[(kk + ksel) * LDS_LD + arow];
+            const float a1 = As[(kk + ksel) * LDS_LD + arow + 32];
+            const float b0 = Bs[(kk + ksel) * LDS_LD + brow];
+            const float b1 = Bs[(kk + ksel) * LDS_LD + brow + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const bool split = g.split_k > 1;
+    float* Cout = split ? g.partial + (size_t)z * g.M * g.N : g.C;
+    const int ldo = split ? g.N : g.ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= g.N) continue;
+            const float bv = (!split && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * ksel;
+                if (row < g.M) {
+                    float* p = Cout + (size_t)row * ldo + col;
+                    if (split) *p = acc[i][j][r];
+                    else {
+                        float v = g.alpha * acc[i][j][r] + bv;
+                        if (g.beta != 0.f) v += g.beta * (*p);
+                        *p = v;
+                    }
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int split_k,
+                                                            int M, int N, float alpha, float beta,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ C, int ldc) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float s = 0.f;
+        for (int z = 0; z < split_k; ++z) s += partial[(size_t)z * total + i];
+        float v = alpha * s + (bias ? bias[n] : 0.f);
+        float* p = C + (size_t)m * ldc + n;
+        if (beta != 0.f) v += beta * (*p);
+        *p = v;
+    }
+}
+
+// out[n] = sum_m X[m,n]; block = 64 columns, 4 waves split the rows, LDS combine (deterministic)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ldx,
+                                                     float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (n < N) {
+        const int rows_per_wave = (M + 3) / 4;
+        const int m0 = wave * rows_per_wave, m1 = min(M, m0 + rows_per_wave);
+        for (int m = m0; m < m1; ++m) s += X[(size_t)m * ldx + n];
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && n < N) out[n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t renet_gemm_workspace(int M, int N, int split_k) {
+    return split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+int renet_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
+                   const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
+                   int split_k, float* workspace, size_t workspace_bytes, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || lda <= 0 || ldb <= 0 || ldc < N) return RENET_ERR_BADARG;
+    if (M == 0 || N == 0) return RENET_OK;
+    if (split_k < 1) split_k = 1;
+    const int kt_total = (K + BK - 1) / BK;
+    if (split_k > kt_total) split_k = max(kt_total, 1);
+    if (split_k > 1 && workspace_bytes < renet_gemm_workspace(M, N, split_k)) return RENET_ERR_WORKSPACE;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha; g.beta = beta;
+    g.split_k = split_k;
+    g.k_tiles_per_split = (kt_total + split_k - 1) / split_k;
+    if (g.k_tiles_per_split < 1) g.k_tiles_per_split = 1;
+    g.partial = workspace;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, split_k);
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(THREADS), 0, st, g);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(THREADS), 0, st, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(THREADS), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
+    RENET_LAUNCH_CHECK();
+    if (split_k > 1) {
+        const size_t total = (size_t)M * N;
+        int blocks = (int)min((size_t)2048, (total + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, split_k, M, N,
+                           alpha, beta, bias, C, ldc);
+        RENET_LAUNCH_CHECK();
+    }
+    return RENET_OK;
+}
+
+int renet_colsum(const float* X, int M, int N, int ldx, float* out, void* stream) {
+    if (M < 0 || N <= 0 || ldx < N) return RENET_ERR_BADARG;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, X, M, N, ldx,
+                       out);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,303 @@
+// Sequence assembly, score-head feature concat, fused softmax cross-entropy and the global model's
+// per-graph readout.  All element-wise / row-wise HBM-bound kernels: float4 lanes, fused dropout.
+#include "common.h"
+
+namespace {
+
+// ---- Aggregator.py:142-165: packed GRU inputs X [S,4D], Xr [S,3D] ----------------------------
+__global__ __launch_bounds__(256) void seq_assemble_fwd_kernel(
+    const float4* __restrict__ h2, const float4* __restrict__ ent, const float4* __restrict__ rel,
+    const float4* __restrict__ glob, const int32_t* __restrict__ subj_row,
+    const int32_t* __restrict__ row_ent, const int32_t* __restrict__ row_rel,
+    const int32_t* __restrict__ glob_row, int S, int CH, DropCfg dx, DropCfg dxr,
+    float4* __restrict__ X, float4* __restrict__ Xr) {
+    const size_t total = (size_t)S * 4 * CH;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / (4 * CH));
+        const int c = (int)(i - (size_t)p * 4 * CH);
+        const int part = c / CH, cc = c - part * CH;
+        float4 v;
+        if (part == 0) v = h2[(size_t)subj_row[p] * CH + cc];
+        else if (part == 1) v = ent[(size_t)row_ent[p] * CH + cc];
+        else if (part == 2) v = rel[(size_t)row_rel[p] * CH + cc];
+        else v = glob[(size_t)glob_row[p] * CH + cc];
+        X[i] = f4_mul(v, renet_drop4(dx, i));
+        if (part != 2) {                                   // Xr = [h2 | ent | glob]
+            const int cr = (part == 3 ? 2 : part) * CH + cc;
+            const size_t ir = (size_t)p * 3 * CH + cr;
+            Xr[ir] = f4_mul(v, renet_drop4(dxr, ir));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void seq_assemble_bwd_kernel(const float4* __restrict__ dX,
+                                                               const float4* __restrict__ dXr, int S,
+                                                               int CH, DropCfg dx, DropCfg dxr,
+                                                               float4* __restrict__ dRows,
+                                                               float4* __restrict__ dEntRow,
+                                                               float4* __restrict__ dRelRow) {
+    const size_t total = (size_t)S * CH;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / CH), cc = (int)(i - (size_t)p * CH);
+        const size_t bx = (size_t)p * 4 * CH, br = (size_t)p * 3 * CH;
+        float4 a = f4_mul(dX[bx + cc], renet_drop4(dx, bx + cc));
+        float4 b = f4_mul(dXr[br + cc], renet_drop4(dxr, br + cc));
+        dRows[i] = f4_add(a, b);
+        a = f4_mul(dX[bx + CH + cc], renet_drop4(dx, bx + CH + cc));
+        b = f4_mul(dXr[br + CH + cc], renet_drop4(dxr, br + CH + cc));
+        dEntRow[i] = f4_add(a, b);
+        dRelRow[i] = f4_mul(dX[bx + 2 * CH + cc], renet_drop4(dx, bx + 2 * CH + cc));
+    }
+}
+
+// ---- model.py:89-90 / 98-99: feat = drop([a[ia] | hmid | c[ic]]) -------------------------------
+__global__ __launch_bounds__(256) void concat3_fwd_kernel(const float4* __restrict__ a,
+                                                          const int32_t* __restrict__ ia,
+                                                          const float4* __restrict__ hmid,
+                                                          const float4* __restrict__ c,
+                                                          const int32_t* __restrict__ ic, int B, int CH,
+                                                          int parts, DropCfg d, float4* __restrict__ feat) {
+    const size_t total = (size_t)B * parts * CH;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / (parts * CH));
+        const int q = (int)(i - (size_t)b * parts * CH);
+        const int part = q / CH, cc = q - part * CH;
+        float4 v;
+        if (part == 0) v = a[(size_t)ia[b] * CH + cc];
+        else if (part == 1) v = hmid[(size_t)b * CH + cc];
+        else v = c[(size_t)ic[b] * CH + cc];
+        feat[i] = f4_mul(v, renet_drop4(d, i));
+    }
+}
+
+__global__ __launch_bounds__(256) void concat3_bwd_kernel(const float4* __restrict__ dfeat, int B, int CH,
+                                                          int parts, DropCfg d, float4* __restrict__ da,
+                                                          float4* __restrict__ dh, float4* __restrict__ dc) {
+    const size_t total = (size_t)B * parts * CH;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / (parts * CH));
+        const int q = (int)(i - (size_t)b * parts * CH);
+        const int part = q / CH, cc = q - part * CH;
+        const float4 v = f4_mul(dfeat[i], renet_drop4(d, i));
+        const size_t o = (size_t)b * CH + cc;
+        if (part == 0) da[o] = v;
+        else if (part == 1) dh[o] = v;
+        else dc[o] = v;
+    }
+}
+
+// ---- fused log-softmax + NLL (+ gradient) : one workgroup per row -----------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits,
+                                                         const int32_t* __restrict__ target, int C, int ld,
+                                                         float grad_scale, float* __restrict__ row_loss,
+                                                         float* __restrict__ dlogits) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* x = logits + (size_t)b * ld;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, x[c]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += expf(x[c] - m);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    const int t = target[b];
+    const float xt = x[t];                      // read before dlogits may overwrite (alias allowed)
+    __syncthreads();
+    if (threadIdx.x == 0) row_loss[b] = logf(s) + m - xt;
+    if (dlogits) {
+        float* dx = dlogits + (size_t)b * ld;
+        const float inv = 1.f / s;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float p = expf(x[c] - m) * inv;
+            dx[c] = (p - (c == t ? 1.f : 0.f)) * grad_scale;
+        }
+    }
+}
+
+// ---- dgl.max_nodes / mean_nodes (Aggregator.py:58-61) ------------------------------------------
+__global__ __launch_bounds__(256) void segment_pool_fwd_kernel(const float* __restrict__ h,
+                                                               const int32_t* __restrict__ seg_ptr, int D,
+                                                               int is_max, float* __restrict__ out,
+                                                               int32_t* __restrict__ argmax) {
+    __shared__ float rv[4][64];
+    __shared__ int ri[4][64];
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    const int r0 = seg_ptr[g], r1 = seg_ptr[g + 1];
+    float best = is_max ? -INFINITY : 0.f;
+    int bi = r0;
+    if (c < D) {
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const float v = h[(size_t)r * D + c];
+            if (is_max) { if (v > best) { best = v; bi = r; } }
+            else best += v;
+        }
+    }
+    rv[wave][lane] = best; ri[wave][lane] = bi;
+    __syncthreads();
+    if (wave == 0 && c < D) {
+        if (is_max) {
+            // first maximum in row order (wave w holds rows r0+w, r0+w+4, ...)
+            for (int w = 1; w < 4; ++w) {
+                const float v = rv[w][lane];
+                const int i = ri[w][lane];
+                if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+            }
+            out[(size_t)g * D + c] = best;
+            argmax[(size_t)g * D + c] = bi;
+        } else {
+            const float s = (rv[0][lane] + rv[1][lane]) + (rv[2][lane] + rv[3][lane]);
+            out[(size_t)g * D + c] = s / (float)max(r1 - r0, 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void segment_pool_bwd_kernel(const float* __restrict__ dout,
+                                                               const int32_t* __restrict__ seg_ptr,
+                                                               const int32_t* __restrict__ argmax, int D,
+                                                               int is_max, float* __restrict__ dh) {
+    const int g = blockIdx.x;
+    const int r0 = seg_ptr[g], r1 = seg_ptr[g + 1];
+    const int n = (r1 - r0) * D;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int r = r0 + i / D, c = i % D;
+        const float go = dout[(size_t)g * D + c];
+        float v;
+        if (is_max) v = (argmax[(size_t)g * D + c] == r) ? go : 0.f;
+        else v = go / (float)(r1 - r0);
+        dh[(size_t)r * D + c] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float4* __restrict__ x, size_t n4, DropCfg d,
+                                                      float4* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = f4_mul(x[i], renet_drop4(d, i));
+}
+
+inline int grid_for(size_t total) { return (int)max((size_t)1, min((size_t)2048, (total + 255) / 256)); }
+
+}  // namespace
+
+extern "C" {
+
+int renet_seq_assemble_fwd(const float* h2, const float* ent, const float* rel, const float* glob,
+                           const int32_t* subj_row, const int32_t* row_ent, const int32_t* row_rel,
+                           const int32_t* glob_row, int S, int D, float drop_p, uint64_t seed_x,
+                           uint64_t seed_xr, float* X, float* Xr, void* stream) {
+    if (S < 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f) return RENET_ERR_BADARG;
+    if (S == 0) return RENET_OK;
+    const int CH = D / 4;
+    hipLaunchKernelGGL(seq_assemble_fwd_kernel, dim3(grid_for((size_t)S * 4 * CH)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)h2, (const float4*)ent, (const float4*)rel,
+                       (const float4*)glob, subj_row, row_ent, row_rel, glob_row, S, CH,
+                       make_drop(drop_p, seed_x), make_drop(drop_p, seed_xr), (float4*)X, (float4*)Xr);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_seq_assemble_bwd(const float* dX, const float* dXr, int S, int D, float drop_p,
+                           uint64_t seed_x, uint64_t seed_xr, float* dRows, float* dEntRow,
+                           float* dRelRow, void* stream) {
+    if (S < 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f) return RENET_ERR_BADARG;
+    if (S == 0) return RENET_OK;
+    const int CH = D / 4;
+    hipLaunchKernelGGL(seq_assemble_bwd_kernel, dim3(grid_for((size_t)S * CH)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)dX, (const float4*)dXr, S, CH,
+                       make_drop(drop_p, seed_x), make_drop(drop_p, seed_xr), (float4*)dRows,
+                       (float4*)dEntRow, (float4*)dRelRow);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_concat3_fwd(const float* a, const int32_t* ia, const float* hmid, const float* c,
+                      const int32_t* ic, int B, int D, float drop_p, uint64_t seed, float* feat,
+                      void* stream) {
+    if (B < 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f) return RENET_ERR_BADARG;
+    if (B == 0) return RENET_OK;
+    const int CH = D / 4, parts = c ? 3 : 2;
+    hipLaunchKernelGGL(concat3_fwd_kernel, dim3(grid_for((size_t)B * parts * CH)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)a, ia, (const float4*)hmid, (const float4*)c, ic,
+                       B, CH, parts, make_drop(drop_p, seed), (float4*)feat);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_concat3_bwd(const float* dfeat, int B, int D, int parts, float drop_p, uint64_t seed,
+                      float* da_rows, float* dhmid, float* dc_rows, void* stream) {
+    if (B < 0 || D <= 0 || (D & 3) || (parts != 2 && parts != 3) || drop_p < 0.f || drop_p >= 1.f)
+        return RENET_ERR_BADARG;
+    if (B == 0) return RENET_OK;
+    const int CH = D / 4;
+    hipLaunchKernelGGL(concat3_bwd_kernel, dim3(grid_for((size_t)B * parts * CH)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)dfeat, B, CH, parts, make_drop(drop_p, seed),
+                       (float4*)da_rows, (float4*)dhmid, (float4*)dc_rows);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_dropout(const float* x, size_t n, float drop_p, uint64_t seed, float* y, void* stream) {
+    if ((n & 3) || drop_p < 0.f || drop_p >= 1.f) return RENET_ERR_BADARG;
+    if (n == 0) return RENET_OK;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x, n / 4, make_drop(drop_p, seed), (float4*)y);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_softmax_ce(const float* logits, const int32_t* target, int B, int C, int ld,
+                     float grad_scale, float* row_loss, float* dlogits, void* stream) {
+    if (B < 0 || C <= 0 || ld < C) return RENET_ERR_BADARG;
+    if (B == 0) return RENET_OK;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, target, C, ld,
+                       grad_scale, row_loss, dlogits);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_segment_pool_fwd(const float* h, const int32_t* seg_ptr, int G, int D, int is_max,
+                           float* out, int32_t* argmax, void* stream) {
+    if (G < 0 || D <= 0) return RENET_ERR_BADARG;
+    if (G == 0) return RENET_OK;
+    hipLaunchKernelGGL(segment_pool_fwd_kernel, dim3(G, (D + 63) / 64), dim3(256), 0, (hipStream_t)stream, h,
+                       seg_ptr, D, is_max, out, argmax);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_segment_pool_bwd(const float* dout, const int32_t* seg_ptr, const int32_t* argmax, int G,
+                           int D, int is_max, int N, float* dh, void* stream) {
+    (void)N;
+    if (G < 0 || D <= 0) return RENET_ERR_BADARG;
+    if (G == 0) return RENET_OK;
+    hipLaunchKernelGGL(segment_pool_bwd_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, dout, seg_ptr,
+                       argmax, D, is_max, dh);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,413 @@
+"""DGL-free graph format and the (host-side, vectorised) batch-graph builder.
+
+Replaces, for the hot path, the reference's use of DGL graph objects:
+  * `TimeGraph`          <- the per-timestamp DGLGraph of utils.py:68-87 (get_big_graph)
+  * `GraphStore`         <- graph_dict flattened into timestamp-indexed triple arrays
+  * `build_batch(...)`   <- utils.py:209-283 get_sorted_s_r_embed_rgcn / get_s_r_embed_rgcn +
+                            utils.py:115-131 make_subgraph + dgl.batch, i.e. ~T_b DGL subgraph
+                            calls and Python dict/set loops per pass, as a handful of numpy
+                            sort/searchsorted passes that emit directly what the HIP kernels
+                            consume: CSR-by-destination with relation-sorted rows, a relation-bucketed
+                            edge list for dW, the packed (time-major) sequence layout and the sorted
+                            plans for the deterministic segmented scatter-adds of the backward pass.
+
+Semantics kept from the reference: the subgraph at time t is induced on the union,
+over ALL sequences of the batch, of {subject} U {objects in the history step at t}; `norm` is
+1/in-degree of that induced subgraph.  Node order inside a member graph is by entity id (the
+reference's is set-iteration order; results do not depend on it).
+"""
+import numpy as np
+import torch
+
+CHUNK = 64          # edges per dW work item (one wave each)
+
+
+class TimeGraph(object):
+    """Per-timestamp multigraph.  `ent` sorted unique entity ids; facts as local triples (ls, r, lo);
+    both directions of every fact are implied: ls->lo with (type_s, type_o) = (r, r+R) and
+    lo->ls with (r+R, r)  (utils.py:74-76)."""
+    __slots__ = ('ent', 'ls', 'r', 'lo', 'num_rels', '_ids')
+
+    def __init__(self, ent, ls, r, lo, num_rels):
+        self.ent = np.ascontiguousarray(ent, dtype=np.int64)
+        self.ls = np.ascontiguousarray(ls, dtype=np.int64)
+        self.r = np.ascontiguousarray(r, dtype=np.int64)
+        self.lo = np.ascontiguousarray(lo, dtype=np.int64)
+        self.num_rels = int(num_rels)
+        self._ids = None
+
+    @classmethod
+    def from_triples(cls, triples, num_rels):
+        triples = np.asarray(triples, dtype=np.int64).reshape(-1, 3)
+        ent, inv = np.unique(np.stack((triples[:, 0], triples[:, 2])), return_inverse=True)
+        ls, lo = inv.reshape(2, -1)
+        return cls(ent, ls, triples[:, 1], lo, num_rels)
+
+    # -- small DGL-flavoured surface the reference's callers use on graph_dict entries ----------
+    def number_of_nodes(self):
+        return int(self.ent.shape[0])
+
+    def number_of_edges(self):
+        return 2 * int(self.ls.shape[0])
+
+    @property
+    def ids(self):
+        """entity id -> local node (the `g.ids` dict of utils.py:82-86), built on demand."""
+        if self._ids is None:
+            self._ids = dict(zip(self.ent.tolist(), range(len(self.ent))))
+        return self._ids
+
+    def edges(self, reverse=False):
+        """(src, dst, etype) of the directed edges; etype = type_o if reverse else type_s."""
+        src = np.concatenate((self.ls, self.lo))
+        dst = np.concatenate((self.lo, self.ls))
+        if reverse:
+            et = np.concatenate((self.r + self.num_rels, self.r))
+        else:
+            et = np.concatenate((self.r, self.r + self.num_rels))
+        return src, dst, et
+
+    def global_triples(self):
+        return self.ent[self.ls], self.r, self.ent[self.lo]
+
+    def __getstate__(self):
+        return (self.ent, self.ls, self.r, self.lo, self.num_rels)
+
+    def __setstate__(self, st):
+        self.ent, self.ls, self.r, self.lo, self.num_rels = st
+        self._ids = None
+
+
+class GraphStore(object):
+    """All per-timestamp graphs of a graph_dict as flat, timestamp-indexed triple arrays."""
+
+    def __init__(self, graph_dict):
+        self.times = np.asarray(list(graph_dict.keys()), dtype=np.int64)
+        self._sig = self.signature(graph_dict)
+        gs = [graph_dict[t] for t in graph_dict]
+        cnt = np.asarray([len(g.ls) for g in gs], dtype=np.int64)
+        self.trip_ptr = np.concatenate(([0], np.cumsum(cnt)))
+        if gs:
+            self.trip_s = np.concatenate([g.ent[g.ls] for g in gs])
+            self.trip_r = np.concatenate([g.r for g in gs])
+            self.trip_o = np.concatenate([g.ent[g.lo] for g in gs])
+        else:
+            self.trip_s = self.trip_r = self.trip_o = np.zeros(0, np.int64)
+        self.node_cnt = np.asarray([g.number_of_nodes() for g in gs], dtype=np.int64)
+        order = np.argsort(self.times, kind='stable')
+        self._sorted_times = self.times[order]
+        self._sorted_pos = order
+
+    @staticmethod
+    def signature(graph_dict):
+        return (id(graph_dict), len(graph_dict), tuple(id(g) for g in graph_dict.values()))
+
+    def matches(self, graph_dict):
+        return self._sig == self.signature(graph_dict)
+
+    def index_of(self, t):
+        p = np.searchsorted(self._sorted_times, t)
+        if np.any(p >= len(self._sorted_times)) or np.any(self._sorted_times[np.minimum(p, len(self._sorted_times) - 1)] != t):
+            raise KeyError('timestamp not in graph_dict')
+        return self._sorted_pos[p]
+
+
+_store_cache = {}
+
+
+def store_for(graph_dict):
+    key = id(graph_dict)
+    st = _store_cache.get(key)
+    if st is None or not st.matches(graph_dict):
+        st = GraphStore(graph_dict)
+        _store_cache.clear()          # one live graph_dict at a time is the norm
+        _store_cache[key] = st
+    return st
+
+
+def ragged_arange(starts, counts):
+    """concat([arange(s, s + c) for s, c in zip(starts, counts)]) without a Python loop."""
+    counts = np.asarray(counts, dtype=np.int64)
+    total = int(counts.sum())
+    if total == 0:
+        return np.zeros(0, np.int64)
+    ends = np.cumsum(counts)
+    base = np.repeat(np.asarray(starts, dtype=np.int64) - (ends - counts), counts)
+    return base + np.arange(total, dtype=np.int64)
+
+
+class FlatHistory(object):
+    """Histories of a list of sequences in flat arrays: sequence i owns steps
+    [seq_ptr[i], seq_ptr[i+1]); step k has timestamp step_t[k] and neighbour objects
+    nbr_o[nbr_ptr[k]:nbr_ptr[k+1]] (the (r, o) arrays of the reference, of which the RGCN path only
+    reads column 1, utils.py:153)."""
+    __slots__ = ('seq_ptr', 'step_t', 'nbr_ptr', 'nbr_o')
+
+    def __init__(self, seq_ptr, step_t, nbr_ptr, nbr_o):
+        self.seq_ptr = np.asarray(seq_ptr, dtype=np.int64)
+        self.step_t = np.asarray(step_t, dtype=np.int64)
+        self.nbr_ptr = np.asarray(nbr_ptr, dtype=np.int64)
+        self.nbr_o = np.asarray(nbr_o, dtype=np.int64)
+
+    @classmethod
+    def from_lists(cls, hist, hist_t):
+        """From the reference layout: hist[i] = list of np.ndarray[k,2]; hist_t[i] = list of t."""
+        lens = np.fromiter((len(h) for h in hist), dtype=np.int64, count=len(hist))
+        seq_ptr = np.concatenate(([0], np.cumsum(lens)))
+        steps = [a for h in hist for a in h]
+        if steps:
+            cnt = np.fromiter((len(a) for a in steps), dtype=np.int64, count=len(steps))
+            nbr_o = np.concatenate([np.asarray(a).reshape(-1, 2)[:, 1] for a in steps]).astype(np.int64)
+            step_t = np.fromiter((int(t) for ht in hist_t for t in ht), dtype=np.int64, count=len(steps))
+        else:
+            cnt = np.zeros(0, np.int64)
+            nbr_o = np.zeros(0, np.int64)
+            step_t = np.zeros(0, np.int64)
+        return cls(seq_ptr, step_t, np.concatenate(([0], np.cumsum(cnt))), nbr_o)
+
+    def __len__(self):
+        return len(self.seq_ptr) - 1
+
+    def take(self, idx):
+        """Sub-batch (sequence indices `idx`) as a new FlatHistory."""
+        idx = np.asarray(idx, dtype=np.int64)
+        lens = self.seq_ptr[idx + 1] - self.seq_ptr[idx]
+        steps = ragged_arange(self.seq_ptr[idx], lens)
+        cnt = self.nbr_ptr[steps + 1] - self.nbr_ptr[steps]
+        nb = ragged_arange(self.nbr_ptr[steps], cnt)
+        return FlatHistory(np.concatenate(([0], np.cumsum(lens))), self.step_t[steps],
+                           np.concatenate(([0], np.cumsum(cnt))), self.nbr_o[nb])
+
+
+class SegPlan(object):
+    """Sorted plan for renet_segment_add: rows `order[seg_ptr[u]:seg_ptr[u+1]]` all target `target[u]`."""
+    __slots__ = ('order', 'seg_ptr', 'target', 'num_segments')
+
+    @classmethod
+    def host(cls, idx):
+        idx = np.asarray(idx, dtype=np.int64)
+        p = cls()
+        p.order = np.argsort(idx, kind='stable').astype(np.int32)
+        srt = idx[p.order]
+        if len(srt):
+            first = np.concatenate(([True], srt[1:] != srt[:-1]))
+            starts = np.nonzero(first)[0]
+            p.target = srt[starts].astype(np.int32)
+            p.seg_ptr = np.concatenate((starts, [len(srt)])).astype(np.int32)
+        else:
+            p.target = np.zeros(0, np.int32)
+            p.seg_ptr = np.zeros(1, np.int32)
+        p.num_segments = int(len(p.target))
+        return p
+
+
+class HostBatch(object):
+    """Everything one direction of one training/inference batch needs, as numpy arrays."""
+    INT_FIELDS = ('node_ent', 'row_ptr', 'col', 'etype', 'e_src', 'e_dst', 'chunk_ptr', 'chunk_type',
+                  'type_chunk_ptr', 'subj_row', 'row_ent', 'row_rel', 'glob_row', 's_sorted', 'r_sorted')
+    PLANS = ('plan_node_ent', 'plan_subj_row', 'plan_row_ent', 'plan_row_rel', 'plan_s', 'plan_r')
+
+    def set_edges(self, n, src, dst, et, num_types):
+        """Directed edges (src -> dst, type et = type_s) -> the two device layouts:
+        CSR by destination with relation-sorted rows (gather-SpMM forward / backward-wrt-h) and the
+        relation-bucketed edge list cut into <= CHUNK-edge work items (backward-wrt-W)."""
+        src = np.asarray(src, dtype=np.int64)
+        dst = np.asarray(dst, dtype=np.int64)
+        et = np.asarray(et, dtype=np.int64)
+        E = len(src)
+        self.N, self.E, self.num_types = int(n), E, int(num_types)
+        order = np.lexsort((et, dst))
+        self.col = src[order].astype(np.int32)
+        self.etype = et[order].astype(np.int32)
+        deg = np.bincount(dst, minlength=n)
+        self.row_ptr = np.concatenate(([0], np.cumsum(deg))).astype(np.int32)
+        self.norm = (1.0 / np.maximum(deg, 1)).astype(np.float32)            # utils.py:89-93
+        order2 = np.argsort(et, kind='stable')
+        self.e_src = src[order2].astype(np.int32)
+        self.e_dst = dst[order2].astype(np.int32)
+        T = int(num_types)
+        tc = np.bincount(et, minlength=T)
+        tstart = np.concatenate(([0], np.cumsum(tc)))
+        nch = (tc + CHUNK - 1) // CHUNK
+        self.type_chunk_ptr = np.concatenate(([0], np.cumsum(nch))).astype(np.int32)
+        ctype = np.repeat(np.arange(T, dtype=np.int64), nch)
+        within = np.arange(int(nch.sum()), dtype=np.int64) - np.repeat(np.cumsum(nch) - nch, nch)
+        self.chunk_type = ctype.astype(np.int32)
+        self.chunk_ptr = np.concatenate((tstart[ctype] + within * CHUNK, [E])).astype(np.int32)
+        self.n_chunks = int(len(ctype))
+        return self
+
+    @classmethod
+    def from_edges(cls, n, src, dst, type_s, num_rels):
+        """A bare batch graph from explicit edge lists (tests, benchmarks)."""
+        return cls().set_edges(n, src, dst, type_s, 2 * num_rels)
+
+
+def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None):
+    """Vectorised restatement of utils.py:209-283 (+115-131,149-181).
+
+    store: GraphStore;  s, r: int arrays [B];  fh: FlatHistory of the B sequences;
+    Edge types are stored as type_s; the object-side pass (reverse, model.py:78) uses
+    type_o = (type_s + R) mod 2R, which the kernels apply as `type_shift`;
+    glob_index: callable mapping an int64 array of timestamps to rows of the global-embedding matrix.
+    Returns a HostBatch (numpy)."""
+    s = np.asarray(s, dtype=np.int64).reshape(-1)
+    r = np.asarray(r, dtype=np.int64).reshape(-1)
+    B = len(s)
+    lens_all = np.diff(fh.seq_ptr)
+    if sort:
+        perm = np.argsort(-lens_all, kind='stable')            # ONE permutation
+    else:
+        perm = np.arange(B)
+    lens_sorted = lens_all[perm]
+    nnz = int(np.count_nonzero(lens_sorted)) if sort else int(np.count_nonzero(lens_all))
+    ln = lens_sorted[:nnz]
+    if not sort and nnz and np.any(ln == 0):
+        raise ValueError('unsorted batches must have their non-empty histories first (utils.py:251-254)')
+    hb = HostBatch()
+    hb.B, hb.nnz, hb.perm, hb.lens = B, nnz, perm, ln
+    hb.num_types = 2 * num_rels
+    s_sorted, r_sorted = s[perm], r[perm]
+    hb.s_sorted, hb.r_sorted = s_sorted.astype(np.int32), r_sorted.astype(np.int32)
+    S = int(ln.sum())
+    hb.S = S
+    L = int(ln[0]) if (nnz and sort) else (int(ln.max()) if nnz else 0)
+    hb.L = L
+    if sort is False and nnz and np.any(np.diff(ln) > 0):
+        raise ValueError('packed layout needs non-increasing lengths')
+
+    # sequence-major step list (the order of node_ids_graph / global_emb_list, utils.py:172-181,223-226)
+    step_seq = np.repeat(np.arange(nnz, dtype=np.int64), ln)
+    step_idx = ragged_arange(fh.seq_ptr[perm[:nnz]], ln)
+    step_j = np.arange(S, dtype=np.int64) - np.repeat(np.cumsum(ln) - ln, ln)
+    t_k = fh.step_t[step_idx]
+    uniq_t, slot_k = np.unique(t_k, return_inverse=True)
+    Tb = len(uniq_t)
+    hb.graph_t = uniq_t
+
+    # node sets per timestamp: {subject} U {history objects}  (utils.py:149-156)
+    ncnt = fh.nbr_ptr[step_idx + 1] - fh.nbr_ptr[step_idx]
+    nb_flat = ragged_arange(fh.nbr_ptr[step_idx], ncnt)
+    key_subj = slot_k * num_ent + s_sorted[step_seq]
+    key_nbr = np.repeat(slot_k, ncnt) * num_ent + fh.nbr_o[nb_flat]
+    keys = np.unique(np.concatenate((key_subj, key_nbr)))
+    N = len(keys)
+    hb.N = N
+    hb.node_ent = (keys % num_ent).astype(np.int32)
+    node_slot = keys // num_ent
+    hb.graph_off = np.searchsorted(node_slot, np.arange(Tb + 1)).astype(np.int64)
+
+    # node-induced edges of every member graph (utils.py:115-131)
+    if Tb:
+        ti = store.index_of(uniq_t)
+        tcnt = store.trip_ptr[ti + 1] - store.trip_ptr[ti]
+        flat = ragged_arange(store.trip_ptr[ti], tcnt)
+        eslot = np.repeat(np.arange(Tb, dtype=np.int64), tcnt)
+        ks = eslot * num_ent + store.trip_s[flat]
+        ko = eslot * num_ent + store.trip_o[flat]
+        ps = np.minimum(np.searchsorted(keys, ks), N - 1)
+        po = np.minimum(np.searchsorted(keys, ko), N - 1)
+        keep = (keys[ps] == ks) & (keys[po] == ko)
+        ls, lo, rr = ps[keep], po[keep], store.trip_r[flat][keep]
+    else:
+        ls = lo = rr = np.zeros(0, np.int64)
+    src = np.concatenate((ls, lo))
+    dst = np.concatenate((lo, ls))
+    et = np.concatenate((rr, rr + num_rels))                          # type_s (utils.py:76)
+    E = len(src)
+    hb.E = E
+
+    hb.set_edges(N, src, dst, et, 2 * num_rels)
+
+    # packed (time-major) layout: row p = off[j] + i  <->  step j of sorted sequence i
+    bs = (ln[None, :] > np.arange(L)[:, None]).sum(axis=1) if L else np.zeros(0, np.int64)
+    off = np.concatenate(([0], np.cumsum(bs))).astype(np.int64)
+    hb.batch_sizes = bs.astype(np.int64)
+    hb.step_off = off.astype(np.int32)
+    p_of_k = off[step_j] + step_seq
+    inv = np.empty(S, dtype=np.int64)
+    inv[p_of_k] = np.arange(S)
+    hb.packed_from_seqmajor = inv                                    # packed row p -> seq-major k
+    subj_row_k = np.searchsorted(keys, key_subj)
+    hb.subj_row_seqmajor = subj_row_k
+    hb.subj_row = subj_row_k[inv].astype(np.int32)
+    hb.row_seq = step_seq[inv].astype(np.int32)
+    hb.row_ent = s_sorted[step_seq[inv]].astype(np.int32)
+    hb.row_rel = r_sorted[step_seq[inv]].astype(np.int32)
+    hb.step_t_packed = t_k[inv]
+    hb.glob_row = (glob_index(t_k[inv]) if glob_index is not None else np.zeros(S, np.int64)).astype(np.int32)
+
+    hb.plan_node_ent = SegPlan.host(hb.node_ent)
+    hb.plan_subj_row = SegPlan.host(hb.subj_row)
+    hb.plan_row_ent = SegPlan.host(hb.row_ent)
+    hb.plan_row_rel = SegPlan.host(hb.row_rel)
+    hb.plan_s = SegPlan.host(hb.s_sorted)
+    hb.plan_r = SegPlan.host(hb.r_sorted)
+    return hb
+
+
+def build_full_graphs(graph_dict, times):
+    """Disjoint union of the FULL graphs of `times` (Aggregator.py:44-55 / 87-98, global model)."""
+    hb = HostBatch()
+    gs = [graph_dict[int(t)] for t in times]
+    num_rels = gs[0].num_rels if gs else 0
+    cnt = np.asarray([g.number_of_nodes() for g in gs], dtype=np.int64)
+    off = np.concatenate(([0], np.cumsum(cnt)))
+    hb.seg_ptr = off.astype(np.int32)
+    hb.G = len(gs)
+    hb.N = int(off[-1])
+    hb.node_ent = (np.concatenate([g.ent for g in gs]) if gs else np.zeros(0, np.int64)).astype(np.int32)
+    srcs, dsts, ets = [], [], []
+    for g, o in zip(gs, off[:-1]):
+        a, b, c = g.edges(False)
+        srcs.append(a + o); dsts.append(b + o); ets.append(c)
+    src = np.concatenate(srcs) if gs else np.zeros(0, np.int64)
+    dst = np.concatenate(dsts) if gs else np.zeros(0, np.int64)
+    et = np.concatenate(ets) if gs else np.zeros(0, np.int64)
+    hb.set_edges(hb.N, src, dst, et, 2 * num_rels)
+    hb.plan_node_ent = SegPlan.host(hb.node_ent)
+    return hb
+
+
+class DeviceGraph(object):
+    """Device-resident view of a HostBatch: ONE int32 upload + ONE float32 upload, sliced into views."""
+
+    def __init__(self, hb, device):
+        ints, names, plan_names = [], [], []
+        for f in HostBatch.INT_FIELDS + ('seg_ptr',):
+            if hasattr(hb, f):
+                names.append(f)
+                ints.append(np.ascontiguousarray(getattr(hb, f), dtype=np.int32).reshape(-1))
+        for pn in HostBatch.PLANS:
+            if hasattr(hb, pn):
+                p = getattr(hb, pn)
+                plan_names.append(pn)
+                for sub in ('order', 'seg_ptr', 'target'):
+                    names.append(pn + '.' + sub)
+                    ints.append(np.ascontiguousarray(getattr(p, sub), dtype=np.int32).reshape(-1))
+        # keep every view 16-byte aligned
+        sizes = [len(a) for a in ints]
+        padded = [(n + 3) & ~3 for n in sizes]
+        buf = np.zeros(int(sum(padded)) + 4, dtype=np.int32)
+        offs, o = [], 0
+        for a, n, pn_ in zip(ints, sizes, padded):
+            buf[o:o + n] = a
+            offs.append(o)
+            o += pn_
+        dev = torch.from_numpy(buf).to(device, non_blocking=False)
+        self._buf = dev
+        views = {nm: dev[o_:o_ + n] for nm, o_, n in zip(names, offs, sizes)}
+        for nm in names:
+            if '.' not in nm:
+                setattr(self, nm, views[nm])
+        for pn in plan_names:
+            p = SegPlan()
+            p.order, p.seg_ptr, p.target = views[pn + '.order'], views[pn + '.seg_ptr'], views[pn + '.target']
+            p.num_segments = getattr(hb, pn).num_segments
+            setattr(self, pn, p)
+        self.norm = torch.from_numpy(hb.norm).to(device)
+        self.ndata = {}                  # 'h' lives here, as on the reference's DGL graph
+        for f in ('N', 'E', 'S', 'B', 'nnz', 'L', 'n_chunks', 'num_types', 'G'):
+            if hasattr(hb, f):
+                setattr(self, f, getattr(hb, f))
+        self.host = hb

@@ -1,0 +1,232 @@
+"""torch.autograd glue around the C-ABI kernels (renet_hip.py).  Each Function's forward AND backward
+run hand-written HIP kernels; torch only owns the tensors and wires the graph.  No CPU / eager
+fallback exists: on a non-HIP tensor these raise."""
+import ctypes
+
+import numpy as np
+import torch
+from torch.autograd import Function
+
+import renet_hip as K
+
+_seed_state = {'counter': 0}
+
+
+def next_seed():
+    """Fresh 63-bit seed for one dropout site, derived from torch's global seed (train.py:31 seeds it)."""
+    _seed_state['counter'] += 1
+    return (torch.initial_seed() * 0x9E3779B1 + _seed_state['counter'] * 0x85EBCA77) & 0x7FFFFFFFFFFFFFFF
+
+
+def auto_split_k(m, n, k):
+    """split-K factor for tall-skinny weight-gradient GEMMs: aim at ~2 workgroups per CU."""
+    tiles = ((m + 127) // 128) * ((n + 127) // 128)
+    if tiles >= 256:
+        return 1
+    ktiles = (k + 31) // 32
+    return int(max(1, min((512 + tiles - 1) // tiles, max(ktiles // 4, 1), 128)))
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class GatherRowsFn(Function):
+    """out = table[idx]  (utils.py:239 h0 = ent_embeds[id]); backward = deterministic segmented add."""
+
+    @staticmethod
+    def forward(ctx, table, idx, plan):
+        ctx.plan, ctx.shape = plan, table.shape
+        return K.gather_rows(_c(table), idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        d = torch.zeros(ctx.shape, device=g.device, dtype=torch.float32)
+        K.segment_add(_c(g), ctx.plan, d)
+        return d, None, None
+
+
+class RGCNLayerFn(Function):
+    """One RGCNBlockLayer (RGCN.py:33-51,79-94): self-loop GEMM + fused gather-SpMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, h, weight, loop_weight, g, reverse, relu, drop_p, seed):
+        h, weight, loop_weight = _c(h), _c(weight), _c(loop_weight)
+        shift = g.num_types // 2 if reverse else 0                     # type_o = type_s +- R (utils.py:75-76)
+        out = K.gemm(h, loop_weight)                                   # RGCN.py:35
+        K.rgcn_gather(h, g.row_ptr, g.col, g.etype, g.norm, weight, shift, False, out, drop_p, seed, relu, out)
+        ctx.g, ctx.relu, ctx.drop_p, ctx.seed, ctx.shift = g, relu, drop_p, seed, shift
+        ctx.save_for_backward(h, weight, loop_weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        h, weight, loop_weight, out = ctx.saved_tensors
+        g = ctx.g
+        g_out = _c(g_out)
+        n, d = h.shape
+        gn = torch.empty_like(h)
+        g_loop = torch.empty_like(h)
+        K.rgcn_bwd_prep(g_out, out, g.norm, ctx.relu, ctx.drop_p, ctx.seed, gn, g_loop)
+        dh = K.gemm(g_loop, loop_weight, tb=True)                      # g_loop @ W_loop^T
+        d_loop = K.gemm(h, g_loop, ta=True, split_k=auto_split_k(d, d, n))      # h^T @ g_loop
+        # dh += sum over out-edges W[type]^T gn[dst]  == same CSR rows, the PAIRED edge's type
+        pair_shift = (ctx.shift + g.num_types // 2) % g.num_types
+        K.rgcn_gather(gn, g.row_ptr, g.col, g.etype, None, weight, pair_shift, True, dh, 0.0, 0, False, dh)
+        d_w = torch.empty_like(weight)
+        K.rgcn_bwd_w(h, gn, g.e_src, g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr,
+                     g.num_types, ctx.shift, d_w)
+        return dh, d_w, d_loop, None, None, None, None, None
+
+
+class SeqAssembleFn(Function):
+    """Aggregator.py:139-165: packed GRU inputs X [S,4D], Xr [S,3D] with fused dropout."""
+
+    @staticmethod
+    def forward(ctx, h2, ent, rel, glob, g, drop_p, seed_x, seed_xr):
+        h2, ent, rel, glob = _c(h2), _c(ent), _c(rel), _c(glob)
+        x, xr = K.seq_assemble_fwd(h2, ent, rel, glob, g.subj_row, g.row_ent, g.row_rel, g.glob_row,
+                                   drop_p, seed_x, seed_xr)
+        ctx.g, ctx.drop_p, ctx.seeds = g, drop_p, (seed_x, seed_xr)
+        ctx.shapes = (h2.shape, ent.shape, rel.shape)
+        return x, xr
+
+    @staticmethod
+    def backward(ctx, dx, dxr):
+        g = ctx.g
+        d = ctx.shapes[0][1]
+        d_rows, d_ent_row, d_rel_row = K.seq_assemble_bwd(_c(dx), _c(dxr), d, ctx.drop_p, *ctx.seeds)
+        dev = dx.device
+        d_h2 = torch.zeros(ctx.shapes[0], device=dev, dtype=torch.float32)
+        K.segment_add(d_rows, g.plan_subj_row, d_h2)
+        d_ent = torch.zeros(ctx.shapes[1], device=dev, dtype=torch.float32)
+        K.segment_add(d_ent_row, g.plan_row_ent, d_ent)
+        d_rel = torch.zeros(ctx.shapes[2], device=dev, dtype=torch.float32)
+        K.segment_add(d_rel_row, g.plan_row_rel, d_rel)
+        return d_h2, d_ent, d_rel, None, None, None, None, None
+
+
+class GRUFn(Function):
+    """nn.GRU (1 layer, h0 = 0) on a packed sequence, returning h_n zero-padded to `total_rows`
+    (model.py:86-88).  x: [S, I] packed time-major; step_off: ctypes int32[L+1] on the host."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, step_off, total_rows):
+        x, w_ih, w_hh, b_ih, b_hh = _c(x), _c(w_ih), _c(w_hh), _c(b_ih), _c(b_hh)
+        hdim = w_hh.shape[1]
+        gi = K.gemm(x, w_ih, tb=True, bias=b_ih)                         # [S, 3H]
+        h_last, saved = K.gru_fwd(gi, step_off, hdim, w_hh, b_hh)
+        nnz = h_last.shape[0]
+        if total_rows > nnz:
+            full = torch.zeros(total_rows, hdim, device=x.device, dtype=torch.float32)
+            full[:nnz] = h_last
+        else:
+            full = h_last
+        ctx.step_off, ctx.nnz, ctx.hdim = step_off, nnz, hdim
+        ctx.save_for_backward(x, w_ih, w_hh, saved)
+        return full.unsqueeze(0)                 # h_n layout of nn.GRU: [1, B, H]
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, w_ih, w_hh, saved = ctx.saved_tensors
+        hdim, nnz = ctx.hdim, ctx.nnz
+        dh_last = _c(dh[0, :nnz])
+        d_gi, d_gh = K.gru_bwd(dh_last, ctx.step_off, hdim, w_hh, saved)
+        s = x.shape[0]
+        dx = K.gemm(d_gi, w_ih)                                          # [S, I]
+        d_wih = K.gemm(d_gi, x, ta=True, split_k=auto_split_k(3 * hdim, x.shape[1], s))
+        d_bih = K.colsum(d_gi)
+        h_prev = saved[:, 4 * hdim:]
+        d_whh = K.gemm(d_gh, h_prev, ta=True, split_k=auto_split_k(3 * hdim, hdim, s))
+        d_bhh = K.colsum(d_gh)
+        return dx, d_wih, d_whh, d_bih, d_bhh, None, None
+
+
+class HeadCEFn(Function):
+    """model.py:89-91 / 98-100: mean CE( Linear( dropout([a[ia] | hmid | c[ic]]) ), target ).
+    The logits never make a second HBM round trip as a separate softmax: the CE kernel turns them
+    into (softmax - onehot)/B in place, which the backward GEMMs then consume."""
+
+    @staticmethod
+    def forward(ctx, a, ia, hmid, c, ic, weight, bias, target, plan_a, plan_c, drop_p, seed):
+        a, hmid, weight, bias = _c(a), _c(hmid), _c(weight), _c(bias)
+        c = _c(c) if c is not None else None
+        b, d = hmid.shape
+        feat = K.concat3_fwd(a, ia, hmid, c, ic, drop_p, seed)
+        logits = K.gemm(feat, weight, tb=True, bias=bias)                # [B, C]
+        need_grad = any(ctx.needs_input_grad)
+        row_loss = K.softmax_ce(logits, target, 1.0 / b, need_grad)
+        ctx.meta = (d, 3 if c is not None else 2, drop_p, seed, plan_a, plan_c, a.shape,
+                    c.shape if c is not None else None)
+        if need_grad:
+            ctx.save_for_backward(feat, logits, weight)
+        return row_loss.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, dlogits, weight = ctx.saved_tensors
+        d, parts, drop_p, seed, plan_a, plan_c, a_shape, c_shape = ctx.meta
+        dfeat = K.gemm(dlogits, weight) * g                              # [B, parts*D]
+        d_w = K.gemm(dlogits, feat * g, ta=True, split_k=auto_split_k(weight.shape[0], weight.shape[1],
+                                                                      feat.shape[0]))
+        d_b = K.colsum(dlogits) * g
+        da_rows, dh, dc_rows = K.concat3_bwd(dfeat, d, parts, drop_p, seed)
+        d_a = torch.zeros(a_shape, device=g.device, dtype=torch.float32)
+        K.segment_add(da_rows, plan_a, d_a)
+        d_c = None
+        if parts == 3:
+            d_c = torch.zeros(c_shape, device=g.device, dtype=torch.float32)
+            K.segment_add(dc_rows, plan_c, d_c)
+        return d_a, None, dh, d_c, None, d_w, d_b, None, None, None, None, None
+
+
+class SegmentPoolFn(Function):
+    """dgl.max_nodes / mean_nodes over the member graphs (Aggregator.py:58-61)."""
+
+    @staticmethod
+    def forward(ctx, h, seg_ptr, num_graphs, is_max):
+        h = _c(h)
+        out, arg = K.segment_pool_fwd(h, seg_ptr, num_graphs, is_max)
+        ctx.meta = (seg_ptr, arg, num_graphs, is_max, h.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        seg_ptr, arg, num_graphs, is_max, n = ctx.meta
+        return K.segment_pool_bwd(_c(dout), seg_ptr, arg, num_graphs, is_max, n), None, None, None
+
+
+class DropoutFn(Function):
+    """Counter-based inverted dropout (Aggregator.py:69); the mask is regenerated in backward."""
+
+    @staticmethod
+    def forward(ctx, x, drop_p, seed):
+        ctx.meta = (drop_p, seed)
+        return K.dropout(_c(x), drop_p, seed)
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.dropout(_c(g), *ctx.meta), None, None
+
+
+class LinearFn(Function):
+    """y = x @ W^T + b on the MFMA GEMM (nn.Linear forward/backward; global_model.py:52)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, weight = _c(x), _c(weight)
+        ctx.save_for_backward(x, weight)
+        return K.gemm(x, weight, tb=True, bias=_c(bias))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = _c(g)
+        return (K.gemm(g, weight), K.gemm(g, x, ta=True, split_k=auto_split_k(weight.shape[0], weight.shape[1],
+                                                                               x.shape[0])), K.colsum(g))
+
+
+def host_offsets(step_off):
+    """int array -> ctypes int32 array kept alive by the caller (the GRU entry points read it on the host)."""
+    arr = np.ascontiguousarray(step_off, dtype=np.int32)
+    return (ctypes.c_int32 * len(arr))(*arr.tolist())

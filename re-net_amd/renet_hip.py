@@ -1,0 +1,287 @@
+"""ctypes binding of librenet_hip.so (include/renet_hip.h).  PyTorch-ROCm is only the owner of device
+memory and streams here: every function takes torch CUDA(HIP) tensors, checks dtype/contiguity,
+and passes raw device pointers + the current stream to the C ABI.
+
+There is NO fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'librenet_hip.so')
+
+_lib = None
+
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_void_p = ctypes.c_void_p
+c_size_t = ctypes.c_size_t
+c_u64 = ctypes.c_uint64
+
+_SIGNATURES = {
+    'renet_version': (c_int, []),
+    'renet_gather_rows': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'renet_segment_add': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'renet_rgcn_gather': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_int, c_int, c_void_p, c_float, c_u64, c_int, c_void_p, c_int, c_void_p]),
+    'renet_rgcn_bwd_prep': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_u64, c_int, c_int,
+                                    c_void_p, c_void_p, c_void_p]),
+    'renet_rgcn_bwd_w_workspace': (c_size_t, [c_int, c_int]),
+    'renet_rgcn_bwd_w': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'renet_gemm_workspace': (c_size_t, [c_int, c_int, c_int]),
+    'renet_gemm_f32': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
+                               c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'renet_colsum': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'renet_seq_assemble_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_void_p,
+                                       c_void_p]),
+    'renet_seq_assemble_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_u64, c_u64, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
+    'renet_gru_workspace': (c_size_t, [c_int, c_int]),
+    'renet_gru_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_size_t, c_void_p]),
+    'renet_gru_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_size_t, c_void_p]),
+    'renet_concat3_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                                  c_u64, c_void_p, c_void_p]),
+    'renet_concat3_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_u64, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
+    'renet_dropout': (c_int, [c_void_p, c_size_t, c_float, c_u64, c_void_p, c_void_p]),
+    'renet_softmax_ce': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                 c_void_p]),
+    'renet_segment_pool_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'renet_segment_pool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                       c_void_p]),
+}
+
+EXPORTS = sorted(_SIGNATURES)
+
+
+class RenetHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads librenet_hip.so (once).  Raises if it has not been built -- no CPU/torch fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RenetHipError('librenet_hip.so not built (%s); run `python re-net_amd/build.py` '
+                                '-- there is no fallback path' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)       # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if L.renet_version() != 1:
+            raise RenetHipError('ABI version mismatch')
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RenetHipError('%s failed with code %d' % (what, rc))
+
+
+def _f32(t, name='tensor'):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RenetHipError('%s must be a contiguous float32 device tensor' % name)
+    return t.data_ptr()
+
+
+def _i32(t, name='index'):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+        raise RenetHipError('%s must be a contiguous int32 device tensor' % name)
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---- thin typed wrappers -----------------------------------------------------------------------
+def gather_rows(table, idx, out=None):
+    n, d = idx.numel(), table.shape[1]
+    if out is None:
+        out = torch.empty(n, d, device=table.device, dtype=torch.float32)
+    _check(lib().renet_gather_rows(_f32(table), _i32(idx), n, d, _f32(out), _stream()), 'gather_rows')
+    return out
+
+
+def segment_add(src, plan, dst):
+    """dst[plan.target[u]] += sum of src rows listed in plan (deterministic)."""
+    _check(lib().renet_segment_add(_f32(src), _i32(plan.order), _i32(plan.seg_ptr), _i32(plan.target),
+                                   plan.num_segments, src.shape[1], _f32(dst), _stream()), 'segment_add')
+    return dst
+
+
+def rgcn_gather(x, row_ptr, col, etype, scale, weight, type_shift, transpose_w, addend, drop_p, seed,
+                relu, out):
+    n, d = x.shape[0], x.shape[1]
+    _check(lib().renet_rgcn_gather(_f32(x), d, _i32(row_ptr), _i32(col), _i32(etype), _f32(scale),
+                                   _f32(weight), weight.shape[0], type_shift, int(transpose_w),
+                                   _f32(addend), float(drop_p), int(seed), int(relu), _f32(out),
+                                   out.shape[0], _stream()), 'rgcn_gather')
+    return out
+
+
+def rgcn_bwd_prep(g_out, out, norm, relu, drop_p, seed, gn, g_loop):
+    n, d = g_out.shape
+    _check(lib().renet_rgcn_bwd_prep(_f32(g_out), _f32(out), _f32(norm), int(relu), float(drop_p),
+                                     int(seed), n, d, _f32(gn), _f32(g_loop), _stream()), 'rgcn_bwd_prep')
+
+
+def rgcn_bwd_w(x, gn, e_src, e_dst, chunk_ptr, chunk_type, n_chunks, type_chunk_ptr, num_types, type_shift,
+               dW):
+    d = x.shape[1]
+    nbytes = lib().renet_rgcn_bwd_w_workspace(n_chunks, d)
+    ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+    _check(lib().renet_rgcn_bwd_w(_f32(x), _f32(gn), _i32(e_src), _i32(e_dst), _i32(chunk_ptr),
+                                  _i32(chunk_type), n_chunks, _i32(type_chunk_ptr), num_types, type_shift, d,
+                                  _f32(dW), ws.data_ptr(), nbytes, _stream()), 'rgcn_bwd_w')
+    return dW
+
+
+def _ld(t):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RenetHipError('GEMM operands must be 2-D with unit inner stride')
+    return t.stride(0)
+
+
+def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, split_k=1):
+    """out = alpha * op(a) @ op(b) + bias + beta * out.  a/b may be row-strided views."""
+    if not (a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32):
+        raise RenetHipError('gemm operands must be float32 device tensors')
+    m, k = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
+    k2, n = (b.shape[1], b.shape[0]) if tb else (b.shape[0], b.shape[1])
+    if k != k2:
+        raise RenetHipError('gemm inner dimensions differ: %d vs %d' % (k, k2))
+    if out is None:
+        out = torch.empty(m, n, device=a.device, dtype=torch.float32)
+        if beta != 0.0:
+            raise RenetHipError('beta != 0 needs an output tensor')
+    ws_ptr, ws_bytes = None, 0
+    if split_k > 1:
+        ws_bytes = lib().renet_gemm_workspace(m, n, split_k)
+        ws = torch.empty(ws_bytes // 4, device=a.device, dtype=torch.float32)
+        ws_ptr = ws.data_ptr()
+    _check(lib().renet_gemm_f32(int(ta), int(tb), m, n, k, float(alpha), a.data_ptr(), _ld(a), b.data_ptr(),
+                                _ld(b), float(beta), out.data_ptr(), _ld(out), _f32(bias), split_k, ws_ptr,
+                                ws_bytes, _stream()), 'gemm_f32')
+    return out
+
+
+def colsum(x, out=None):
+    m, n = x.shape
+    if out is None:
+        out = torch.empty(n, device=x.device, dtype=torch.float32)
+    _check(lib().renet_colsum(x.data_ptr(), m, n, _ld(x), _f32(out), _stream()), 'colsum')
+    return out
+
+
+def seq_assemble_fwd(h2, ent, rel, glob, subj_row, row_ent, row_rel, glob_row, drop_p, seed_x, seed_xr):
+    s, d = subj_row.numel(), h2.shape[1]
+    x = torch.empty(s, 4 * d, device=h2.device, dtype=torch.float32)
+    xr = torch.empty(s, 3 * d, device=h2.device, dtype=torch.float32)
+    _check(lib().renet_seq_assemble_fwd(_f32(h2), _f32(ent), _f32(rel), _f32(glob), _i32(subj_row),
+                                        _i32(row_ent), _i32(row_rel), _i32(glob_row), s, d, float(drop_p),
+                                        int(seed_x), int(seed_xr), _f32(x), _f32(xr), _stream()),
+           'seq_assemble_fwd')
+    return x, xr
+
+
+def seq_assemble_bwd(dx, dxr, d, drop_p, seed_x, seed_xr):
+    s = dx.shape[0]
+    d_rows = torch.empty(s, d, device=dx.device, dtype=torch.float32)
+    d_ent = torch.empty(s, d, device=dx.device, dtype=torch.float32)
+    d_rel = torch.empty(s, d, device=dx.device, dtype=torch.float32)
+    _check(lib().renet_seq_assemble_bwd(_f32(dx), _f32(dxr), s, d, float(drop_p), int(seed_x), int(seed_xr),
+                                        _f32(d_rows), _f32(d_ent), _f32(d_rel), _stream()), 'seq_assemble_bwd')
+    return d_rows, d_ent, d_rel
+
+
+def gru_fwd(gi, step_off_host, hdim, w_hh, b_hh):
+    """gi [S,3H] packed; step_off_host: ctypes int32 array (L+1).  Returns (h_last[B,H], saved[S,5H])."""
+    L = len(step_off_host) - 1
+    s = gi.shape[0]
+    b = step_off_host[1] - step_off_host[0] if L > 0 else 0
+    h_last = torch.empty(b, hdim, device=gi.device, dtype=torch.float32)
+    saved = torch.empty(s, 5 * hdim, device=gi.device, dtype=torch.float32)
+    nbytes = lib().renet_gru_workspace(b, hdim)
+    ws = torch.empty(max(nbytes // 4, 1), device=gi.device, dtype=torch.float32)
+    _check(lib().renet_gru_fwd(_f32(gi), ctypes.cast(step_off_host, c_void_p), L, hdim, _f32(w_hh), _f32(b_hh),
+                               _f32(h_last), _f32(saved), ws.data_ptr(), nbytes, _stream()), 'gru_fwd')
+    return h_last, saved
+
+
+def gru_bwd(dh_last, step_off_host, hdim, w_hh, saved):
+    L = len(step_off_host) - 1
+    s = saved.shape[0]
+    b = dh_last.shape[0]
+    d_gi = torch.empty(s, 3 * hdim, device=saved.device, dtype=torch.float32)
+    d_gh = torch.empty(s, 3 * hdim, device=saved.device, dtype=torch.float32)
+    nbytes = lib().renet_gru_workspace(b, hdim)
+    ws = torch.empty(max(nbytes // 4, 1), device=saved.device, dtype=torch.float32)
+    _check(lib().renet_gru_bwd(_f32(dh_last), ctypes.cast(step_off_host, c_void_p), L, hdim, _f32(w_hh),
+                               _f32(saved), _f32(d_gi), _f32(d_gh), ws.data_ptr(), nbytes, _stream()), 'gru_bwd')
+    return d_gi, d_gh
+
+
+def concat3_fwd(a, ia, hmid, c, ic, drop_p, seed):
+    b, d = hmid.shape
+    parts = 3 if c is not None else 2
+    feat = torch.empty(b, parts * d, device=hmid.device, dtype=torch.float32)
+    _check(lib().renet_concat3_fwd(_f32(a), _i32(ia), _f32(hmid), _f32(c), _i32(ic), b, d, float(drop_p),
+                                   int(seed), _f32(feat), _stream()), 'concat3_fwd')
+    return feat
+
+
+def concat3_bwd(dfeat, d, parts, drop_p, seed):
+    b = dfeat.shape[0]
+    da = torch.empty(b, d, device=dfeat.device, dtype=torch.float32)
+    dh = torch.empty(b, d, device=dfeat.device, dtype=torch.float32)
+    dc = torch.empty(b, d, device=dfeat.device, dtype=torch.float32) if parts == 3 else None
+    _check(lib().renet_concat3_bwd(_f32(dfeat), b, d, parts, float(drop_p), int(seed), _f32(da), _f32(dh),
+                                   _f32(dc), _stream()), 'concat3_bwd')
+    return da, dh, dc
+
+
+def dropout(x, drop_p, seed):
+    y = torch.empty_like(x)
+    _check(lib().renet_dropout(_f32(x), x.numel(), float(drop_p), int(seed), _f32(y), _stream()), 'dropout')
+    return y
+
+
+def softmax_ce(logits, target, grad_scale, want_grad):
+    """Returns row_loss[B]; if want_grad, logits is OVERWRITTEN with (softmax - onehot) * grad_scale."""
+    b, c = logits.shape
+    row_loss = torch.empty(b, device=logits.device, dtype=torch.float32)
+    _check(lib().renet_softmax_ce(logits.data_ptr(), _i32(target), b, c, _ld(logits), float(grad_scale),
+                                  _f32(row_loss), logits.data_ptr() if want_grad else None, _stream()),
+           'softmax_ce')
+    return row_loss
+
+
+def segment_pool_fwd(h, seg_ptr, num_graphs, is_max):
+    d = h.shape[1]
+    out = torch.empty(num_graphs, d, device=h.device, dtype=torch.float32)
+    arg = torch.empty(num_graphs, d, device=h.device, dtype=torch.int32)
+    _check(lib().renet_segment_pool_fwd(_f32(h), _i32(seg_ptr), num_graphs, d, int(is_max), _f32(out),
+                                        _i32(arg), _stream()), 'segment_pool_fwd')
+    return out, arg
+
+
+def segment_pool_bwd(dout, seg_ptr, arg, num_graphs, is_max, n):
+    d = dout.shape[1]
+    dh = torch.empty(n, d, device=dout.device, dtype=torch.float32)
+    _check(lib().renet_segment_pool_bwd(_f32(dout), _i32(seg_ptr), _i32(arg), num_graphs, d, int(is_max), n,
+                                        _f32(dh), _stream()), 'segment_pool_bwd')
+    return dh

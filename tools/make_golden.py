@@ -120,23 +120,23 @@ def gen_prep(name):
 
 
 def gen_rgcn(d):
+    """RGCNBlockLayer on a node-induced subgraph (utils.make_subgraph) of a get_big_graph graph: the
+    structure RE-Net always feeds the layer -- both directions of every fact with paired types,
+    multi-edges, and nodes left with zero in-degree by the induction."""
     ref = ref_loader.load()
     rng = np.random.RandomState(100 + d)
-    n, e, num_rels = 48, 260, 7
-    src = rng.randint(0, n - 4, size=e)           # last 4 nodes never a source
-    dst = rng.randint(4, n, size=e)               # first 4 nodes have zero in-degree
-    src[:6] = src[6:12]; dst[:6] = dst[6:12]      # exact multi-edges
-    type_s = rng.randint(0, 2 * num_rels, size=e)
-    type_o = (type_s + num_rels) % (2 * num_rels)
-    g = ref.dgl.DGLGraph()
-    g.add_nodes(n)
-    g.add_edges(src, dst)
-    norm = ref.utils.comp_deg_norm(g)
-    g.edata['type_s'] = torch.LongTensor(type_s)
-    g.edata['type_o'] = torch.LongTensor(type_o)
-    g.ndata['norm'] = norm.view(-1, 1)
-    out = dict(src=src, dst=dst, type_s=type_s, type_o=type_o, n=n, num_rels=num_rels,
-               norm=norm.numpy().astype(np.float32))
+    num_ent, num_rels, m = 64, 7, 150
+    trip = np.stack((rng.randint(0, num_ent, m), rng.randint(0, num_rels, m), rng.randint(0, num_ent, m)), axis=1)
+    trip[:8] = trip[8:16]                              # exact duplicate facts -> multi-edges
+    with ref_loader.cpu_mode():
+        big = ref.utils.get_big_graph(trip, num_rels)
+        present = sorted(big.ids.keys())
+        keep = [e for e in present if rng.rand() < 0.75]
+        g = ref.utils.make_subgraph(big, keep)
+    n = g.number_of_nodes()
+    out = dict(src=g._src.numpy(), dst=g._dst.numpy(), type_s=g.edata['type_s'].numpy(),
+               type_o=g.edata['type_o'].numpy(), n=n, num_rels=num_rels,
+               norm=g.ndata['norm'].view(-1).numpy().astype(np.float32))
     p = fixtures.make_params(200 + d, {'weight': (2 * num_rels, d * d // 100), 'loop_weight': (d, d),
                                        'h': (n, d), 'gout': (n, d)}, scale=0.5)
     for relu in (0, 1):
