@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""Benchmark of the RE-Net hot path on MI355X: one "step" = one full training step on one batch of
+1024 quadruples -- both directions (train.py:136-137) of RGCN x2 -> sequence assembly -> GRU x2 ->
+score heads -> loss, backward, gradient all-reduce (N>1), clip (train.py:140) and Adam.
+
+Workload (BASELINE.json configs[1]): ICEWS18-shaped synthetic stream (re-net_amd/synth.py, seed 999),
+n_hidden=200, seq_len=10, batch=1024 per GPU, dropout 0.5, fp32, random-init weights.
+Inputs are device-resident when the timed region starts: the batch graphs / packed layouts of the
+W+K steps are prepared (host builder + one upload each) before it; the per-step host build time is
+reported separately (`host_build_ms`) and an end-to-end rate with the builder in the loop as
+`e2e_value`.  Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under
+torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 're-net_amd')
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--shape', default='ICEWS18')
+    ap.add_argument('--batch', type=int, default=1024)
+    ap.add_argument('--hidden', type=int, default=200)
+    ap.add_argument('--seq-len', type=int, default=10)
+    ap.add_argument('--dropout', type=float, default=0.5)
+    ap.add_argument('--cpu-steps', type=int, default=2, help='oracle steps timed for cpu_baseline (0 = skip)')
+    ap.add_argument('--e2e-steps', type=int, default=5)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write('WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run\n' % (world, args.gpus))
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(2)
+    assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU fallback exists)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    import renet_hip as K
+    K.lib()
+    import model as M
+    import parallel
+    import preprocess as P
+    import synth
+
+    # ---- workload ------------------------------------------------------------------------------
+    quads, num_ent, num_rels, unit = synth.make_stream(args.shape, seed=999)
+    graph_dict = P.build_graph_dict(quads, num_rels)
+    hist_s = P.HistoryIndex(quads, 's', history_len=args.seq_len)
+    hist_o = P.HistoryIndex(quads, 'o', history_len=args.seq_len)
+    np.random.seed(999)
+    torch.manual_seed(999)
+    net = M.RENet(num_ent, args.hidden, num_rels, dropout=args.dropout, seq_len=args.seq_len, num_k=1000)
+    gen = torch.Generator().manual_seed(7)
+    net.global_emb = {int(t): torch.randn(1, 1, args.hidden, generator=gen) * 0.1 for t in graph_dict}
+    net.to(dev)
+    net.train()
+    flat = parallel.FlatGrads(net)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)      # train.py:61
+    perm = np.random.RandomState(999).permutation(len(quads))
+
+    def prepare(step):
+        idx = parallel.shard_indices(perm, step, rank, world, args.batch)
+        b = quads[idx]
+        return (net.prepare(b, hist_s.take(idx), graph_dict, subject=True),
+                net.prepare(b, hist_o.take(idx), graph_dict, subject=False))
+
+    def train_step(ps, po):
+        loss = net.loss_prepared(ps) + net.loss_prepared(po)
+        loss.backward()
+        flat.allreduce_mean()
+        flat.clip_(1.0)
+        opt.step()
+        flat.zero()
+        return loss
+
+    n_total = args.warmup + args.steps
+    t0 = time.time()
+    prepared = [prepare(k) for k in range(n_total)]
+    torch.cuda.synchronize()
+    host_build_ms = (time.time() - t0) * 1e3 / max(n_total, 1)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        train_step(*prepared[k])
+    assert flat.check_views(), 'param.grad views were replaced'
+
+    timer = K.KernelTimer()
+    K.set_timer(timer)
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, n_total):
+        loss = train_step(*prepared[k])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    K.set_timer(None)
+    last_loss = float(loss.item())
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    value = args.batch * world * args.steps / elapsed
+
+    # ---- end-to-end rate with the host builder in the loop (extra, not `value`) -------------------
+    e2e = None
+    if args.e2e_steps > 0:
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(args.e2e_steps):
+            train_step(*prepare(n_total + k))
+        sync_all()
+        e2e = args.batch * world * args.e2e_steps / (time.perf_counter() - t0)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel class (HIP events recorded on the launch stream) ---------
+    stats = timer.summary()
+    g0 = prepared[args.warmup][0].g.host
+    kernels = {}
+    for name, st in stats.items():
+        ent = {'calls_per_step': st['calls'] / args.steps, 'avg_us': st['ms'] * 1e3 / max(st['calls'], 1),
+               'ms_per_step': st['ms'] / args.steps}
+        if st['flops']:
+            ent['tflops'] = st['flops'] / (st['ms'] * 1e-3) / 1e12
+        if st['bytes']:
+            ent['gbs'] = st['bytes'] / (st['ms'] * 1e-3) / 1e9
+        kernels[name] = ent
+    dom = max(stats, key=lambda n: stats[n]['ms']) if stats else None
+    roofline = None
+    if dom:
+        st = stats[dom]
+        if st['flops']:
+            ach = st['flops'] / (st['ms'] * 1e-3) / 1e12
+            roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TF,
+                        'unit': 'TFLOP/s', 'frac': ach / MFMA_F32_PEAK_TF, 'traffic': None}
+        else:
+            ach = st['bytes'] / (st['ms'] * 1e-3) / 1e9
+            roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': ach / HBM_PEAK_GBS, 'traffic': None}
+    gather = None
+    if 'rgcn_gather' in stats:
+        st = stats['rgcn_gather']
+        ach = st['bytes'] / (st['ms'] * 1e-3) / 1e9
+        gather = {'kernel': 'rgcn_gather', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                  'frac': ach / HBM_PEAK_GBS, 'traffic': None, 'avg_us': st['ms'] * 1e3 / st['calls'],
+                  'algorithmic_bytes_per_launch': st['bytes'] / st['calls']}
+
+    # ---- CPU baseline: the oracle (restated reference path) on this box's host cores -------------
+    cpu = None
+    if args.cpu_steps > 0 and world == 1:
+        cpu = cpu_baseline(args, quads, num_ent, num_rels, hist_s, hist_o, net, perm)
+
+    out = {
+        'metric': 'RGCN+GRU encoder triples/s at bs=1024 n_hidden=200 (full training step, both directions)',
+        'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s-shaped synthetic stream (seed 999), n_hidden=%d, seq_len=%d, batch=%d per GPU, '
+                               'dropout=%.2f, fwd+bwd both directions + clip + Adam' %
+                               (args.shape, args.hidden, args.seq_len, args.batch, args.dropout),
+                   'num_entities': num_ent, 'num_relations': num_rels, 'parallelism': 'dp%d' % world,
+                   'batch_graph': {'nodes': int(g0.N), 'edges': int(g0.E), 'history_steps': int(g0.S),
+                                   'nonempty': int(g0.nnz)}},
+        'roofline': roofline, 'roofline_rgcn_gather': gather, 'kernels': kernels, 'cpu_baseline': cpu,
+        'host_build_ms': host_build_ms, 'e2e_value': e2e, 'last_loss': last_loss,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, quads, num_ent, num_rels, hist_s, hist_o, net, perm):
+    """Times the oracle (oracle/renet_oracle.py: the reference's algorithm restated on torch-CPU) on a
+    bounded sample of the SAME workload: `cpu_steps` training steps (forward both directions +
+    backward) at the same batch size.  Reported baseline, not a target."""
+    from oracle import renet_oracle as O
+    import parallel
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    ge = {t: v.view(-1).cpu() for t, v in net.global_emb.items()}
+    ogd = O.build_graph_dict(quads, num_rels)
+    times = []
+    for k in range(args.cpu_steps + 1):
+        idx = parallel.shard_indices(perm, 1000 + k, 0, 1, args.batch)
+        hs, hst = hist_s.to_lists(idx)
+        ho, hot = hist_o.to_lists(idx)
+        t0 = time.perf_counter()
+        loss = O.renet_forward_loss(params, quads[idx], hs, hst, ogd, ge, num_rels, args.seq_len, subject=True) + \
+            O.renet_forward_loss(params, quads[idx], ho, hot, ogd, ge, num_rels, args.seq_len, subject=False)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        for p in params.values():
+            p.grad = None
+    t = float(np.mean(times[1:])) if len(times) > 1 else times[0]
+    return {'value': args.batch / t, 'unit': 'triples/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+            'host_cpus': os.cpu_count(),
+            'sample': '%d training steps (fwd both directions + bwd, eval-mode dropout) of batch %d after 1 warm-up, '
+                      'oracle/renet_oracle.py on torch-CPU' % (args.cpu_steps, args.batch)}
+
+
+if __name__ == '__main__':
+    main()

@@ -103,40 +103,65 @@ class RENet(nn.Module):
             return triplets[:, 0], triplets[:, 1], triplets[:, 2], self.rel_embeds[:self.num_rels], False
         return triplets[:, 2], triplets[:, 1], triplets[:, 0], self.rel_embeds[self.num_rels:], True
 
+    def prepare(self, triplets, hist, graph_dict, subject=True):
+        """Host half of one direction of a training step: batch graph + packed layout + plans, uploaded
+        once (graph.DeviceGraph).  Everything `loss_prepared` needs is device-resident afterwards, so an
+        input pipeline can run this ahead of the step (bench.py does).  hist: (histories, timestamps) in
+        the reference's nested-list layout, or a graph.FlatHistory."""
+        trip = triplets.detach().cpu().numpy() if isinstance(triplets, torch.Tensor) else np.asarray(triplets)
+        s, r, o, _, _ = self._direction(trip, subject)
+        dev = self.ent_embeds.device
+        prep = PreparedBatch()
+        prep.subject, prep.b = bool(subject), len(s)
+        g = self.aggregator.build(hist, s, r, self.ent_embeds, graph_dict, self.global_emb, sort=True)
+        prep.g = g
+        if g is None:       # every history empty: the reference crashes here (SURVEY quirk 1); use h = 0
+            perm = np.arange(len(s))
+            prep.s_idx = torch.from_numpy(s.astype(np.int32)).to(dev)
+            prep.r_idx = torch.from_numpy(r.astype(np.int32)).to(dev)
+            prep.plan_s, prep.plan_r = _device_plan(s, dev), _device_plan(r, dev)
+        else:
+            perm = g.host.perm
+            prep.s_idx, prep.r_idx, prep.plan_s, prep.plan_r = g.s_sorted, g.r_sorted, g.plan_s, g.plan_r
+            prep.batch_sizes = torch.from_numpy(g.host.batch_sizes)
+        prep.perm = perm
+        prep.o_idx = torch.from_numpy(o[perm].astype(np.int32)).to(dev)
+        return prep
+
+    def loss_prepared(self, prep):
+        """Device half (model.py:82-103): RGCN x2 -> sequence assembly -> GRU x2 -> heads -> loss."""
+        subject = prep.subject
+        rel_embeds = self.rel_embeds[:self.num_rels] if subject else self.rel_embeds[self.num_rels:]
+        dev = self.ent_embeds.device
+        b, g = prep.b, prep.g
+        self.aggregator.last_batch = g
+        if g is None:
+            s_h = torch.zeros(b, self.h_dim, device=dev)
+            s_q = torch.zeros(b, self.h_dim, device=dev)
+        else:
+            x, xr = self.aggregator.encode(g, self.ent_embeds, rel_embeds, reverse=not subject)
+            _, s_h = self.encoder(PackedSequence(x, prep.batch_sizes), total_rows=b)      # model.py:86-88
+            _, s_q = self.encoder_r(PackedSequence(xr, prep.batch_sizes), total_rows=b)   # model.py:94-96
+            s_h, s_q = s_h[0], s_q[0]
+        p = self.drop_p if self.training else 0.0
+        loss_sub = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_h, rel_embeds, prep.r_idx,
+                                      self.linear.weight, self.linear.bias, prep.o_idx, prep.plan_s,
+                                      prep.plan_r, p, ops.next_seed() if p > 0 else 0)   # model.py:89-91
+        loss_r = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_q, None, None, self.linear_r.weight,
+                                    self.linear_r.bias, prep.r_idx, prep.plan_s, None, p,
+                                    ops.next_seed() if p > 0 else 0)                      # model.py:98-100
+        return loss_sub + 0.1 * loss_r                                                    # model.py:103
+
     def forward(self, triplets, s_hist, o_hist, graph_dict, subject=True):
         """Training loss of one direction (model.py:64-104): CE over objects + 0.1 * CE over relations.
         triplets: int tensor [B, >=3]; s_hist / o_hist: (histories, timestamps) in the reference's nested
         list layout, or graph.FlatHistory objects."""
-        trip = triplets.detach().cpu().numpy() if isinstance(triplets, torch.Tensor) else np.asarray(triplets)
-        s, r, o, rel_embeds, reverse = self._direction(trip, subject)
-        hist = s_hist if subject else o_hist
-        dev = self.ent_embeds.device
-        b = len(s)
-        px, pxr = self.aggregator(hist, s, r, self.ent_embeds, rel_embeds, graph_dict, self.global_emb,
-                                  reverse=reverse)
-        g = self.aggregator.last_batch
-        if g is None:       # every history empty: the reference crashes here (SURVEY quirk 1); use h = 0
-            perm = np.arange(b)
-            s_h = torch.zeros(b, self.h_dim, device=dev)
-            s_q = torch.zeros(b, self.h_dim, device=dev)
-            s_idx = torch.from_numpy(s.astype(np.int32)).to(dev)
-            r_idx = torch.from_numpy(r.astype(np.int32)).to(dev)
-            plan_s, plan_r = _device_plan(s, dev), _device_plan(r, dev)
-        else:
-            perm = g.host.perm
-            _, s_h = self.encoder(px, total_rows=b)                       # model.py:86-88
-            _, s_q = self.encoder_r(pxr, total_rows=b)                    # model.py:94-96
-            s_h, s_q = s_h[0], s_q[0]
-            s_idx, r_idx, plan_s, plan_r = g.s_sorted, g.r_sorted, g.plan_s, g.plan_r
-        o_idx = torch.from_numpy(o[perm].astype(np.int32)).to(dev)
-        p = self.drop_p if self.training else 0.0
-        loss_sub = ops.HeadCEFn.apply(self.ent_embeds, s_idx, s_h, rel_embeds, r_idx, self.linear.weight,
-                                      self.linear.bias, o_idx, plan_s, plan_r, p,
-                                      ops.next_seed() if p > 0 else 0)                    # model.py:89-91
-        loss_r = ops.HeadCEFn.apply(self.ent_embeds, s_idx, s_q, None, None, self.linear_r.weight,
-                                    self.linear_r.bias, r_idx, plan_s, None, p,
-                                    ops.next_seed() if p > 0 else 0)                      # model.py:98-100
-        return loss_sub + 0.1 * loss_r                                                    # model.py:103
+        return self.loss_prepared(self.prepare(triplets, s_hist if subject else o_hist, graph_dict, subject))
+
+
+class PreparedBatch(object):
+    """Device-resident inputs of one direction of one step (see RENet.prepare)."""
+    __slots__ = ('g', 'subject', 'b', 'perm', 's_idx', 'r_idx', 'o_idx', 'plan_s', 'plan_r', 'batch_sizes')
 
 
 def _device_plan(idx, device):

@@ -107,6 +107,41 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py) -----------
+class KernelTimer(object):
+    """Collects (start, stop) HIP events around C-ABI calls plus the ALGORITHMIC work of each call.
+    torch.cuda.Event records on torch's current stream, which is the stream the call launches on."""
+
+    def __init__(self):
+        self.recs = {}
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, name, e0, flops=0.0, nbytes=0.0):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.recs.setdefault(name, []).append((e0, e1, flops, nbytes))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, rs in self.recs.items():
+            out[name] = {'calls': len(rs), 'ms': sum(a.elapsed_time(b) for a, b, _, _ in rs),
+                         'flops': sum(r[2] for r in rs), 'bytes': sum(r[3] for r in rs)}
+        return out
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
 # ---- thin typed wrappers -----------------------------------------------------------------------
 def gather_rows(table, idx, out=None):
     n, d = idx.numel(), table.shape[1]
@@ -126,10 +161,17 @@ def segment_add(src, plan, dst):
 def rgcn_gather(x, row_ptr, col, etype, scale, weight, type_shift, transpose_w, addend, drop_p, seed,
                 relu, out):
     n, d = x.shape[0], x.shape[1]
+    t0 = _timer.begin() if _timer is not None else None
     _check(lib().renet_rgcn_gather(_f32(x), d, _i32(row_ptr), _i32(col), _i32(etype), _f32(scale),
                                    _f32(weight), weight.shape[0], type_shift, int(transpose_w),
                                    _f32(addend), float(drop_p), int(seed), int(relu), _f32(out),
                                    out.shape[0], _stream()), 'rgcn_gather')
+    if t0 is not None:
+        # algorithmic bytes: per edge one source row + src + type index; per node one output
+        # row + row_ptr + norm (+ the fused addend row); the relation weight table once
+        e, nn = col.numel(), out.shape[0]
+        nbytes = e * (d * 4 + 8) + nn * (d * 4 + 8) + weight.numel() * 4 + (nn * d * 4 if addend is not None else 0)
+        _timer.end('rgcn_gather', t0, nbytes=float(nbytes))
     return out
 
 
@@ -144,9 +186,12 @@ def rgcn_bwd_w(x, gn, e_src, e_dst, chunk_ptr, chunk_type, n_chunks, type_chunk_
     d = x.shape[1]
     nbytes = lib().renet_rgcn_bwd_w_workspace(n_chunks, d)
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
+    t0 = _timer.begin() if _timer is not None else None
     _check(lib().renet_rgcn_bwd_w(_f32(x), _f32(gn), _i32(e_src), _i32(e_dst), _i32(chunk_ptr),
                                   _i32(chunk_type), n_chunks, _i32(type_chunk_ptr), num_types, type_shift, d,
                                   _f32(dW), ws.data_ptr(), nbytes, _stream()), 'rgcn_bwd_w')
+    if t0 is not None:      # SURVEY 8d backward-W: E * 2 rows + indices, dW written once
+        _timer.end('rgcn_bwd_w', t0, nbytes=float(e_src.numel() * (2 * d * 4 + 8) + dW.numel() * 4))
     return dW
 
 
@@ -173,9 +218,12 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, spl
         ws_bytes = lib().renet_gemm_workspace(m, n, split_k)
         ws = torch.empty(ws_bytes // 4, device=a.device, dtype=torch.float32)
         ws_ptr = ws.data_ptr()
+    t0 = _timer.begin() if _timer is not None else None
     _check(lib().renet_gemm_f32(int(ta), int(tb), m, n, k, float(alpha), a.data_ptr(), _ld(a), b.data_ptr(),
                                 _ld(b), float(beta), out.data_ptr(), _ld(out), _f32(bias), split_k, ws_ptr,
                                 ws_bytes, _stream()), 'gemm_f32')
+    if t0 is not None:
+        _timer.end('gemm_f32', t0, flops=2.0 * m * n * k)
     return out
 
 

@@ -127,3 +127,40 @@ def test_utils_match_reference(tmp_path):
     assert np.array_equal(g1._src.numpy(), src) and np.array_equal(g1._dst.numpy(), dst)
     assert np.array_equal(g1.edata['type_s'].numpy(), et) and np.array_equal(g1.edata['type_o'].numpy(), g2.edges(True)[2])
     assert g1.ids == g2.ids
+
+
+@pytest.mark.parametrize('name', ['tiny', 'small'])
+def test_history_index_matches_oracle_streaming_builder(name):
+    """preprocess.HistoryIndex (vectorised snapshot ranges) vs the restated reference loop."""
+    import preprocess as P
+    cfg, tr, va, te = fixtures.split_dataset(name)
+    allq = np.concatenate((tr, va, te))
+    state = None
+    ref = {'s': ([], []), 'o': ([], [])}
+    for q in (tr, va, te):
+        (sh, sht), (oh, oht), state = O.build_histories(q, cfg['num_ent'], state=state)
+        ref['s'][0].extend(sh); ref['s'][1].extend(sht)
+        ref['o'][0].extend(oh); ref['o'][1].extend(oht)
+    for role in ('s', 'o'):
+        hi = P.HistoryIndex(allq, role, history_len=10)
+        mine = hi.to_lists(np.arange(len(allq)))
+        assert fixtures.histories_equal(mine, ref[role]), role
+        idx = np.array([len(allq) - 1, 5, len(allq) // 2, 0])
+        a = hi.take(idx)
+        b = G.FlatHistory.from_lists([ref[role][0][i] for i in idx], [ref[role][1][i] for i in idx])
+        for f in ('seq_ptr', 'step_t', 'nbr_ptr', 'nbr_o'):
+            assert np.array_equal(getattr(a, f), getattr(b, f))
+        c = hi.take(idx, max_len=3)
+        d = G.FlatHistory.from_lists([ref[role][0][i][-3:] for i in idx], [ref[role][1][i][-3:] for i in idx])
+        for f in ('seq_ptr', 'step_t', 'nbr_ptr', 'nbr_o'):
+            assert np.array_equal(getattr(c, f), getattr(d, f))
+
+
+def test_synthetic_stream_shape():
+    import synth
+    q, ne, nr, unit = synth.make_stream('ICEWS18', seed=999, num_t=12)
+    assert ne == 23033 and nr == 256 and unit == 24
+    assert np.all(np.diff(q[:, 3]) >= 0) and len(np.unique(q[:, 3])) == 12
+    assert q[:, 0].max() < ne and q[:, 1].max() < nr and 1000 < len(q) / 12 < 2200
+    q2, _, _, _ = synth.make_stream('ICEWS18', seed=999, num_t=12)
+    assert np.array_equal(q, q2)
