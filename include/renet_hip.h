@@ -107,8 +107,11 @@ int renet_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, const float
                    const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                    int split_k, float* workspace, size_t workspace_bytes, void* stream);
 
-/* column sums: out[n] = sum_m X[m,n]  (bias gradients) */
-int renet_colsum(const float* X, int M, int N, int ldx, float* out, void* stream);
+/* column sums: out[n] = sum_m X[m,n]  (bias gradients); two deterministic passes over row groups,
+ * `workspace` = renet_colsum_workspace(M, N) bytes (0 for short matrices). */
+size_t renet_colsum_workspace(int M, int N);
+int renet_colsum(const float* X, int M, int N, int ldx, float* out, float* workspace,
+                 size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sequence assembly (Aggregator.py:142-165): builds the GRU inputs directly in PACKED time-major
@@ -118,17 +121,19 @@ int renet_colsum(const float* X, int M, int N, int ldx, float* out, void* stream
  *   X [p,:] = drop([ h2[subj_row[p]] | ent[s[seq[p]]] | rel[r[seq[p]]] | glob[glob_row[p]] ])   (4D)
  *   Xr[p,:] = drop([ h2[subj_row[p]] | ent[s[seq[p]]] |                  glob[glob_row[p]] ])   (3D)
  * Masks are counter-based: keep(seed_x, p*4D+c), keep(seed_xr, p*3D+c).
- * Backward: dRows[p,:]  = grad wrt the gathered h2 row (X and Xr parts),
- *           dEntSeq[p,:], dRelSeq[p,:] = grad wrt ent[s] / rel[r] contributed by row p
- *           (the caller reduces them per sequence / entity with renet_segment_add).
+ * Backward: dRows[p,:]  = grad wrt the gathered h2 row of packed row p (X and Xr parts);
+ *           dEntSeq[i,:], dRelSeq[i,:] (i < B) = grad wrt ent[s_i] / rel[r_i] summed over the steps of
+ *           sequence i (packed row of step j = step_off[j] + i; step_off is a DEVICE array [L+1]);
+ *           rows of sequences without history come out zero.  The caller scatters the three with
+ *           renet_segment_add.
  * ---------------------------------------------------------------------------------------------- */
 int renet_seq_assemble_fwd(const float* h2, const float* ent, const float* rel, const float* glob,
                            const int32_t* subj_row, const int32_t* row_ent, const int32_t* row_rel,
                            const int32_t* glob_row, int S, int D, float drop_p, uint64_t seed_x,
                            uint64_t seed_xr, float* X, float* Xr, void* stream);
-int renet_seq_assemble_bwd(const float* dX, const float* dXr, int S, int D, float drop_p,
-                           uint64_t seed_x, uint64_t seed_xr, float* dRows, float* dEntRow,
-                           float* dRelRow, void* stream);
+int renet_seq_assemble_bwd(const float* dX, const float* dXr, const int32_t* step_off, int L, int S,
+                           int B, int D, float drop_p, uint64_t seed_x, uint64_t seed_xr, float* dRows,
+                           float* dEntSeq, float* dRelSeq, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GRU over the packed <= seq_len window (torch.nn.GRU semantics, 1 layer, h0 = 0, gate order r,z,n;

@@ -194,22 +194,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-// out[n] = sum_m X[m,n]; block = 64 columns, 4 waves split the rows, LDS combine (deterministic)
+// out[g, n] = sum over the rows of group g of X[m, n].  Block = 64 columns x one row group; the 4
+// waves take rows g0+w, g0+w+4, ... (4 independent loads in flight each), then a fixed-order LDS
+// combine => deterministic.  Two launches (row groups, then the groups) keep every CU busy on the
+// tall-skinny bias-gradient shapes ([7.6k, 600], [1024, 23033]).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ldx,
-                                                     float* __restrict__ out) {
+                                                     int rows_per_group, float* __restrict__ out) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
-    float s = 0.f;
+    const int g = blockIdx.y;
+    const int m0 = g * rows_per_group, m1 = min(M, m0 + rows_per_group);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (n < N) {
-        const int rows_per_wave = (M + 3) / 4;
-        const int m0 = wave * rows_per_wave, m1 = min(M, m0 + rows_per_wave);
-        for (int m = m0; m < m1; ++m) s += X[(size_t)m * ldx + n];
+        int m = m0 + wave;
+        for (; m + 12 < m1; m += 16) {
+            s0 += X[(size_t)m * ldx + n];
+            s1 += X[(size_t)(m + 4) * ldx + n];
+            s2 += X[(size_t)(m + 8) * ldx + n];
+            s3 += X[(size_t)(m + 12) * ldx + n];
+        }
+        for (; m < m1; m += 4) s0 += X[(size_t)m * ldx + n];
     }
-    red[wave][lane] = s;
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (wave == 0 && n < N) out[n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wave == 0 && n < N)
+        out[(size_t)g * N + n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
+
+inline int colsum_groups(int M) { return max(1, min(64, (M + 127) / 128)); }
 
 }  // namespace
 
@@ -252,10 +265,26 @@ int renet_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, const float
     return RENET_OK;
 }
 
-int renet_colsum(const float* X, int M, int N, int ldx, float* out, void* stream) {
+size_t renet_colsum_workspace(int M, int N) {
+    const int G = colsum_groups(M);
+    return G > 1 ? (size_t)G * (size_t)N * sizeof(float) : 0;
+}
+
+int renet_colsum(const float* X, int M, int N, int ldx, float* out, float* workspace,
+                 size_t workspace_bytes, void* stream) {
     if (M < 0 || N <= 0 || ldx < N) return RENET_ERR_BADARG;
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, X, M, N, ldx,
-                       out);
+    const int G = colsum_groups(M);
+    hipStream_t st = (hipStream_t)stream;
+    if (G == 1) {
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, st, X, M, N, ldx, max(M, 1), out);
+        RENET_LAUNCH_CHECK();
+        return RENET_OK;
+    }
+    if (workspace_bytes < renet_colsum_workspace(M, N)) return RENET_ERR_WORKSPACE;
+    const int rpg = (M + G - 1) / G;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, G), dim3(256), 0, st, X, M, N, ldx, rpg, workspace);
+    RENET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, st, workspace, G, N, N, G, out);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }

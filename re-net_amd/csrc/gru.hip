@@ -1,125 +1,323 @@
-// GRU recurrence over the packed <= seq_len history window (torch.nn.GRU semantics: 1 layer,
-// h0 = 0, gate order r,z,n; reference model.py:28-29,86,94 and global_model.py:25,49).
+// Fused GRU over the packed <= seq_len history window (torch.nn.GRU semantics: 1 layer, h0 = 0,
+// gate order r,z,n; reference model.py:28-29,86,94 and global_model.py:25,49).
 //
-// The input projection Gi = X W_ih^T + b_ih is one large GEMM done by the caller; here each step j
-// runs   Gh = H[0:bs_j] W_hh^T + b_hh   (MFMA GEMM, bs_j = sequences still alive at step j; the
-// batch is sorted by length so the live sequences are a prefix) followed by ONE fused gate kernel that
-// produces h_j in place and stashes (r, z, n, W_hn h + b_hn, h_prev) for the backward pass.
-// step_off lives on the host: the per-step loop is enqueued from C, not from Python.
+// The input projection Gi = X W_ih^T + b_ih is one large GEMM done by the caller.  The recurrence is ONE
+// persistent launch per direction of time: a workgroup owns 16 sequences (sequences are independent,
+// so there is no inter-workgroup traffic) and walks all their steps with the hidden state resident in
+// LDS.  Per step the 16 x 3H recurrent product h W_hh^T runs on the f32-input MFMA
+// (v_mfma_f32_16x16x4_f32, exact fp32): a wave owns blocks of 16 hidden units and accumulates the r, z
+// and n gates of the same (sequence, unit) pairs in three accumulators that share one C layout, so the
+// whole gate non-linearity is lane-local -- no G_h tensor, no per-step kernel boundary.
+// W_hh (<= 1.9 MB) is streamed from L2 every step as float4 B-fragments: a group of 4 MFMA k-steps
+// covers 16 consecutive k, lane (j, kq) holding k = 16*kg + 4*kq + {0..3} for both operands, which
+// turns both fragment fetches into 16-byte loads (ds_read_b128 for h, global_load_dwordx4 for W_hh).
+// The batch is length-sorted, so the sequences alive at step j are a prefix; rows past it are masked.
 #include "common.h"
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MT = 16;           // sequences per workgroup (MFMA M)
+constexpr int MAXL = 32;         // max packed steps (seq_len is 10 / 15 in the reference configs)
+
+struct StepOff {
+    int off[MAXL + 1];
+};
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
-__global__ __launch_bounds__(256) void gru_gate_fwd_kernel(const float* __restrict__ Gi,   // [bs,3H] rows of this step
-                                                           const float* __restrict__ Gh,   // [bs,3H]
-                                                           float* __restrict__ Hcur,       // [bs,H] in/out
-                                                           float* __restrict__ saved,      // [bs,5H]
-                                                           int bs, int H) {
-    const int total = bs * H;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int b = i / H, c = i - b * H;
-        const float* gi = Gi + (size_t)b * 3 * H;
-        const float* gh = Gh + (size_t)b * 3 * H;
-        const float r = sigmoidf_(gi[c] + gh[c]);
-        const float z = sigmoidf_(gi[H + c] + gh[H + c]);
-        const float hn = gh[2 * H + c];
-        const float n = tanhf(gi[2 * H + c] + r * hn);
-        const float hp = Hcur[i];
-        const float h = (1.f - z) * n + z * hp;
-        float* sv = saved + (size_t)b * 5 * H;
-        sv[c] = r; sv[H + c] = z; sv[2 * H + c] = n; sv[3 * H + c] = hn; sv[4 * H + c] = hp;
-        Hcur[i] = h;
+template <int H>
+struct Cfg {
+    static constexpr int NUB = (H + 15) / 16;          // blocks of 16 hidden units
+    static constexpr int KG = (H + 15) / 16;           // groups of 16 k over K = H
+    static constexpr int LDH = NUB * 16 + 4;           // LDS row stride of the h / dh tile (16 B aligned)
+    static constexpr int K3 = 3 * H;
+    static constexpr int KG3 = (K3 + 15) / 16;         // groups of 16 k over K = 3H (backward)
+    static constexpr int LDG = KG3 * 16 + 4;
+};
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ Gi, StepOff so, int L,
+                                                      const float* __restrict__ Whh,
+                                                      const float* __restrict__ bhh,
+                                                      float* __restrict__ h_last,
+                                                      float* __restrict__ saved) {
+    using C = Cfg<H>;
+    __shared__ __attribute__((aligned(16))) float Hs[MT * C::LDH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * MT;
+    const int B = so.off[1] - so.off[0];
+    for (int t = tid; t < MT * C::LDH; t += 256) Hs[t] = 0.f;          // h0 = 0 (and zero k-padding)
+    __syncthreads();
+
+    const int jj = lane & 15;          // B column / C column: hidden unit within the block
+    const int kq = lane >> 4;          // k quad within a 16-k group; C rows 4*kq .. 4*kq+3
+    const int ai = lane & 15;          // A row: sequence within the tile
+
+    for (int j = 0; j < L; ++j) {
+        const int p0 = so.off[j];
+        const int bs = so.off[j + 1] - p0;
+        if (i0 >= bs) break;                                            // whole tile finished (sorted batch)
+        f32x4 hnew[(C::NUB + 3) / 4];
+#pragma unroll
+        for (int q = 0; q < (C::NUB + 3) / 4; ++q) {
+            const int ub = wave + 4 * q;
+            if (ub < C::NUB) {
+                const int u = ub * 16 + jj;                             // this lane's hidden unit
+                const bool uok = u < H;
+                f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
+                const float* wr = Whh + (size_t)(uok ? u : 0) * H;
+                const float* wz = wr + (size_t)H * H;
+                const float* wn = wz + (size_t)H * H;
+#pragma unroll 4
+                for (int kg = 0; kg < C::KG; ++kg) {
+                    const int k = kg * 16 + 4 * kq;
+                    const float4 a = *reinterpret_cast<const float4*>(&Hs[ai * C::LDH + k]);
+                    float4 br = make_float4(0.f, 0.f, 0.f, 0.f), bz = br, bn = br;
+                    if (uok && k < H) {
+                        br = *reinterpret_cast<const float4*>(wr + k);
+                        bz = *reinterpret_cast<const float4*>(wz + k);
+                        bn = *reinterpret_cast<const float4*>(wn + k);
+                    }
+                    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, br.x, ar, 0, 0, 0);
+                    az = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bz.x, az, 0, 0, 0);
+                    an = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bn.x, an, 0, 0, 0);
+                    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, br.y, ar, 0, 0, 0);
+                    az = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bz.y, az, 0, 0, 0);
+                    an = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bn.y, an, 0, 0, 0);
+                    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, br.z, ar, 0, 0, 0);
+                    az = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bz.z, az, 0, 0, 0);
+                    an = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bn.z, an, 0, 0, 0);
+                    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, br.w, ar, 0, 0, 0);
+                    az = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bz.w, az, 0, 0, 0);
+                    an = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bn.w, an, 0, 0, 0);
+                }
+                // C layout: column = lane & 15 (unit u), row = 4 * (lane >> 4) + reg (sequence)
+                const float b_r = uok ? bhh[u] : 0.f, b_z = uok ? bhh[H + u] : 0.f, b_n = uok ? bhh[2 * H + u] : 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int i = 4 * kq + reg;
+                    const float hp = Hs[i * C::LDH + (uok ? u : 0)];
+                    float hv = hp;
+                    if (uok && i0 + i < bs) {
+                        const size_t p = (size_t)(p0 + i0 + i);
+                        const float* gi = Gi + p * C::K3;
+                        const float hn = an[reg] + b_n;
+                        const float r = sigmoidf_(gi[u] + ar[reg] + b_r);
+                        const float z = sigmoidf_(gi[H + u] + az[reg] + b_z);
+                        const float n = tanhf(gi[2 * H + u] + r * hn);
+                        hv = (1.f - z) * n + z * hp;
+                        float* sv = saved + p * 5 * H;
+                        sv[u] = r; sv[H + u] = z; sv[2 * H + u] = n; sv[3 * H + u] = hn; sv[4 * H + u] = hp;
+                    }
+                    hnew[q][reg] = hv;
+                }
+            }
+        }
+        __syncthreads();                                                // every wave is done reading Hs
+#pragma unroll
+        for (int q = 0; q < (C::NUB + 3) / 4; ++q) {
+            const int ub = wave + 4 * q;
+            const int u = ub * 16 + jj;
+            if (ub < C::NUB && u < H) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Hs[(4 * kq + reg) * C::LDH + u] = hnew[q][reg];
+            }
+        }
+        __syncthreads();
+    }
+    for (int t = tid; t < MT * H; t += 256) {
+        const int i = t / H, u = t - i * H;
+        if (i0 + i < B) h_last[(size_t)(i0 + i) * H + u] = Hs[i * C::LDH + u];
     }
 }
 
-__global__ __launch_bounds__(256) void gru_gate_bwd_kernel(const float* __restrict__ saved,  // [bs,5H]
-                                                           float* __restrict__ dh,           // [bs,H] in/out
-                                                           float* __restrict__ dGi,          // [bs,3H]
-                                                           float* __restrict__ dGh,          // [bs,3H]
-                                                           int bs, int H) {
-    const int total = bs * H;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int b = i / H, c = i - b * H;
-        const float* sv = saved + (size_t)b * 5 * H;
-        const float r = sv[c], z = sv[H + c], n = sv[2 * H + c], hn = sv[3 * H + c], hp = sv[4 * H + c];
-        const float g = dh[i];
-        const float dn = g * (1.f - z);
-        const float dz = g * (hp - n);
-        const float dan = dn * (1.f - n * n);
-        const float daz = dz * z * (1.f - z);
-        const float dar = dan * hn * r * (1.f - r);
-        float* gi = dGi + (size_t)b * 3 * H;
-        float* gh = dGh + (size_t)b * 3 * H;
-        gi[c] = dar; gi[H + c] = daz; gi[2 * H + c] = dan;
-        gh[c] = dar; gh[H + c] = daz; gh[2 * H + c] = dan * r;
-        dh[i] = g * z;                       // direct path h_prev -> h ; the W_hh path is added by the GEMM
+// ---------------------------------------------------------------------------------------------
+// backward (BPTT): dh lives in LDS; per step the gate gradients are formed element-wise, written out
+// as dGi / dGh rows (the caller turns them into dW_ih, dW_hh, dX with large GEMMs) and dGh is kept in
+// LDS as the A operand of   dh_prev = dh * z + dGh W_hh   (K = 3H, B fragments from W_hh^T [H, 3H]).
+// ---------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ dh_last, StepOff so, int L,
+                                                      const float* __restrict__ WhhT,   // [H, 3H]
+                                                      const float* __restrict__ saved,
+                                                      float* __restrict__ dGi, float* __restrict__ dGh) {
+    using C = Cfg<H>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dHs = smem;                         // [MT][LDH]
+    float* Gs = smem + MT * C::LDH;            // [MT][LDG]  dGh tile (k-padded with zeros)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * MT;
+    const int B = so.off[1] - so.off[0];
+    for (int t = tid; t < MT * C::LDH; t += 256) {
+        const int i = t / C::LDH, u = t - i * C::LDH;
+        dHs[t] = (u < H && i0 + i < B) ? dh_last[(size_t)(i0 + i) * H + u] : 0.f;
+    }
+    for (int t = tid; t < MT * C::LDG; t += 256) Gs[t] = 0.f;
+    __syncthreads();
+    const int jj = lane & 15, kq = lane >> 4, ai = lane & 15;
+
+    for (int j = L - 1; j >= 0; --j) {
+        const int p0 = so.off[j];
+        const int bs = so.off[j + 1] - p0;
+        if (i0 >= bs) continue;                                         // tile not alive yet at this step
+        // phase 1: gate gradients of the live rows
+        for (int t = tid; t < MT * H; t += 256) {
+            const int i = t / H, u = t - i * H;
+            float gr = 0.f, gz = 0.f, gn = 0.f;
+            if (i0 + i < bs) {
+                const size_t p = (size_t)(p0 + i0 + i);
+                const float* sv = saved + p * 5 * H;
+                const float r = sv[u], z = sv[H + u], n = sv[2 * H + u], hn = sv[3 * H + u], hp = sv[4 * H + u];
+                const float g = dHs[i * C::LDH + u];
+                const float dan = g * (1.f - z) * (1.f - n * n);
+                const float daz = g * (hp - n) * z * (1.f - z);
+                const float dar = dan * hn * r * (1.f - r);
+                float* gi = dGi + p * C::K3;
+                float* gh = dGh + p * C::K3;
+                gi[u] = dar; gi[H + u] = daz; gi[2 * H + u] = dan;
+                gr = dar; gz = daz; gn = dan * r;
+                gh[u] = gr; gh[H + u] = gz; gh[2 * H + u] = gn;
+                dHs[i * C::LDH + u] = g * z;                            // direct path h_prev -> h
+            }
+            Gs[i * C::LDG + u] = gr; Gs[i * C::LDG + H + u] = gz; Gs[i * C::LDG + 2 * H + u] = gn;
+        }
+        __syncthreads();
+        if (j > 0) {
+            // phase 2: dh_prev += dGh W_hh  (rows of dead sequences have dGh = 0 and keep their dh)
+#pragma unroll
+            for (int q = 0; q < (C::NUB + 3) / 4; ++q) {
+                const int ub = wave + 4 * q;
+                if (ub < C::NUB) {
+                    const int u = ub * 16 + jj;
+                    const bool uok = u < H;
+                    f32x4 acc;
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) acc[reg] = dHs[(4 * kq + reg) * C::LDH + (uok ? u : 0)];
+                    const float* wt = WhhT + (size_t)(uok ? u : 0) * C::K3;
+#pragma unroll 4
+                    for (int kg = 0; kg < C::KG3; ++kg) {
+                        const int k = kg * 16 + 4 * kq;
+                        const float4 a = *reinterpret_cast<const float4*>(&Gs[ai * C::LDG + k]);
+                        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (uok && k < C::K3) b = *reinterpret_cast<const float4*>(wt + k);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+                    }
+                    if (uok) {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) dHs[(4 * kq + reg) * C::LDH + u] = acc[reg];
+                    }
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
-inline int grid_for(int total) { return max(1, min(2048, (total + 255) / 256)); }
+// W_hh [3H, H] -> W_hh^T [H, 3H]  (tiny; once per backward call)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int rows, int cols,
+                                                        float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (int r = ty; r < 32; r += 8)
+        if (by + r < rows && bx + tx < cols) tile[r][tx] = in[(size_t)(by + r) * cols + bx + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (bx + r < cols && by + tx < rows) out[(size_t)(bx + r) * rows + by + tx] = tile[tx][r];
+}
+
+template <int H>
+int launch_fwd(const float* Gi, const StepOff& so, int L, int B, const float* Whh, const float* bhh,
+               float* h_last, float* saved, hipStream_t st) {
+    hipLaunchKernelGGL((gru_fwd_kernel<H>), dim3((B + MT - 1) / MT), dim3(256), 0, st, Gi, so, L, Whh, bhh,
+                       h_last, saved);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+template <int H>
+int launch_bwd(const float* dh_last, const StepOff& so, int L, int B, const float* WhhT, const float* saved,
+               float* dGi, float* dGh, hipStream_t st) {
+    using C = Cfg<H>;
+    const size_t lds = (size_t)MT * (C::LDH + C::LDG) * sizeof(float);
+    static bool attr_set = false;      // benign race: the attribute is idempotent
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gru_bwd_kernel<H>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gru_bwd_kernel<H>), dim3((B + MT - 1) / MT), dim3(256), lds, st, dh_last, so, L, WhhT,
+                       saved, dGi, dGh);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+bool fill_offsets(const int32_t* step_off, int L, StepOff& so, int& B) {
+    if (L < 1 || L > MAXL || !step_off) return false;
+    for (int j = 0; j <= L; ++j) so.off[j] = step_off[j];
+    for (int j = L + 1; j <= MAXL; ++j) so.off[j] = step_off[L];
+    B = step_off[1] - step_off[0];
+    for (int j = 1; j < L; ++j)                                   // batch sizes must be non-increasing
+        if (step_off[j + 1] - step_off[j] > step_off[j] - step_off[j - 1]) return false;
+    return B >= 0;
+}
 
 }  // namespace
 
 extern "C" {
 
 size_t renet_gru_workspace(int B, int H) {
-    return ((size_t)B * 3 * H + (size_t)B * H) * sizeof(float);
+    (void)B;
+    return (size_t)3 * H * H * sizeof(float);                     // W_hh^T for the backward pass
 }
 
 int renet_gru_fwd(const float* Gi, const int32_t* step_off, int L, int H, const float* Whh,
                   const float* bhh, float* h_last, float* saved, float* workspace,
                   size_t workspace_bytes, void* stream) {
-    if (L < 0 || H <= 0 || !step_off) return RENET_ERR_BADARG;
+    (void)workspace; (void)workspace_bytes;
     if (L == 0) return RENET_OK;
-    const int B = step_off[1] - step_off[0];
-    if (B <= 0) return RENET_OK;
-    if (workspace_bytes < renet_gru_workspace(B, H)) return RENET_ERR_WORKSPACE;
+    StepOff so;
+    int B;
+    if (!fill_offsets(step_off, L, so, B)) return RENET_ERR_BADARG;
+    if (B == 0) return RENET_OK;
     hipStream_t st = (hipStream_t)stream;
-    float* Gh = workspace;
-    hipError_t e = hipMemsetAsync(h_last, 0, (size_t)B * H * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-    for (int j = 0; j < L; ++j) {
-        const int p0 = step_off[j], bs = step_off[j + 1] - step_off[j];
-        if (bs <= 0) break;
-        if (bs > B) return RENET_ERR_BADARG;      // batch sizes must be non-increasing
-        int rc = renet_gemm_f32(0, 1, bs, 3 * H, H, 1.f, h_last, H, Whh, H, 0.f, Gh, 3 * H, bhh, 1,
-                                nullptr, 0, stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3(grid_for(bs * H)), dim3(256), 0, st,
-                           Gi + (size_t)p0 * 3 * H, Gh, h_last, saved + (size_t)p0 * 5 * H, bs, H);
-        RENET_LAUNCH_CHECK();
+    switch (H) {
+        case 100: return launch_fwd<100>(Gi, so, L, B, Whh, bhh, h_last, saved, st);
+        case 200: return launch_fwd<200>(Gi, so, L, B, Whh, bhh, h_last, saved, st);
+        case 400: return launch_fwd<400>(Gi, so, L, B, Whh, bhh, h_last, saved, st);
+        default: return RENET_ERR_UNSUPPORTED;
     }
-    return RENET_OK;
 }
 
 int renet_gru_bwd(const float* dh_last, const int32_t* step_off, int L, int H, const float* Whh,
                   const float* saved, float* dGi, float* dGh, float* workspace,
                   size_t workspace_bytes, void* stream) {
-    if (L < 0 || H <= 0 || !step_off) return RENET_ERR_BADARG;
     if (L == 0) return RENET_OK;
-    const int B = step_off[1] - step_off[0];
-    if (B <= 0) return RENET_OK;
+    StepOff so;
+    int B;
+    if (!fill_offsets(step_off, L, so, B)) return RENET_ERR_BADARG;
+    if (B == 0) return RENET_OK;
+    if (H != 100 && H != 200 && H != 400) return RENET_ERR_UNSUPPORTED;
     if (workspace_bytes < renet_gru_workspace(B, H)) return RENET_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    float* dh = workspace + (size_t)B * 3 * H;
-    hipError_t e = hipMemcpyAsync(dh, dh_last, (size_t)B * H * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    for (int j = L - 1; j >= 0; --j) {
-        const int p0 = step_off[j], bs = step_off[j + 1] - step_off[j];
-        if (bs <= 0) continue;
-        hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(grid_for(bs * H)), dim3(256), 0, st,
-                           saved + (size_t)p0 * 5 * H, dh, dGi + (size_t)p0 * 3 * H,
-                           dGh + (size_t)p0 * 3 * H, bs, H);
-        RENET_LAUNCH_CHECK();
-        if (j > 0) {   // dh_prev += dGh W_hh   (h_prev of step 0 is the constant h0 = 0)
-            int rc = renet_gemm_f32(0, 0, bs, H, 3 * H, 1.f, dGh + (size_t)p0 * 3 * H, 3 * H, Whh, H, 1.f,
-                                    dh, H, nullptr, 1, nullptr, 0, stream);
-            if (rc) return rc;
-        }
+    float* WhhT = workspace;
+    hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, st, Whh, 3 * H, H,
+                       WhhT);
+    RENET_LAUNCH_CHECK();
+    switch (H) {
+        case 100: return launch_bwd<100>(dh_last, so, L, B, WhhT, saved, dGi, dGh, st);
+        case 200: return launch_bwd<200>(dh_last, so, L, B, WhhT, saved, dGi, dGh, st);
+        default: return launch_bwd<400>(dh_last, so, L, B, WhhT, saved, dGi, dGh, st);
     }
-    return RENET_OK;
 }
 
 }  // extern "C"

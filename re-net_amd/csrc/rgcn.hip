@@ -288,15 +288,40 @@ __global__ __launch_bounds__(kThreads) void segment_add_kernel(const float4* __r
                                                                const int32_t* __restrict__ seg_ptr,
                                                                const int32_t* __restrict__ seg_target,
                                                                int U, int CH, float4* __restrict__ dst) {
-    const int lane = threadIdx.x & 63;
-    const int u = blockIdx.x * kWaves + (threadIdx.x >> 6);
+    // One workgroup per segment: the 4 waves take rows k0+w, k0+w+4, ... (hot entities / relations own
+    // hundreds of rows), 4 independent row loads in flight per wave, fixed-order LDS combine.
+    __shared__ float4 red[kWaves][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = blockIdx.x;
     if (u >= U) return;
     const int k0 = seg_ptr[u], k1 = seg_ptr[u + 1];
     const size_t tgt = (size_t)seg_target[u] * CH;
+    const bool single = (k1 - k0) <= 1;                  // the common case: no cross-wave combine needed
     for (int ch = lane; ch < CH; ch += 64) {
-        float4 s = dst[tgt + ch];
-        for (int k = k0; k < k1; ++k) s = f4_add(s, src[(size_t)order[k] * CH + ch]);
-        dst[tgt + ch] = s;
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+        int k = k0 + wave;
+        for (; k + 12 < k1; k += 16) {
+            const int r0 = order[k], r1 = order[k + 4], r2 = order[k + 8], r3 = order[k + 12];
+            s0 = f4_add(s0, src[(size_t)r0 * CH + ch]);
+            s1 = f4_add(s1, src[(size_t)r1 * CH + ch]);
+            s2 = f4_add(s2, src[(size_t)r2 * CH + ch]);
+            s3 = f4_add(s3, src[(size_t)r3 * CH + ch]);
+        }
+        for (; k < k1; k += 4) s0 = f4_add(s0, src[(size_t)order[k] * CH + ch]);
+        const float4 s = f4_add(f4_add(s0, s1), f4_add(s2, s3));
+        if (single) {
+            if (wave == 0) dst[tgt + ch] = f4_add(dst[tgt + ch], s);
+        } else {
+            red[wave][ch] = s;
+        }
+    }
+    if (single) return;
+    __syncthreads();
+    if (wave == 0) {
+        for (int ch = lane; ch < CH; ch += 64) {
+            const float4 s = f4_add(f4_add(red[0][ch], red[1][ch]), f4_add(red[2][ch], red[3][ch]));
+            dst[tgt + ch] = f4_add(dst[tgt + ch], s);
+        }
     }
 }
 
@@ -322,7 +347,8 @@ int renet_segment_add(const float* src, const int32_t* order, const int32_t* seg
                       const int32_t* seg_target, int U, int D, float* dst, void* stream) {
     if (U < 0 || D <= 0 || (D & 3)) return RENET_ERR_BADARG;
     if (U == 0) return RENET_OK;
-    hipLaunchKernelGGL(segment_add_kernel, dim3((U + kWaves - 1) / kWaves), dim3(kThreads), 0,
+    if (D > 512) return RENET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(segment_add_kernel, dim3(U), dim3(kThreads), 0,
                        (hipStream_t)stream, (const float4*)src, order, seg_ptr, seg_target, U, D / 4,
                        (float4*)dst);
     RENET_LAUNCH_CHECK();

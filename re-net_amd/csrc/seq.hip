@@ -31,24 +31,47 @@ __global__ __launch_bounds__(256) void seq_assemble_fwd_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void seq_assemble_bwd_kernel(const float4* __restrict__ dX,
-                                                               const float4* __restrict__ dXr, int S,
-                                                               int CH, DropCfg dx, DropCfg dxr,
-                                                               float4* __restrict__ dRows,
-                                                               float4* __restrict__ dEntRow,
-                                                               float4* __restrict__ dRelRow) {
+// backward, part 1: gradient wrt the gathered h2 row of every packed row (X and Xr segments)
+__global__ __launch_bounds__(256) void seq_assemble_bwd_rows_kernel(const float4* __restrict__ dX,
+                                                                    const float4* __restrict__ dXr, int S,
+                                                                    int CH, DropCfg dx, DropCfg dxr,
+                                                                    float4* __restrict__ dRows) {
     const size_t total = (size_t)S * CH;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const int p = (int)(i / CH), cc = (int)(i - (size_t)p * CH);
         const size_t bx = (size_t)p * 4 * CH, br = (size_t)p * 3 * CH;
-        float4 a = f4_mul(dX[bx + cc], renet_drop4(dx, bx + cc));
-        float4 b = f4_mul(dXr[br + cc], renet_drop4(dxr, br + cc));
+        const float4 a = f4_mul(dX[bx + cc], renet_drop4(dx, bx + cc));
+        const float4 b = f4_mul(dXr[br + cc], renet_drop4(dxr, br + cc));
         dRows[i] = f4_add(a, b);
-        a = f4_mul(dX[bx + CH + cc], renet_drop4(dx, bx + CH + cc));
-        b = f4_mul(dXr[br + CH + cc], renet_drop4(dxr, br + CH + cc));
-        dEntRow[i] = f4_add(a, b);
-        dRelRow[i] = f4_mul(dX[bx + 2 * CH + cc], renet_drop4(dx, bx + 2 * CH + cc));
+    }
+}
+
+// backward, part 2: ent[s_i] and rel[r_i] were broadcast to every step of sequence i
+// (Aggregator.py:150-155), so their gradients are summed over the sequence's steps here: packed row of
+// step j of sequence i is off[j] + i while i < off[j+1] - off[j].  Rows i >= nnz come out zero.
+__global__ __launch_bounds__(256) void seq_assemble_bwd_seq_kernel(const float4* __restrict__ dX,
+                                                                   const float4* __restrict__ dXr,
+                                                                   const int32_t* __restrict__ off, int L,
+                                                                   int B, int CH, DropCfg dx, DropCfg dxr,
+                                                                   float4* __restrict__ dEntSeq,
+                                                                   float4* __restrict__ dRelSeq) {
+    const size_t total = (size_t)B * CH;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t / CH), cc = (int)(t - (size_t)i * CH);
+        float4 se = make_float4(0.f, 0.f, 0.f, 0.f), sr = se;
+        for (int j = 0; j < L; ++j) {
+            const int o0 = off[j], o1 = off[j + 1];
+            if (i >= o1 - o0) break;
+            const size_t p = (size_t)(o0 + i);
+            const size_t bx = p * 4 * CH, br = p * 3 * CH;
+            se = f4_add(se, f4_mul(dX[bx + CH + cc], renet_drop4(dx, bx + CH + cc)));
+            se = f4_add(se, f4_mul(dXr[br + CH + cc], renet_drop4(dxr, br + CH + cc)));
+            sr = f4_add(sr, f4_mul(dX[bx + 2 * CH + cc], renet_drop4(dx, bx + 2 * CH + cc)));
+        }
+        dEntSeq[t] = se;
+        dRelSeq[t] = sr;
     }
 }
 
@@ -220,17 +243,24 @@ int renet_seq_assemble_fwd(const float* h2, const float* ent, const float* rel, 
     return RENET_OK;
 }
 
-int renet_seq_assemble_bwd(const float* dX, const float* dXr, int S, int D, float drop_p,
-                           uint64_t seed_x, uint64_t seed_xr, float* dRows, float* dEntRow,
-                           float* dRelRow, void* stream) {
-    if (S < 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f) return RENET_ERR_BADARG;
-    if (S == 0) return RENET_OK;
+int renet_seq_assemble_bwd(const float* dX, const float* dXr, const int32_t* step_off, int L, int S,
+                           int B, int D, float drop_p, uint64_t seed_x, uint64_t seed_xr, float* dRows,
+                           float* dEntSeq, float* dRelSeq, void* stream) {
+    if (S < 0 || B < 0 || L < 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f) return RENET_ERR_BADARG;
     const int CH = D / 4;
-    hipLaunchKernelGGL(seq_assemble_bwd_kernel, dim3(grid_for((size_t)S * CH)), dim3(256), 0,
-                       (hipStream_t)stream, (const float4*)dX, (const float4*)dXr, S, CH,
-                       make_drop(drop_p, seed_x), make_drop(drop_p, seed_xr), (float4*)dRows,
-                       (float4*)dEntRow, (float4*)dRelRow);
-    RENET_LAUNCH_CHECK();
+    const DropCfg dx = make_drop(drop_p, seed_x), dxr = make_drop(drop_p, seed_xr);
+    if (S > 0) {
+        hipLaunchKernelGGL(seq_assemble_bwd_rows_kernel, dim3(grid_for((size_t)S * CH)), dim3(256), 0,
+                           (hipStream_t)stream, (const float4*)dX, (const float4*)dXr, S, CH, dx, dxr,
+                           (float4*)dRows);
+        RENET_LAUNCH_CHECK();
+    }
+    if (B > 0) {
+        hipLaunchKernelGGL(seq_assemble_bwd_seq_kernel, dim3(grid_for((size_t)B * CH)), dim3(256), 0,
+                           (hipStream_t)stream, (const float4*)dX, (const float4*)dXr, step_off, L, B, CH, dx,
+                           dxr, (float4*)dEntSeq, (float4*)dRelSeq);
+        RENET_LAUNCH_CHECK();
+    }
     return RENET_OK;
 }
 

@@ -204,8 +204,9 @@ class SegPlan(object):
 class HostBatch(object):
     """Everything one direction of one training/inference batch needs, as numpy arrays."""
     INT_FIELDS = ('node_ent', 'row_ptr', 'col', 'etype', 'e_src', 'e_dst', 'chunk_ptr', 'chunk_type',
-                  'type_chunk_ptr', 'subj_row', 'row_ent', 'row_rel', 'glob_row', 's_sorted', 'r_sorted')
-    PLANS = ('plan_node_ent', 'plan_subj_row', 'plan_row_ent', 'plan_row_rel', 'plan_s', 'plan_r')
+                  'type_chunk_ptr', 'subj_row', 'row_ent', 'row_rel', 'glob_row', 's_sorted', 'r_sorted',
+                  'step_off')
+    PLANS = ('plan_node_ent', 'plan_subj_row', 'plan_s', 'plan_r')
 
     def set_edges(self, n, src, dst, et, num_types):
         """Directed edges (src -> dst, type et = type_s) -> the two device layouts:
@@ -339,8 +340,6 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None):
 
     hb.plan_node_ent = SegPlan.host(hb.node_ent)
     hb.plan_subj_row = SegPlan.host(hb.subj_row)
-    hb.plan_row_ent = SegPlan.host(hb.row_ent)
-    hb.plan_row_rel = SegPlan.host(hb.row_rel)
     hb.plan_s = SegPlan.host(hb.s_sorted)
     hb.plan_r = SegPlan.host(hb.r_sorted)
     return hb

@@ -18,15 +18,6 @@ def next_seed():
     return (torch.initial_seed() * 0x9E3779B1 + _seed_state['counter'] * 0x85EBCA77) & 0x7FFFFFFFFFFFFFFF
 
 
-def auto_split_k(m, n, k):
-    """split-K factor for tall-skinny weight-gradient GEMMs: aim at ~2 workgroups per CU."""
-    tiles = ((m + 127) // 128) * ((n + 127) // 128)
-    if tiles >= 256:
-        return 1
-    ktiles = (k + 31) // 32
-    return int(max(1, min((512 + tiles - 1) // tiles, max(ktiles // 4, 1), 128)))
-
-
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
@@ -69,7 +60,7 @@ class RGCNLayerFn(Function):
         g_loop = torch.empty_like(h)
         K.rgcn_bwd_prep(g_out, out, g.norm, ctx.relu, ctx.drop_p, ctx.seed, gn, g_loop)
         dh = K.gemm(g_loop, loop_weight, tb=True)                      # g_loop @ W_loop^T
-        d_loop = K.gemm(h, g_loop, ta=True, split_k=auto_split_k(d, d, n))      # h^T @ g_loop
+        d_loop = K.gemm(h, g_loop, ta=True)                            # h^T @ g_loop (auto split-K)
         # dh += sum over out-edges W[type]^T gn[dst]  == same CSR rows, the PAIRED edge's type
         pair_shift = (ctx.shift + g.num_types // 2) % g.num_types
         K.rgcn_gather(gn, g.row_ptr, g.col, g.etype, None, weight, pair_shift, True, dh, 0.0, 0, False, dh)
@@ -95,14 +86,15 @@ class SeqAssembleFn(Function):
     def backward(ctx, dx, dxr):
         g = ctx.g
         d = ctx.shapes[0][1]
-        d_rows, d_ent_row, d_rel_row = K.seq_assemble_bwd(_c(dx), _c(dxr), d, ctx.drop_p, *ctx.seeds)
+        d_rows, d_ent_seq, d_rel_seq = K.seq_assemble_bwd(_c(dx), _c(dxr), g.step_off, g.L, g.B, d, ctx.drop_p,
+                                                          *ctx.seeds)
         dev = dx.device
         d_h2 = torch.zeros(ctx.shapes[0], device=dev, dtype=torch.float32)
         K.segment_add(d_rows, g.plan_subj_row, d_h2)
         d_ent = torch.zeros(ctx.shapes[1], device=dev, dtype=torch.float32)
-        K.segment_add(d_ent_row, g.plan_row_ent, d_ent)
+        K.segment_add(d_ent_seq, g.plan_s, d_ent)             # per-sequence sums, keyed by s[perm]
         d_rel = torch.zeros(ctx.shapes[2], device=dev, dtype=torch.float32)
-        K.segment_add(d_rel_row, g.plan_row_rel, d_rel)
+        K.segment_add(d_rel_seq, g.plan_r, d_rel)
         return d_h2, d_ent, d_rel, None, None, None, None, None
 
 
@@ -134,10 +126,10 @@ class GRUFn(Function):
         d_gi, d_gh = K.gru_bwd(dh_last, ctx.step_off, hdim, w_hh, saved)
         s = x.shape[0]
         dx = K.gemm(d_gi, w_ih)                                          # [S, I]
-        d_wih = K.gemm(d_gi, x, ta=True, split_k=auto_split_k(3 * hdim, x.shape[1], s))
+        d_wih = K.gemm(d_gi, x, ta=True)
         d_bih = K.colsum(d_gi)
         h_prev = saved[:, 4 * hdim:]
-        d_whh = K.gemm(d_gh, h_prev, ta=True, split_k=auto_split_k(3 * hdim, hdim, s))
+        d_whh = K.gemm(d_gh, h_prev, ta=True)
         d_bhh = K.colsum(d_gh)
         return dx, d_wih, d_whh, d_bih, d_bhh, None, None
 
@@ -167,8 +159,7 @@ class HeadCEFn(Function):
         feat, dlogits, weight = ctx.saved_tensors
         d, parts, drop_p, seed, plan_a, plan_c, a_shape, c_shape = ctx.meta
         dfeat = K.gemm(dlogits, weight) * g                              # [B, parts*D]
-        d_w = K.gemm(dlogits, feat * g, ta=True, split_k=auto_split_k(weight.shape[0], weight.shape[1],
-                                                                      feat.shape[0]))
+        d_w = K.gemm(dlogits, feat * g, ta=True)
         d_b = K.colsum(dlogits) * g
         da_rows, dh, dc_rows = K.concat3_bwd(dfeat, d, parts, drop_p, seed)
         d_a = torch.zeros(a_shape, device=g.device, dtype=torch.float32)
@@ -222,8 +213,7 @@ class LinearFn(Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g = _c(g)
-        return (K.gemm(g, weight), K.gemm(g, x, ta=True, split_k=auto_split_k(weight.shape[0], weight.shape[1],
-                                                                               x.shape[0])), K.colsum(g))
+        return (K.gemm(g, weight), K.gemm(g, x, ta=True), K.colsum(g))
 
 
 def host_offsets(step_off):

@@ -34,12 +34,13 @@ _SIGNATURES = {
     'renet_gemm_workspace': (c_size_t, [c_int, c_int, c_int]),
     'renet_gemm_f32': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
-    'renet_colsum': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'renet_colsum_workspace': (c_size_t, [c_int, c_int]),
+    'renet_colsum': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_seq_assemble_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_void_p,
                                        c_void_p]),
-    'renet_seq_assemble_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_u64, c_u64, c_void_p,
-                                       c_void_p, c_void_p, c_void_p]),
+    'renet_seq_assemble_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                       c_u64, c_u64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'renet_gru_workspace': (c_size_t, [c_int, c_int]),
     'renet_gru_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_size_t, c_void_p]),
@@ -201,8 +202,19 @@ def _ld(t):
     return t.stride(0)
 
 
-def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, split_k=1):
-    """out = alpha * op(a) @ op(b) + bias + beta * out.  a/b may be row-strided views."""
+def auto_split_k(m, n, k):
+    """split-K factor when the output has too few 128x128 tiles to fill 256 CUs (weight-gradient and
+    dX-of-the-head shapes): aim at ~2 workgroups per CU, keep >= 4 k-tiles per slice."""
+    tiles = ((m + 127) // 128) * ((n + 127) // 128)
+    if tiles >= 200:
+        return 1
+    ktiles = (k + 31) // 32
+    return int(max(1, min((512 + tiles - 1) // tiles, max(ktiles // 4, 1), 128)))
+
+
+def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, split_k=None):
+    """out = alpha * op(a) @ op(b) + bias + beta * out.  a/b may be row-strided views.
+    split_k=None picks the deterministic split-K factor automatically."""
     if not (a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32):
         raise RenetHipError('gemm operands must be float32 device tensors')
     m, k = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
@@ -213,6 +225,8 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, spl
         out = torch.empty(m, n, device=a.device, dtype=torch.float32)
         if beta != 0.0:
             raise RenetHipError('beta != 0 needs an output tensor')
+    if split_k is None:
+        split_k = auto_split_k(m, n, k)
     ws_ptr, ws_bytes = None, 0
     if split_k > 1:
         ws_bytes = lib().renet_gemm_workspace(m, n, split_k)
@@ -231,7 +245,10 @@ def colsum(x, out=None):
     m, n = x.shape
     if out is None:
         out = torch.empty(n, device=x.device, dtype=torch.float32)
-    _check(lib().renet_colsum(x.data_ptr(), m, n, _ld(x), _f32(out), _stream()), 'colsum')
+    nbytes = lib().renet_colsum_workspace(m, n)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
+    _check(lib().renet_colsum(x.data_ptr(), m, n, _ld(x), _f32(out), ws.data_ptr() if nbytes else None, nbytes,
+                              _stream()), 'colsum')
     return out
 
 
@@ -246,13 +263,15 @@ def seq_assemble_fwd(h2, ent, rel, glob, subj_row, row_ent, row_rel, glob_row, d
     return x, xr
 
 
-def seq_assemble_bwd(dx, dxr, d, drop_p, seed_x, seed_xr):
+def seq_assemble_bwd(dx, dxr, step_off, num_steps, num_seq, d, drop_p, seed_x, seed_xr):
+    """-> (dRows[S,D], dEntSeq[num_seq,D], dRelSeq[num_seq,D]); step_off: device int32 [L+1]."""
     s = dx.shape[0]
     d_rows = torch.empty(s, d, device=dx.device, dtype=torch.float32)
-    d_ent = torch.empty(s, d, device=dx.device, dtype=torch.float32)
-    d_rel = torch.empty(s, d, device=dx.device, dtype=torch.float32)
-    _check(lib().renet_seq_assemble_bwd(_f32(dx), _f32(dxr), s, d, float(drop_p), int(seed_x), int(seed_xr),
-                                        _f32(d_rows), _f32(d_ent), _f32(d_rel), _stream()), 'seq_assemble_bwd')
+    d_ent = torch.empty(num_seq, d, device=dx.device, dtype=torch.float32)
+    d_rel = torch.empty(num_seq, d, device=dx.device, dtype=torch.float32)
+    _check(lib().renet_seq_assemble_bwd(_f32(dx), _f32(dxr), _i32(step_off), num_steps, s, num_seq, d,
+                                        float(drop_p), int(seed_x), int(seed_xr), _f32(d_rows), _f32(d_ent),
+                                        _f32(d_rel), _stream()), 'seq_assemble_bwd')
     return d_rows, d_ent, d_rel
 
 
