@@ -1,10 +1,17 @@
 // fp32 GEMM on the f32-input matrix cores of gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, i.e. a
 // k-ordered fmaf chain, at the 157 TF/s vector-equivalent rate).  128x128x32 workgroup tile, 4 waves
 // in a 2x2 arrangement, each wave 2x2 MFMA tiles of 32x32 (64 accumulator registers per lane).
-// Operands are staged global -> registers -> LDS in a k-major image As[k][m] / Bs[k][n] so that the
-// MFMA operand fetch (lane l reads element [k = l>>5][i = l&31]) is a conflict-free ds_read_b32 of
-// 32 consecutive floats per half-wave, whatever the storage order of A and B.  The global loads for
-// tile t+1 are issued before the MFMAs of tile t (register double buffer).
+//
+// Operand staging is global -> registers -> LDS with 16-byte accesses end to end, double-buffered in
+// LDS (one barrier per k-tile; the global loads of tile t+2 are in flight during the MFMAs of tile t):
+//  * an operand whose k index is contiguous in memory (A of C=A.B, B of C=A.B^T) keeps that order in
+//    LDS, image [row][k] with a 36-float row stride: ds_write_b128 in, ds_read_b128 out, both
+//    conflict-free.  The MFMA consumes k in a permuted order to make that possible: within a group of
+//    8 k the half-wave `ksel` owns k = 8g + 4*ksel + {0..3}, so one float4 feeds 4 consecutive MFMAs.
+//    (Any k order is legal as long as A and B agree; the sum over k is the same set of products.)
+//  * an operand whose row index is contiguous (A of C=A^T.B, B of C=A.B) is kept [k][row] with a
+//    132-float stride: ds_write_b128 in, conflict-free ds_read_b32 out (32 consecutive rows per
+//    half-wave), in the same permuted k order.
 //
 // Used for: the RGCN self-loop h @ W_loop (RGCN.py:35), the GRU input projections (inside nn.GRU,
 // model.py:86,94), the score heads (model.py:89-90,98-99) and all their backward GEMMs
@@ -14,8 +21,11 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDS_LD = BM + 1;          // +1: conflict-free transposing ds_write_b32 (see header)
+constexpr int LDK = BK + 4;             // [row][k] image: 36-float rows
+constexpr int LDR = BM + 4;             // [k][row] image: 132-float rows
+constexpr int OPBUF = BM * LDK;         // floats per operand buffer (>= BK * LDR)
 constexpr int THREADS = 256;
+static_assert(BK * LDR <= OPBUF, "operand buffer too small");
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -31,7 +41,7 @@ struct GemmArgs {
     float* partial;             // [split_k, M, N] when split_k > 1
 };
 
-// Loads one BM(or BN) x BK operand tile into 4 float4 registers per thread.
+// Loads one 128 x BK operand tile into 4 float4 registers per thread.
 //  CONTIG_K = true : storage is [rows, K] (k contiguous): float4 along k; thread f -> row f/8, kq f%8
 //  CONTIG_K = false: storage is [K, rows] (row index contiguous): float4 along rows; f -> k f/32, rq f%32
 template <bool CONTIG_K>
@@ -75,27 +85,26 @@ __device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = tid + THREADS * i;
-        if constexpr (CONTIG_K) {
-            const int row = f >> 3, k = (f & 7) << 2;
-            S[(k + 0) * LDS_LD + row] = r[i].x;
-            S[(k + 1) * LDS_LD + row] = r[i].y;
-            S[(k + 2) * LDS_LD + row] = r[i].z;
-            S[(k + 3) * LDS_LD + row] = r[i].w;
-        } else {
-            const int k = f >> 5, row = (f & 31) << 2;
-            S[k * LDS_LD + row + 0] = r[i].x;
-            S[k * LDS_LD + row + 1] = r[i].y;
-            S[k * LDS_LD + row + 2] = r[i].z;
-            S[k * LDS_LD + row + 3] = r[i].w;
-        }
+        if constexpr (CONTIG_K) *reinterpret_cast<float4*>(&S[(f >> 3) * LDK + ((f & 7) << 2)]) = r[i];
+        else *reinterpret_cast<float4*>(&S[(f >> 5) * LDR + ((f & 31) << 2)]) = r[i];
+    }
+}
+
+// the 4 values (MFMA steps tt = 0..3) of k-group g for tile row `row`, half-wave ksel
+template <bool CONTIG_K>
+__device__ __forceinline__ float4 read_frag(const float* __restrict__ S, int row, int g, int ksel) {
+    if constexpr (CONTIG_K) {
+        return *reinterpret_cast<const float4*>(&S[row * LDK + 8 * g + 4 * ksel]);
+    } else {
+        const float* p = S + (8 * g + 4 * ksel) * LDR + row;
+        return make_float4(p[0], p[LDR], p[2 * LDR], p[3 * LDR]);
     }
 }
 
 // TA: A stored [K,M] (A^T);  TB: B stored [N,K] (B^T)
 template <bool TA, bool TB>
 __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ float As[BK * LDS_LD];
-    __shared__ float Bs[BK * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float smem[2][2][OPBUF];       // [buffer][A|B]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -123,31 +132,54 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(GemmArgs g) {
     if (kt0 < kt1) {
         load_tile<A_CK>(g.A, g.lda, g.M, g.K, m0, kt0 * BK, tid, a_vec, ra);
         load_tile<B_CK>(g.B, g.ldb, g.N, g.K, n0, kt0 * BK, tid, b_vec, rb);
+        store_tile<A_CK>(smem[0][0], tid, ra);
+        store_tile<B_CK>(smem[0][1], tid, rb);
+        if (kt0 + 1 < kt1) {
+            load_tile<A_CK>(g.A, g.lda, g.M, g.K, m0, (kt0 + 1) * BK, tid, a_vec, ra);
+            load_tile<B_CK>(g.B, g.ldb, g.N, g.K, n0, (kt0 + 1) * BK, tid, b_vec, rb);
+        }
     }
+    __syncthreads();
     const int arow = wm * 64 + (lane & 31);
     const int brow = wn * 64 + (lane & 31);
     const int ksel = lane >> 5;
 
     for (int kt = kt0; kt < kt1; ++kt) {
-        __syncthreads();                       // previous tile fully consumed
-        store_tile<A_CK>(As, tid, ra);
-        store_tile<B_CK>(Bs, tid, rb);
-        __syncthreads();
-        if (kt + 1 < kt1) {                    // prefetch next tile while the MFMAs run
-            load_tile<A_CK>(g.A, g.lda, g.M, g.K, m0, (kt + 1) * BK, tid, a_vec, ra);
-            load_tile<B_CK>(g.B, g.ldb, g.N, g.K, n0, (kt + 1) * BK, tid, b_vec, rb);
+        const int cur = (kt - kt0) & 1;
+        if (kt + 1 < kt1) {                    // tile t+1: registers -> the other LDS buffer
+            store_tile<A_CK>(smem[cur ^ 1][0], tid, ra);
+            store_tile<B_CK>(smem[cur ^ 1][1], tid, rb);
         }
+        if (kt + 2 < kt1) {                    // tile t+2: global -> registers, lands during the MFMAs below
+            load_tile<A_CK>(g.A, g.lda, g.M, g.K, m0, (kt + 2) * BK, tid, a_vec, ra);
+            load_tile<B_CK>(g.B, g.ldb, g.N, g.K, n0, (kt + 2) * BK, tid, b_vec, rb);
+        }
+        const float* As = smem[cur][0];
+        const float* Bs = smem[cur][1];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = As[(kk + ksel) * LDS_LD + arow];
-            const float a1 = As[(kk + ksel) * LDS_LD + arow + 32];
-            const float b0 = Bs[(kk + ksel) * LDS_LD + brow];
-            const float b1 = Bs[(kk + ksel) * LDS_LD + brow + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            const float4 a0 = read_frag<A_CK>(As, arow, kg, ksel);
+            const float4 a1 = read_frag<A_CK>(As, arow + 32, kg, ksel);
+            const float4 b0 = read_frag<B_CK>(Bs, brow, kg, ksel);
+            const float4 b1 = read_frag<B_CK>(Bs, brow + 32, kg, ksel);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b1.x, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b0.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b1.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b0.y, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b1.z, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b0.z, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b1.w, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b0.w, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[1][1], 0, 0, 0);
         }
+        __syncthreads();                       // buffer `cur` free for tile t+2, buffer cur^1 complete
     }
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)

@@ -19,6 +19,8 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MT = 16;           // sequences per workgroup (MFMA M)
+constexpr int NW = 8;            // waves per workgroup: 2 per SIMD so that W_hh fetch latency hides behind the partner's MFMAs
+constexpr int NT = NW * 64;
 constexpr int MAXL = 32;         // max packed steps (seq_len is 10 / 15 in the reference configs)
 
 struct StepOff {
@@ -41,7 +43,7 @@ struct Cfg {
 // forward
 // ---------------------------------------------------------------------------------------------
 template <int H>
-__global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ Gi, StepOff so, int L,
+__global__ __launch_bounds__(NT) void gru_fwd_kernel(const float* __restrict__ Gi, StepOff so, int L,
                                                       const float* __restrict__ Whh,
                                                       const float* __restrict__ bhh,
                                                       float* __restrict__ h_last,
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = blockIdx.x * MT;
     const int B = so.off[1] - so.off[0];
-    for (int t = tid; t < MT * C::LDH; t += 256) Hs[t] = 0.f;          // h0 = 0 (and zero k-padding)
+    for (int t = tid; t < MT * C::LDH; t += NT) Hs[t] = 0.f;          // h0 = 0 (and zero k-padding)
     __syncthreads();
 
     const int jj = lane & 15;          // B column / C column: hidden unit within the block
@@ -62,10 +64,10 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
         const int p0 = so.off[j];
         const int bs = so.off[j + 1] - p0;
         if (i0 >= bs) break;                                            // whole tile finished (sorted batch)
-        f32x4 hnew[(C::NUB + 3) / 4];
+        f32x4 hnew[(C::NUB + NW - 1) / NW];
 #pragma unroll
-        for (int q = 0; q < (C::NUB + 3) / 4; ++q) {
-            const int ub = wave + 4 * q;
+        for (int q = 0; q < (C::NUB + NW - 1) / NW; ++q) {
+            const int ub = wave + NW * q;
             if (ub < C::NUB) {
                 const int u = ub * 16 + jj;                             // this lane's hidden unit
                 const bool uok = u < H;
@@ -120,8 +122,8 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
         }
         __syncthreads();                                                // every wave is done reading Hs
 #pragma unroll
-        for (int q = 0; q < (C::NUB + 3) / 4; ++q) {
-            const int ub = wave + 4 * q;
+        for (int q = 0; q < (C::NUB + NW - 1) / NW; ++q) {
+            const int ub = wave + NW * q;
             const int u = ub * 16 + jj;
             if (ub < C::NUB && u < H) {
 #pragma unroll
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
         }
         __syncthreads();
     }
-    for (int t = tid; t < MT * H; t += 256) {
+    for (int t = tid; t < MT * H; t += NT) {
         const int i = t / H, u = t - i * H;
         if (i0 + i < B) h_last[(size_t)(i0 + i) * H + u] = Hs[i * C::LDH + u];
     }
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ 
 // LDS as the A operand of   dh_prev = dh * z + dGh W_hh   (K = 3H, B fragments from W_hh^T [H, 3H]).
 // ---------------------------------------------------------------------------------------------
 template <int H>
-__global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ dh_last, StepOff so, int L,
+__global__ __launch_bounds__(NT) void gru_bwd_kernel(const float* __restrict__ dh_last, StepOff so, int L,
                                                       const float* __restrict__ WhhT,   // [H, 3H]
                                                       const float* __restrict__ saved,
                                                       float* __restrict__ dGi, float* __restrict__ dGh) {
@@ -153,11 +155,11 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = blockIdx.x * MT;
     const int B = so.off[1] - so.off[0];
-    for (int t = tid; t < MT * C::LDH; t += 256) {
+    for (int t = tid; t < MT * C::LDH; t += NT) {
         const int i = t / C::LDH, u = t - i * C::LDH;
         dHs[t] = (u < H && i0 + i < B) ? dh_last[(size_t)(i0 + i) * H + u] : 0.f;
     }
-    for (int t = tid; t < MT * C::LDG; t += 256) Gs[t] = 0.f;
+    for (int t = tid; t < MT * C::LDG; t += NT) Gs[t] = 0.f;
     __syncthreads();
     const int jj = lane & 15, kq = lane >> 4, ai = lane & 15;
 
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
         const int bs = so.off[j + 1] - p0;
         if (i0 >= bs) continue;                                         // tile not alive yet at this step
         // phase 1: gate gradients of the live rows
-        for (int t = tid; t < MT * H; t += 256) {
+        for (int t = tid; t < MT * H; t += NT) {
             const int i = t / H, u = t - i * H;
             float gr = 0.f, gz = 0.f, gn = 0.f;
             if (i0 + i < bs) {
@@ -190,8 +192,8 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ 
         if (j > 0) {
             // phase 2: dh_prev += dGh W_hh  (rows of dead sequences have dGh = 0 and keep their dh)
 #pragma unroll
-            for (int q = 0; q < (C::NUB + 3) / 4; ++q) {
-                const int ub = wave + 4 * q;
+            for (int q = 0; q < (C::NUB + NW - 1) / NW; ++q) {
+                const int ub = wave + NW * q;
                 if (ub < C::NUB) {
                     const int u = ub * 16 + jj;
                     const bool uok = u < H;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 template <int H>
 int launch_fwd(const float* Gi, const StepOff& so, int L, int B, const float* Whh, const float* bhh,
                float* h_last, float* saved, hipStream_t st) {
-    hipLaunchKernelGGL((gru_fwd_kernel<H>), dim3((B + MT - 1) / MT), dim3(256), 0, st, Gi, so, L, Whh, bhh,
+    hipLaunchKernelGGL((gru_fwd_kernel<H>), dim3((B + MT - 1) / MT), dim3(NT), 0, st, Gi, so, L, Whh, bhh,
                        h_last, saved);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
@@ -255,7 +257,7 @@ int launch_bwd(const float* dh_last, const StepOff& so, int L, int B, const floa
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gru_bwd_kernel<H>), dim3((B + MT - 1) / MT), dim3(256), lds, st, dh_last, so, L, WhhT,
+    hipLaunchKernelGGL((gru_bwd_kernel<H>), dim3((B + MT - 1) / MT), dim3(NT), lds, st, dh_last, so, L, WhhT,
                        saved, dGi, dGh);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
