@@ -65,13 +65,17 @@ int renet_segment_add(const float* src, const int32_t* order, const int32_t* seg
  *   relu     : 1 = ReLU epilogue (rgcn1, Aggregator.py:119-120), 0 = identity (rgcn2)
  *
  * The graph is CSR by destination (row_ptr[N+1], col[E] = source row, etype[E]).
+ * heavy_rows[n_heavy] (optional, may be NULL/0) lists the rows whose in-degree exceeds heavy_thresh:
+ * the row-group kernel skips them and a second launch reduces each with a whole workgroup, so a
+ * Zipf-tail hub row cannot serialise one wave for the entire launch.
  * The backward wrt x uses the same CSR: RE-Net graphs hold both directions of every fact with paired
  * types (utils.py:74-76), so the transposed graph is the same structure with type_shift = num_rels.
  * ---------------------------------------------------------------------------------------------- */
 int renet_rgcn_gather(const float* x, int D, const int32_t* row_ptr, const int32_t* col,
                       const int32_t* etype, const float* scale, const float* W, int T, int type_shift,
                       int transpose_w, const float* addend, float drop_p, uint64_t seed, int relu,
-                      float* out, int N, void* stream);
+                      float* out, int N, const int32_t* heavy_rows, int n_heavy, int heavy_thresh,
+                      void* stream);
 
 /* Backward prologue of one RGCN layer (element-wise, RGCN.py:42-50 + :93-94 reversed):
  *   g_pre = g_out * (relu ? out > 0 : 1);  gn = g_pre * norm[v];  g_loop = g_pre * dropmask       */

@@ -60,92 +60,227 @@ struct GatherArgs {
     const float* W;
     const float* addend;
     float* out;
+    const int32_t* heavy;       // rows with in-degree > heavy_thresh, handled by rgcn_gather_heavy_kernel
+    int n_heavy, heavy_thresh;
     int N, T, shift, relu;
     DropCfg drop;
 };
 
-// SI = D/100 (relation block size); NCH = float4 chunks per lane = ceil(D/4/64)
-template <int SI, int NCH, bool TR>
+template <int CH>
+__device__ __forceinline__ void gather_epilogue(const GatherArgs& a, int v, int ch, float4 o, float sc) {
+    o = f4_scale(o, sc);
+    if (a.addend) {
+        float4 ad = reinterpret_cast<const float4*>(a.addend)[(size_t)v * CH + ch];
+        ad = f4_mul(ad, renet_drop4(a.drop, (uint64_t)v * CH + ch));
+        o = f4_add(o, ad);
+    }
+    if (a.relu) {
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    reinterpret_cast<float4*>(a.out)[(size_t)v * CH + ch] = o;
+}
+
+// SI = D/100 (relation block size); NCH = float4 chunks per lane = ceil(D/4/64); UNR = edges whose
+// operand loads are in flight together.
+//
+// A wave owns a GROUP of R = 8 consecutive destination rows: one coalesced fetch brings the group's
+// row_ptr slice (and norm), one more the source/type indices of its in-edges (rows are short: the
+// group's CSR segment is ~20-40 contiguous edges), so the dependent-load chain is
+// {row_ptr} -> {indices} -> {source rows + relation blocks} for 8 rows at once instead of per row.
+// Edges are walked in CSR order in batches of UNR with all UNR source-row / weight loads issued
+// before the first FMA; a row is flushed (norm, +self-loop addend with dropout, ReLU, store) when the
+// walk crosses its row_ptr boundary.  Hub rows (in-degree > heavy_thresh; a Zipf tail of a few hundred
+// rows with up to ~300 in-edges) would serialise one wave for the whole launch, so they are skipped
+// by the row-group walk and reduced by a whole workgroup each (gather_heavy_row, same launch).  Everything that steers
+// control flow is wave-uniform (SGPR).
+template <int SI, int NCH, int UNR, bool TR>
+__device__ __forceinline__ void gather_heavy_row(const GatherArgs& a, int v);
+
+template <int SI, int NCH, int UNR, bool TR>
 __global__ __launch_bounds__(kThreads) void rgcn_gather_kernel(GatherArgs a) {
     constexpr int D = 100 * SI;
     constexpr int CH = D / 4;               // float4 chunks per feature row
     constexpr int WCH = SI;                 // float4 weight loads per chunk
     constexpr int WROW4 = D * SI / 4;       // float4 per relation weight row
+    constexpr int R = 8;                    // rows per group
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int nb = gridDim.x;
-    const int vb = renet_xcd_block(blockIdx.x, nb);
-    const int rows_per_block = (a.N + nb - 1) / nb;
-    const int r0 = vb * rows_per_block;
-    const int r1 = min(a.N, r0 + rows_per_block);
+    // the first n_heavy workgroups of the launch each reduce one hub row (longest work items first);
+    // the rest walk row groups
+    if ((int)blockIdx.x < a.n_heavy) {
+        gather_heavy_row<SI, NCH, UNR, TR>(a, a.heavy[blockIdx.x]);
+        return;
+    }
+    const int nb = gridDim.x - a.n_heavy;
+    const int vb = renet_xcd_block(blockIdx.x - a.n_heavy, nb);
+    const int ngroups = (a.N + R - 1) / R;
+    const int gpb = (ngroups + nb - 1) / nb;
+    const int g0 = vb * gpb;
+    const int g1 = min(ngroups, g0 + gpb);
     const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x);
     const float4* __restrict__ w4 = reinterpret_cast<const float4*>(a.W);
 
-    for (int v = r0 + wave; v < r1; v += kWaves) {
-        const int e0 = a.row_ptr[v];
-        const int e1 = a.row_ptr[v + 1];
+    for (int grp = g0 + wave; grp < g1; grp += kWaves) {
+        const int v0 = grp * R;
+        const int nrows = min(R, a.N - v0);
+        int my_rp = 0;
+        float my_sc = 1.f;
+        if (lane <= nrows) my_rp = a.row_ptr[v0 + lane];
+        if (a.scale && lane < nrows) my_sc = a.scale[v0 + lane];
+        const int e_end = __builtin_amdgcn_readlane(my_rp, nrows);
+        int e = __builtin_amdgcn_readlane(my_rp, 0);
+        int r = 0;                                       // current row; [row_beg, row_end) its edges
+        int row_end = __builtin_amdgcn_readlane(my_rp, 1);
+        bool row_heavy = (row_end - e) > a.heavy_thresh;
         float4 acc[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-        for (int eb = e0; eb < e1; eb += 64) {
-            // one coalesced index fetch for up to 64 in-edges of this row
-            const int my_e = eb + lane;
-            int my_col = 0, my_t = 0;
-            if (my_e < e1) {
-                my_col = a.col[my_e];
-                my_t = a.etype[my_e] + a.shift;
-                if (my_t >= a.T) my_t -= a.T;
+        auto flush = [&]() {
+            if (!row_heavy) {
+                const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_sc), r));
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    if (lane + 64 * c < CH) gather_epilogue<CH>(a, v0 + r, lane + 64 * c, acc[c], sc);
             }
-            const int cnt = min(64, e1 - eb);
-#pragma unroll 4
-            for (int k = 0; k < cnt; ++k) {
-                const int src = __builtin_amdgcn_readlane(my_col, k);   // wave-uniform -> SGPR base
-                const int t = __builtin_amdgcn_readlane(my_t, k);
-                const float4* xr = x4 + (size_t)src * CH;
-                const float4* wr = w4 + (size_t)t * WROW4;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const int ch = lane + 64 * c;
-                    if (ch < CH) {
-                        const float4 xv = xr[ch];
-                        float4 wv[WCH];
+            for (int c = 0; c < NCH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ++r;
+            const int beg = row_end;
+            row_end = r < nrows ? __builtin_amdgcn_readlane(my_rp, r + 1) : 0x7fffffff;
+            row_heavy = r < nrows && (row_end - beg) > a.heavy_thresh;
+        };
+
+        int eb = e - 64;                                 // start of the index window held in registers
+        int my_col = 0, my_t = 0;
+        while (e < e_end) {
+            while (e >= row_end) flush();                // row boundary (also empty rows)
+            if (row_heavy) { e = row_end; continue; }    // hub row: left to the heavy kernel
+            if (e >= eb + 64) {                          // refill the 64-edge index window (coalesced)
+                eb = e;
+                const int my_e = eb + lane;
+                my_col = 0; my_t = 0;
+                if (my_e < e_end) {
+                    my_col = a.col[my_e];
+                    my_t = a.etype[my_e] + a.shift;
+                    if (my_t >= a.T) my_t -= a.T;
+                }
+            }
+            const int k0 = e - eb;
+            const int cnt = min(64, e_end - eb);
+            float4 xv[UNR][NCH];
+            float4 wv[UNR][NCH][WCH];
 #pragma unroll
-                        for (int q = 0; q < WCH; ++q) wv[q] = wr[ch * WCH + q];
-                        blockmul<SI, TR>(xv, wv, acc[c]);
+            for (int u = 0; u < UNR; ++u) {
+                if (k0 + u < cnt) {
+                    const int src = __builtin_amdgcn_readlane(my_col, k0 + u);   // wave-uniform -> SGPR base
+                    const int t = __builtin_amdgcn_readlane(my_t, k0 + u);
+                    const float4* xr = x4 + (size_t)src * CH;
+                    const float4* wr = w4 + (size_t)t * WROW4;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const int ch = lane + 64 * c;
+                        if (ch < CH) {
+                            xv[u][c] = xr[ch];
+#pragma unroll
+                            for (int q = 0; q < WCH; ++q) wv[u][c][q] = wr[ch * WCH + q];
+                        }
+                    }
+                }
+            }
+            // (a batch may run into the next rows; loads past a hub row's start are simply unused)
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (k0 + u < cnt && e == eb + k0 + u) {
+                    while (e >= row_end) flush();
+                    if (!row_heavy) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c)
+                            if (lane + 64 * c < CH) blockmul<SI, TR>(xv[u][c], wv[u][c], acc[c]);
+                        ++e;
                     }
                 }
             }
         }
+        while (r < nrows) flush();
+    }
+}
 
+// One workgroup (4 waves) per hub row: wave w takes in-edges w, w+4, ... in batches of UNR, then a
+// fixed-order LDS combine and the same fused epilogue => deterministic.
+template <int SI, int NCH, int UNR, bool TR>
+__device__ __forceinline__ void gather_heavy_row(const GatherArgs& a, int v) {
+    constexpr int D = 100 * SI;
+    constexpr int CH = D / 4;
+    constexpr int WCH = SI;
+    constexpr int WROW4 = D * SI / 4;
+    __shared__ float4 red[kWaves][CH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e0 = a.row_ptr[v], e1 = a.row_ptr[v + 1];
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x);
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(a.W);
+    float4 acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = e0 + wave; e < e1; e += kWaves * UNR) {
+        float4 xv[UNR][NCH];
+        float4 wv[UNR][NCH][WCH];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int ee = e + u * kWaves;
+            if (ee < e1) {
+                const int src = a.col[ee];
+                int t = a.etype[ee] + a.shift;
+                if (t >= a.T) t -= a.T;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int ch = lane + 64 * c;
+                    if (ch < CH) {
+                        xv[u][c] = x4[(size_t)src * CH + ch];
+#pragma unroll
+                        for (int q = 0; q < WCH; ++q) wv[u][c][q] = w4[(size_t)t * WROW4 + ch * WCH + q];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (e + u * kWaves < e1) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    if (lane + 64 * c < CH) blockmul<SI, TR>(xv[u][c], wv[u][c], acc[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if (lane + 64 * c < CH) red[wave][lane + 64 * c] = acc[c];
+    __syncthreads();
+    if (wave == 0) {
         const float sc = a.scale ? a.scale[v] : 1.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int ch = lane + 64 * c;
             if (ch < CH) {
-                float4 r = f4_scale(acc[c], sc);
-                if (a.addend) {
-                    float4 ad = reinterpret_cast<const float4*>(a.addend)[(size_t)v * CH + ch];
-                    ad = f4_mul(ad, renet_drop4(a.drop, (uint64_t)v * CH + ch));
-                    r = f4_add(r, ad);
-                }
-                if (a.relu) {
-                    r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f);
-                }
-                reinterpret_cast<float4*>(a.out)[(size_t)v * CH + ch] = r;
+                float4 s = red[0][ch];
+#pragma unroll
+                for (int w = 1; w < kWaves; ++w) s = f4_add(s, red[w][ch]);
+                gather_epilogue<CH>(a, v, ch, s, sc);
             }
         }
     }
 }
 
-template <int SI, int NCH>
+template <int SI, int NCH, int UNR>
 int launch_gather(const GatherArgs& a, bool tr, hipStream_t st) {
-    // >> 256 workgroups, multiple of 8 (XCD remap), ~4 rows per wave minimum
-    int blocks = (a.N + 15) / 16;
+    // one 8-row group per wave where possible; multiple of 8 blocks for the XCD remap
+    const int ngroups = (a.N + 7) / 8;
+    int blocks = (ngroups + kWaves - 1) / kWaves;
     blocks = max(8, min(blocks, 256 * 8));
     blocks = (blocks + 7) & ~7;
-    if (tr) hipLaunchKernelGGL((rgcn_gather_kernel<SI, NCH, true>), dim3(blocks), dim3(kThreads), 0, st, a);
-    else hipLaunchKernelGGL((rgcn_gather_kernel<SI, NCH, false>), dim3(blocks), dim3(kThreads), 0, st, a);
+    const int grid = blocks + a.n_heavy;         // hub rows first, then the row groups, in ONE launch
+    if (tr) hipLaunchKernelGGL((rgcn_gather_kernel<SI, NCH, UNR, true>), dim3(grid), dim3(kThreads), 0, st, a);
+    else hipLaunchKernelGGL((rgcn_gather_kernel<SI, NCH, UNR, false>), dim3(grid), dim3(kThreads), 0, st, a);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -198,40 +333,56 @@ __global__ __launch_bounds__(kThreads) void rgcn_bwd_w_partial_kernel(
         int my_s = 0, my_d = 0;
         if (my_e < e1) { my_s = e_src[my_e]; my_d = e_dst[my_e]; }
         const int cnt = min(64, e1 - eb);
-#pragma unroll 4
-        for (int k = 0; k < cnt; ++k) {
-            const int s = __builtin_amdgcn_readlane(my_s, k);
-            const int d = __builtin_amdgcn_readlane(my_d, k);
+        constexpr int UNR = (SI == 4) ? 2 : 4;              // edges with both row loads in flight together
+        for (int k0 = 0; k0 < cnt; k0 += UNR) {
+            float4 xv[UNR][NCH], gv[UNR][NCH];
 #pragma unroll
-            for (int q = 0; q < NCH; ++q) {
-                const int ch = lane + 64 * q;
-                if (ch < CH) {
-                    const float4 xv = x4[(size_t)s * CH + ch];
-                    const float4 gv = g4[(size_t)d * CH + ch];
-                    if constexpr (SI == 1) {
-                        acc[q][0].x = fmaf(xv.x, gv.x, acc[q][0].x);
-                        acc[q][0].y = fmaf(xv.y, gv.y, acc[q][0].y);
-                        acc[q][0].z = fmaf(xv.z, gv.z, acc[q][0].z);
-                        acc[q][0].w = fmaf(xv.w, gv.w, acc[q][0].w);
-                    } else if constexpr (SI == 2) {
-                        // block0: dW[i][j] = x_i g_j (i,j in {0,1}); block1 with elements 2,3
-                        acc[q][0].x = fmaf(xv.x, gv.x, acc[q][0].x);
-                        acc[q][0].y = fmaf(xv.x, gv.y, acc[q][0].y);
-                        acc[q][0].z = fmaf(xv.y, gv.x, acc[q][0].z);
-                        acc[q][0].w = fmaf(xv.y, gv.y, acc[q][0].w);
-                        acc[q][1].x = fmaf(xv.z, gv.z, acc[q][1].x);
-                        acc[q][1].y = fmaf(xv.z, gv.w, acc[q][1].y);
-                        acc[q][1].z = fmaf(xv.w, gv.z, acc[q][1].z);
-                        acc[q][1].w = fmaf(xv.w, gv.w, acc[q][1].w);
-                    } else {
-                        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            for (int u = 0; u < UNR; ++u) {
+                if (k0 + u < cnt) {
+                    const int s = __builtin_amdgcn_readlane(my_s, k0 + u);
+                    const int d = __builtin_amdgcn_readlane(my_d, k0 + u);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            acc[q][i].x = fmaf(xs[i], gv.x, acc[q][i].x);
-                            acc[q][i].y = fmaf(xs[i], gv.y, acc[q][i].y);
-                            acc[q][i].z = fmaf(xs[i], gv.z, acc[q][i].z);
-                            acc[q][i].w = fmaf(xs[i], gv.w, acc[q][i].w);
+                    for (int q = 0; q < NCH; ++q) {
+                        const int ch = lane + 64 * q;
+                        if (ch < CH) {
+                            xv[u][q] = x4[(size_t)s * CH + ch];
+                            gv[u][q] = g4[(size_t)d * CH + ch];
                         }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                if (k0 + u < cnt) {
+#pragma unroll
+                    for (int q = 0; q < NCH; ++q) {
+                        if (lane + 64 * q < CH) {
+                        if constexpr (SI == 1) {
+                            acc[q][0].x = fmaf(xv[u][q].x, gv[u][q].x, acc[q][0].x);
+                            acc[q][0].y = fmaf(xv[u][q].y, gv[u][q].y, acc[q][0].y);
+                            acc[q][0].z = fmaf(xv[u][q].z, gv[u][q].z, acc[q][0].z);
+                            acc[q][0].w = fmaf(xv[u][q].w, gv[u][q].w, acc[q][0].w);
+                        } else if constexpr (SI == 2) {
+                            // block0: dW[i][j] = x_i g_j (i,j in {0,1}); block1 with elements 2,3
+                            acc[q][0].x = fmaf(xv[u][q].x, gv[u][q].x, acc[q][0].x);
+                            acc[q][0].y = fmaf(xv[u][q].x, gv[u][q].y, acc[q][0].y);
+                            acc[q][0].z = fmaf(xv[u][q].y, gv[u][q].x, acc[q][0].z);
+                            acc[q][0].w = fmaf(xv[u][q].y, gv[u][q].y, acc[q][0].w);
+                            acc[q][1].x = fmaf(xv[u][q].z, gv[u][q].z, acc[q][1].x);
+                            acc[q][1].y = fmaf(xv[u][q].z, gv[u][q].w, acc[q][1].y);
+                            acc[q][1].z = fmaf(xv[u][q].w, gv[u][q].z, acc[q][1].z);
+                            acc[q][1].w = fmaf(xv[u][q].w, gv[u][q].w, acc[q][1].w);
+                        } else {
+                            const float xs[4] = {xv[u][q].x, xv[u][q].y, xv[u][q].z, xv[u][q].w};
+    #pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                acc[q][i].x = fmaf(xs[i], gv[u][q].x, acc[q][i].x);
+                                acc[q][i].y = fmaf(xs[i], gv[u][q].y, acc[q][i].y);
+                                acc[q][i].z = fmaf(xs[i], gv[u][q].z, acc[q][i].z);
+                                acc[q][i].w = fmaf(xs[i], gv[u][q].w, acc[q][i].w);
+                            }
+                        }
+                    }
                     }
                 }
             }
@@ -358,20 +509,24 @@ int renet_segment_add(const float* src, const int32_t* order, const int32_t* seg
 int renet_rgcn_gather(const float* x, int D, const int32_t* row_ptr, const int32_t* col,
                       const int32_t* etype, const float* scale, const float* W, int T, int type_shift,
                       int transpose_w, const float* addend, float drop_p, uint64_t seed, int relu,
-                      float* out, int N, void* stream) {
+                      float* out, int N, const int32_t* heavy_rows, int n_heavy, int heavy_thresh,
+                      void* stream) {
     if (!renet_dim_ok(D)) return RENET_ERR_UNSUPPORTED;
+    if (n_heavy < 0 || (n_heavy > 0 && (!heavy_rows || heavy_thresh < 1))) return RENET_ERR_BADARG;
     if (N < 0 || T <= 0 || type_shift < 0 || type_shift >= T || drop_p < 0.f || drop_p >= 1.f)
         return RENET_ERR_BADARG;
     if (N == 0) return RENET_OK;
     GatherArgs a;
     a.x = x; a.row_ptr = row_ptr; a.col = col; a.etype = etype; a.scale = scale; a.W = W;
     a.addend = addend; a.out = out; a.N = N; a.T = T; a.shift = type_shift; a.relu = relu;
+    a.heavy = heavy_rows; a.n_heavy = n_heavy;
+    a.heavy_thresh = n_heavy > 0 ? heavy_thresh : 0x7fffffff;
     a.drop = make_drop(drop_p, seed);
     hipStream_t st = (hipStream_t)stream;
     switch (D) {
-        case 100: return launch_gather<1, 1>(a, transpose_w != 0, st);
-        case 200: return launch_gather<2, 1>(a, transpose_w != 0, st);
-        default: return launch_gather<4, 2>(a, transpose_w != 0, st);
+        case 100: return launch_gather<1, 1, 4>(a, transpose_w != 0, st);
+        case 200: return launch_gather<2, 1, 4>(a, transpose_w != 0, st);
+        default: return launch_gather<4, 2, 2>(a, transpose_w != 0, st);
     }
 }
 

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 CHUNK = 64          # edges per dW work item (one wave each)
+HEAVY = 8           # in-degree above which a row is reduced by a whole workgroup (hub rows; swept in tools/gather_bench.py)
 
 
 class TimeGraph(object):
@@ -205,7 +206,7 @@ class HostBatch(object):
     """Everything one direction of one training/inference batch needs, as numpy arrays."""
     INT_FIELDS = ('node_ent', 'row_ptr', 'col', 'etype', 'e_src', 'e_dst', 'chunk_ptr', 'chunk_type',
                   'type_chunk_ptr', 'subj_row', 'row_ent', 'row_rel', 'glob_row', 's_sorted', 'r_sorted',
-                  'step_off')
+                  'step_off', 'heavy_rows')
     PLANS = ('plan_node_ent', 'plan_subj_row', 'plan_s', 'plan_r')
 
     def set_edges(self, n, src, dst, et, num_types):
@@ -223,6 +224,7 @@ class HostBatch(object):
         deg = np.bincount(dst, minlength=n)
         self.row_ptr = np.concatenate(([0], np.cumsum(deg))).astype(np.int32)
         self.norm = (1.0 / np.maximum(deg, 1)).astype(np.float32)            # utils.py:89-93
+        self.heavy_rows = np.nonzero(deg > HEAVY)[0].astype(np.int32)
         order2 = np.argsort(et, kind='stable')
         self.e_src = src[order2].astype(np.int32)
         self.e_dst = dst[order2].astype(np.int32)
@@ -406,6 +408,9 @@ class DeviceGraph(object):
             setattr(self, pn, p)
         self.norm = torch.from_numpy(hb.norm).to(device)
         self.ndata = {}                  # 'h' lives here, as on the reference's DGL graph
+        self.heavy_thresh = HEAVY
+        if getattr(self, 'heavy_rows', None) is not None and self.heavy_rows.numel() == 0:
+            self.heavy_rows = None
         for f in ('N', 'E', 'S', 'B', 'nnz', 'L', 'n_chunks', 'num_types', 'G'):
             if hasattr(hb, f):
                 setattr(self, f, getattr(hb, f))

@@ -45,7 +45,8 @@ class RGCNLayerFn(Function):
         h, weight, loop_weight = _c(h), _c(weight), _c(loop_weight)
         shift = g.num_types // 2 if reverse else 0                     # type_o = type_s +- R (utils.py:75-76)
         out = K.gemm(h, loop_weight)                                   # RGCN.py:35
-        K.rgcn_gather(h, g.row_ptr, g.col, g.etype, g.norm, weight, shift, False, out, drop_p, seed, relu, out)
+        K.rgcn_gather(h, g.row_ptr, g.col, g.etype, g.norm, weight, shift, False, out, drop_p, seed, relu, out,
+                      g.heavy_rows, g.heavy_thresh)
         ctx.g, ctx.relu, ctx.drop_p, ctx.seed, ctx.shift = g, relu, drop_p, seed, shift
         ctx.save_for_backward(h, weight, loop_weight, out)
         return out
@@ -63,7 +64,8 @@ class RGCNLayerFn(Function):
         d_loop = K.gemm(h, g_loop, ta=True)                            # h^T @ g_loop (auto split-K)
         # dh += sum over out-edges W[type]^T gn[dst]  == same CSR rows, the PAIRED edge's type
         pair_shift = (ctx.shift + g.num_types // 2) % g.num_types
-        K.rgcn_gather(gn, g.row_ptr, g.col, g.etype, None, weight, pair_shift, True, dh, 0.0, 0, False, dh)
+        K.rgcn_gather(gn, g.row_ptr, g.col, g.etype, None, weight, pair_shift, True, dh, 0.0, 0, False, dh,
+                      g.heavy_rows, g.heavy_thresh)
         d_w = torch.empty_like(weight)
         K.rgcn_bwd_w(h, gn, g.e_src, g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr,
                      g.num_types, ctx.shift, d_w)

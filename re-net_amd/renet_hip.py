@@ -25,7 +25,8 @@ _SIGNATURES = {
     'renet_gather_rows': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'renet_segment_add': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'renet_rgcn_gather': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                  c_int, c_int, c_void_p, c_float, c_u64, c_int, c_void_p, c_int, c_void_p]),
+                                  c_int, c_int, c_void_p, c_float, c_u64, c_int, c_void_p, c_int, c_void_p,
+                                  c_int, c_int, c_void_p]),
     'renet_rgcn_bwd_prep': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_u64, c_int, c_int,
                                     c_void_p, c_void_p, c_void_p]),
     'renet_rgcn_bwd_w_workspace': (c_size_t, [c_int, c_int]),
@@ -160,13 +161,15 @@ def segment_add(src, plan, dst):
 
 
 def rgcn_gather(x, row_ptr, col, etype, scale, weight, type_shift, transpose_w, addend, drop_p, seed,
-                relu, out):
+                relu, out, heavy_rows=None, heavy_thresh=0):
     n, d = x.shape[0], x.shape[1]
     t0 = _timer.begin() if _timer is not None else None
     _check(lib().renet_rgcn_gather(_f32(x), d, _i32(row_ptr), _i32(col), _i32(etype), _f32(scale),
                                    _f32(weight), weight.shape[0], type_shift, int(transpose_w),
                                    _f32(addend), float(drop_p), int(seed), int(relu), _f32(out),
-                                   out.shape[0], _stream()), 'rgcn_gather')
+                                   out.shape[0], _i32(heavy_rows) if heavy_rows is not None else None,
+                                   heavy_rows.numel() if heavy_rows is not None else 0, int(heavy_thresh),
+                                   _stream()), 'rgcn_gather')
     if t0 is not None:
         # algorithmic bytes: per edge one source row + src + type index; per node one output
         # row + row_ptr + norm (+ the fused addend row); the relation weight table once
@@ -209,7 +212,18 @@ def auto_split_k(m, n, k):
     if tiles >= 200:
         return 1
     ktiles = (k + 31) // 32
-    return int(max(1, min((512 + tiles - 1) // tiles, max(ktiles // 4, 1), 128)))
+    smax = int(max(1, min(max(ktiles // 4, 1), 128)))
+    # 2 workgroups are resident per CU (73.7 KB LDS each): pick the split whose workgroup count fills
+    # whole rounds of 512 best (e.g. 40 tiles: 12 slices = 480 WGs in one round, not 13 = 520 in two)
+    best, best_u = 1, 0.0
+    for s in range(1, smax + 1):
+        wgs = tiles * s
+        util = wgs / float(((wgs + 511) // 512) * 512)
+        if wgs < 256:
+            util *= wgs / 256.0
+        if util > best_u + 1e-9:
+            best, best_u = s, util
+    return best
 
 
 def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, split_k=None):

@@ -336,12 +336,16 @@ def test_full_size_gather_properties(dev):
     x1 = torch.randn(hb.N, d, device=dev)
     x2 = torch.randn(hb.N, d, device=dev)
 
-    def A(x, shift=0, tr=False, graph=g):
+    def A(x, shift=0, tr=False, graph=g, heavy=True):
         out = torch.empty_like(x)
         K.rgcn_gather(x, graph.row_ptr, graph.col, graph.etype, graph.norm if not tr else None, w, shift, tr,
-                      None, 0.0, 0, False, out)
+                      None, 0.0, 0, False, out, graph.heavy_rows if heavy else None, graph.heavy_thresh)
         return out
     y1, y2, y12 = A(x1), A(x2), A(2.0 * x1 - 3.0 * x2)
+    # hub rows (in-degree > graph.HEAVY) go through the workgroup-per-row kernel: same values as the
+    # single-kernel walk up to summation order
+    assert g.heavy_rows is not None and g.heavy_rows.numel() > 10 and int(np.diff(hb.row_ptr).max()) > 200
+    np.testing.assert_allclose(A(x1, heavy=False).cpu().numpy(), y1.cpu().numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(y12.cpu().numpy(), (2.0 * y1 - 3.0 * y2).cpu().numpy(), rtol=1e-4, atol=1e-4)
     # edge-order invariance: a different edge permutation builds the same rows up to summation order
     perm = np.random.RandomState(9).permutation(len(src))
