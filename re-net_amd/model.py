@@ -169,3 +169,238 @@ def _device_plan(idx, device):
     for f in ('order', 'seg_ptr', 'target'):
         setattr(p, f, torch.from_numpy(getattr(p, f)).to(device))
     return p
+
+
+# =================================================================================================
+# Inference-time state machine (reference model.py:107-446), restated on the HIP path.  Same public
+# methods / attributes / semantics; what differs is mechanical:
+#   * per-entity prediction caches are int64 numpy arrays [k,2] (the reference keeps torch tensors);
+#   * the num_k sampled subjects (objects) of a new timestamp are de-duplicated before the expensive
+#     pred_r_rank2 call and the result reused for every duplicate (the reference's `s in s_done`
+#     test compares tensor identities and never fires, model.py:229-235; results are identical);
+#   * candidate bookkeeping is array based instead of dicts keyed by tensor objects.
+# =================================================================================================
+def _as_int(x):
+    return int(x.item()) if isinstance(x, torch.Tensor) else int(x)
+
+
+def _linear_eval(lin, x):
+    """y = x W^T + b on the MFMA GEMM (no autograd: inference only)."""
+    return K.gemm(x.contiguous(), lin.weight, tb=True, bias=lin.bias)
+
+
+def _init_history(self, triples, s_history, o_history, valid_triples, s_history_valid, o_history_valid,
+                  test_triples=None, s_history_test=None, o_history_test=None):
+    """model.py:107-165: per-entity rolling windows as of the end of training (+ valid/test entries whose
+    last step is not later than the last training time)."""
+    n = self.in_dim
+    self.s_hist_test = [[] for _ in range(n)]
+    self.o_hist_test = [[] for _ in range(n)]
+    self.s_hist_test_t = [[] for _ in range(n)]
+    self.o_hist_test_t = [[] for _ in range(n)]
+    self.s_his_cache = [[] for _ in range(n)]
+    self.o_his_cache = [[] for _ in range(n)]
+    self.s_his_cache_t = [None for _ in range(n)]
+    self.o_his_cache_t = [None for _ in range(n)]
+    last_t = None
+    for k in range(len(triples)):
+        s, o, last_t = _as_int(triples[k][0]), _as_int(triples[k][2]), triples[k][3]
+        self.s_hist_test[s] = list(s_history[0][k])
+        self.s_hist_test_t[s] = list(s_history[1][k])
+        self.o_hist_test[o] = list(o_history[0][k])
+        self.o_hist_test_t[o] = list(o_history[1][k])
+    for trip, sh, oh in ((valid_triples, s_history_valid, o_history_valid),
+                         (test_triples, s_history_test, o_history_test)):
+        if trip is None:
+            continue
+        for k in range(len(trip)):
+            s, o = _as_int(trip[k][0]), _as_int(trip[k][2])
+            st, ot = sh[1][k], oh[1][k]
+            if len(st) != 0 and st[-1] <= last_t:
+                self.s_hist_test[s] = list(sh[0][k])
+                self.s_hist_test_t[s] = list(st)
+            if len(ot) != 0 and ot[-1] <= last_t:
+                self.o_hist_test[o] = list(oh[0][k])
+                self.o_hist_test_t[o] = list(ot)
+
+
+def _update_cache(self, cache, r, o_candidate):
+    """model.py:421-446: add (r, o) pairs to an entity's prediction cache, keeping pairs unique."""
+    r = _as_int(r)
+    cand = np.asarray(o_candidate.cpu() if isinstance(o_candidate, torch.Tensor) else o_candidate,
+                      dtype=np.int64).reshape(-1) % self.in_dim
+    if len(cache) == 0:
+        return np.stack((np.full(len(cand), r, np.int64), cand), axis=1)
+    cache = np.asarray(cache.cpu() if isinstance(cache, torch.Tensor) else cache, dtype=np.int64).reshape(-1, 2)
+    known = cache[cache[:, 0] == r][:, 1]
+    new = cand[~np.isin(cand, known)]
+    if len(new) == 0:
+        return cache
+    return np.concatenate((cache, np.stack((np.full(len(new), r, np.int64), new), axis=1)), axis=0)
+
+
+def _pred_r_rank2(self, s, r, subject=True):
+    """model.py:168-211: joint distribution p(r, o | s, history) as [num_rels, in_dim] for ONE entity
+    (s holds num_rels copies of it, r = arange(num_rels))."""
+    ent_id = _as_int(s[0])
+    R, dev = self.num_rels, self.ent_embeds.device
+    if subject:
+        hist, hist_t = self.s_hist_test[ent_id], self.s_hist_test_t[ent_id]
+        rel_embeds, reverse = self.rel_embeds[:R], False
+    else:
+        hist, hist_t = self.o_hist_test[ent_id], self.o_hist_test_t[ent_id]
+        rel_embeds, reverse = self.rel_embeds[R:], True
+    ent_row = self.ent_embeds[ent_id].view(1, -1)
+    if len(hist) == 0:
+        s_h = torch.zeros(R, self.h_dim, device=dev)
+        s_q0 = torch.zeros(1, self.h_dim, device=dev)
+    else:
+        # the R sequences differ only in the relation segment of X: run the graph part for one
+        # sequence per relation through the same batch path (identical node sets => identical graph)
+        s_arr = np.full(R, ent_id, dtype=np.int64)
+        px, pxr = self.aggregator.predict_batch(([list(hist)] * R, [list(hist_t)] * R), s_arr, np.arange(R),
+                                                self.ent_embeds, rel_embeds, self.graph_dict, self.global_emb,
+                                                reverse=reverse)
+        _, s_h = self.encoder(px, total_rows=R)
+        _, s_q = self.encoder_r(pxr, total_rows=R)
+        s_h, s_q0 = s_h[0], s_q[0][:1]
+    feat = torch.cat((ent_row.expand(R, -1), s_h, rel_embeds), dim=1)
+    p_o = torch.softmax(_linear_eval(self.linear, feat), dim=1)                      # [R, N_ent]
+    p_r = torch.softmax(_linear_eval(self.linear_r, torch.cat((ent_row, s_q0), dim=1)).view(-1), dim=0)
+    return p_o * p_r.view(R, 1)
+
+
+def _sample(self, prob):
+    """model.py:225-227: num_k draws from the global model's entity distribution."""
+    return torch.distributions.categorical.Categorical(prob).sample(torch.Size([self.num_k]))
+
+
+def _advance_side(self, picks, prob, subject):
+    """model.py:229-258 (subjects) / 266-297 (objects): rank (r, o) continuations of every sampled entity,
+    keep the globally best num_k and write them into the prediction caches."""
+    picks_np = picks.detach().cpu().numpy().astype(np.int64)
+    uniq, first = np.unique(picks_np, return_index=True)
+    per_ent = {}
+    for e in uniq:                      # identical entities give identical results: compute once
+        joint = self.pred_r_rank2(torch.full((self.num_rels,), int(e), dtype=torch.long),
+                                  torch.arange(self.num_rels), subject=subject)
+        vals, idx = torch.topk((prob[int(e)] * joint).view(-1), self.num_k, sorted=False)
+        per_ent[int(e)] = (vals, idx)
+    all_vals = torch.cat([per_ent[int(e)][0] for e in picks_np])          # sample order, duplicates included
+    _, best = torch.topk(all_vals, self.num_k, sorted=False)
+    cache, cache_t = (self.s_his_cache, self.s_his_cache_t) if subject else (self.o_his_cache, self.o_his_cache_t)
+    now = _as_int(self.latest_time)
+    for c in best.cpu().numpy():
+        e = int(picks_np[c // self.num_k])
+        code = int(per_ent[e][1][c % self.num_k])
+        rr, other = code // self.in_dim, code % self.in_dim
+        cache[e] = self.update_cache(cache[e], rr, np.asarray([other]))
+        cache_t[e] = now
+
+
+def _roll_histories(self):
+    """model.py:305-321: move every non-empty prediction cache into the entity's rolling window."""
+    for hist, hist_t, cache, cache_t in ((self.s_hist_test, self.s_hist_test_t, self.s_his_cache, self.s_his_cache_t),
+                                         (self.o_hist_test, self.o_hist_test_t, self.o_his_cache, self.o_his_cache_t)):
+        for e in range(self.in_dim):
+            if len(cache[e]) != 0:
+                while len(hist[e]) >= self.seq_len:
+                    hist[e].pop(0)
+                    hist_t[e].pop(0)
+                hist[e].append(np.asarray(cache[e], dtype=np.int64).copy())
+                hist_t[e].append(cache_t[e])
+                cache[e] = []
+                cache_t[e] = None
+
+
+def _advance_time(self, t, global_model):
+    """model.py:222-328: executed once when the evaluated stream moves to a new timestamp."""
+    _, _, prob_sub = global_model.predict(self.latest_time, self.graph_dict, subject=True)
+    self._advance_side(self.sample_entities(prob_sub), prob_sub, subject=True)
+    _, ob, _ = global_model.predict(t, self.graph_dict, subject=False)
+    prob_ob = torch.softmax(ob.view(-1), dim=0)
+    self._advance_side(self.sample_entities(prob_ob), prob_ob, subject=False)
+    now = _as_int(self.latest_time)
+    self.data = get_data(self.s_his_cache, self.o_his_cache)
+    if self.data is not None:
+        self.graph_dict[now] = get_big_graph(self.data, self.num_rels)               # model.py:301
+    emb, _, _ = global_model.predict(self.latest_time, self.graph_dict, subject=True)
+    self.global_emb[now] = emb.detach()                                              # model.py:302-303
+    self.aggregator.glob_table.invalidate()
+    self._roll_histories()
+    self.latest_time = t
+    self.data = None
+    self._reset_candidates()
+
+
+def _predict(self, triplet, s_hist, o_hist, global_model):
+    """model.py:216-363: scores of one test quadruple in both directions -> (loss, sub_pred, ob_pred)."""
+    s, r, o = _as_int(triplet[0]), _as_int(triplet[1]), _as_int(triplet[2])
+    t = triplet[3].cpu() if isinstance(triplet[3], torch.Tensor) else triplet[3]
+    if _as_int(self.latest_time) != _as_int(t):
+        self._advance_time(t, global_model)
+    R, dev = self.num_rels, self.ent_embeds.device
+
+    def encode(ent_id, given_hist, hist, hist_t, rel_embeds, reverse):
+        if len(given_hist[0]) == 0 or len(hist) == 0:                                 # model.py:332,342
+            return torch.zeros(1, self.h_dim, device=dev)
+        inp, _ = self.aggregator.predict((hist, hist_t), np.asarray([ent_id]), np.asarray([r]), self.ent_embeds,
+                                         rel_embeds, self.graph_dict, self.global_emb, reverse=reverse)
+        _, h = self.encoder(inp.view(1, len(hist), 4 * self.h_dim))
+        return h[0]
+
+    s_h = encode(s, s_hist, self.s_hist_test[s], self.s_hist_test_t[s], self.rel_embeds[:R], False)
+    o_h = encode(o, o_hist, self.o_hist_test[o], self.o_hist_test_t[o], self.rel_embeds[R:], True)
+    ob_pred = _linear_eval(self.linear, torch.cat((self.ent_embeds[s].view(1, -1), s_h,
+                                                   self.rel_embeds[r].view(1, -1)), dim=1)).view(-1)
+    sub_pred = _linear_eval(self.linear, torch.cat((self.ent_embeds[o].view(1, -1), o_h,
+                                                    self.rel_embeds[R + r].view(1, -1)), dim=1)).view(-1)
+    tgt = torch.tensor([o, s], device=dev, dtype=torch.int32)
+    loss = K.softmax_ce(ob_pred.view(1, -1), tgt[:1], 1.0, False)[0] + \
+        K.softmax_ce(sub_pred.view(1, -1), tgt[1:], 1.0, False)[0]                   # model.py:358-361
+    return loss, sub_pred, ob_pred
+
+
+def _rank(scores, label, filter_ids=None):
+    """model.py:368-376 / 391-418: rank = #greater + (#equal - 1)/2 + 1 (ties averaged); the filtered variant
+    zeroes the (sigmoid) scores of all other known-true completions first."""
+    if filter_ids is not None:
+        scores = torch.sigmoid(scores)
+        ground = scores[label].clone()
+        scores[filter_ids] = 0
+        scores[label] = ground
+    else:
+        ground = scores[label]
+    greater = int((scores > ground).sum().item())
+    equal = int((scores == ground).sum().item())
+    return greater + (equal - 1.0) / 2 + 1
+
+
+def _evaluate(self, triplet, s_hist, o_hist, global_model):
+    s, o = _as_int(triplet[0]), _as_int(triplet[2])
+    loss, sub_pred, ob_pred = self.predict(triplet, s_hist, o_hist, global_model)
+    return np.array([_rank(sub_pred, s), _rank(ob_pred, o)]), loss
+
+
+def _evaluate_filter(self, triplet, s_hist, o_hist, global_model, all_triplets):
+    """model.py:384-419: time-agnostic filtered ranks of the gold subject and object."""
+    s, r, o = _as_int(triplet[0]), _as_int(triplet[1]), _as_int(triplet[2])
+    loss, sub_pred, ob_pred = self.predict(triplet, s_hist, o_hist, global_model)
+    at = all_triplets
+    obj_known = at[(at[:, 0] == s) & (at[:, 1] == r), 2]
+    sub_known = at[(at[:, 2] == o) & (at[:, 1] == r), 0]
+    rank_ob = _rank(ob_pred.clone(), o, obj_known.to(ob_pred.device).long())
+    rank_sub = _rank(sub_pred.clone(), s, sub_known.to(sub_pred.device).long())
+    return np.array([rank_sub, rank_ob]), loss
+
+
+RENet.init_history = _init_history
+RENet.update_cache = _update_cache
+RENet.pred_r_rank2 = _pred_r_rank2
+RENet.sample_entities = _sample
+RENet._advance_side = _advance_side
+RENet._roll_histories = _roll_histories
+RENet._advance_time = _advance_time
+RENet.predict = _predict
+RENet.evaluate = _evaluate
+RENet.evaluate_filter = _evaluate_filter

@@ -279,6 +279,70 @@ def gen_global(name, d, seq_len, prep, maxpool):
     np.savez_compressed(os.path.join(OUT, 'global_%s_%d_max%d.npz' % (name, d, maxpool)), **out)
 
 
+def gen_eval(name, d, seq_len, num_k, n_eval, prep):
+    """model.RENet.evaluate_filter over the first n_eval validation quadruples (the multi-step inference
+    state machine, model.py:216-419), with the random entity samples recorded so that another
+    implementation can be driven through the identical trajectory."""
+    ref = ref_loader.load()
+    cfg, tr, va, te = dataset(name)
+    num_ent, num_rels = cfg['num_ent'], cfg['num_rels']
+    import copy
+    graph_dict = copy.deepcopy(prep['graphs'])
+    model = ref.model.RENet(num_ent, d, num_rels, dropout=0.0, model=0, seq_len=seq_len, num_k=num_k)
+    gmodel = ref.global_model.RENet_global(num_ent, d, num_rels, dropout=0.0, model=0, seq_len=seq_len,
+                                           num_k=num_k, maxpool=1)
+    pm = fixtures.make_params(cfg['seed'] * 17 + d, {k: tuple(v.shape) for k, v in model.state_dict().items()})
+    pg = fixtures.make_params(cfg['seed'] * 19 + d, {k: tuple(v.shape) for k, v in gmodel.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in pm.items()})
+    gmodel.load_state_dict({k: torch.from_numpy(v) for k, v in pg.items()})
+    model.eval(); gmodel.eval()
+    samples = []
+    Cat = torch.distributions.categorical.Categorical
+    orig_sample = Cat.sample
+
+    def rec_sample(self, shape=torch.Size()):
+        out = orig_sample(self, shape)
+        samples.append(out.clone())
+        return out
+    total = torch.from_numpy(np.concatenate((tr, va, te)))
+    valid = torch.from_numpy(va)
+    (vs, vst), (vo, vot) = prep['valid']
+    (ts_, tst), (to_, tot) = prep['test']
+    (s_hist, s_hist_t), (o_hist, o_hist_t) = prep['train']
+    ranks, losses = [], []
+    Cat.sample = rec_sample
+    try:
+        with ref_loader.cpu_mode(), torch.no_grad():
+            times = np.unique(tr[:, 3])
+            model.global_emb = gmodel.get_global_emb(times, graph_dict)
+            model.graph_dict = graph_dict
+            model.init_history(tr, (s_hist, s_hist_t), (o_hist, o_hist_t), valid, (vs, vst), (vo, vot), te,
+                               (ts_, tst), (to_, tot))
+            model.latest_time = valid[0][3]
+            for i in range(n_eval):
+                rk, loss = model.evaluate_filter(valid[i], (vs[i], vst[i]), (vo[i], vot[i]), gmodel, total)
+                ranks.append(rk)
+                losses.append(loss.item())
+    finally:
+        Cat.sample = orig_sample
+    out = dict(d=d, seq_len=seq_len, num_k=num_k, n_eval=n_eval, model_seed=cfg['seed'] * 17 + d,
+               global_seed=cfg['seed'] * 19 + d, ranks=np.asarray(ranks), losses=np.asarray(losses),
+               samples=np.stack([x.numpy() for x in samples]) if samples else np.zeros((0, num_k), np.int64),
+               n_new_graphs=np.int64(len(graph_dict) - len(prep['graphs'])))
+    # the graphs the model predicted for the timestamps it advanced over (model.py:300-301)
+    new_t = [t for t in graph_dict if t not in prep['graphs']]
+    trip = []
+    for t in new_t:
+        g = graph_dict[t]
+        m = g.number_of_edges() // 2
+        ids = g.ndata['id'].view(-1).numpy()
+        q = np.stack((ids[g._src[:m].numpy()], g.edata['type_s'][:m].numpy(), ids[g._dst[:m].numpy()],
+                      np.full(m, int(t))), axis=1)
+        trip.append(q[np.lexsort((q[:, 2], q[:, 1], q[:, 0]))])
+    out['new_graph_quads'] = np.concatenate(trip) if trip else np.zeros((0, 4), np.int64)
+    np.savez_compressed(os.path.join(OUT, 'eval_%s_%d.npz' % (name, d)), **out)
+
+
 def main():
     if not ref_loader.available():
         raise SystemExit('reference tree not available: fixtures can only be generated in the build container')
@@ -293,6 +357,7 @@ def main():
     gen_global('tiny', 100, 4, preps['tiny'], 1)
     gen_global('tiny', 200, 10, preps['tiny'], 0)
     gen_global('small', 200, 10, preps['small'], 1)
+    gen_eval('small', 100, 10, 6, 180, preps['small'])
     for f in sorted(os.listdir(OUT)):
         print('%-32s %8.1f KB' % (f, os.path.getsize(os.path.join(OUT, f)) / 1024.0))
 
