@@ -224,7 +224,8 @@ def _init_history(self, triples, s_history, o_history, valid_triples, s_history_
                 self.o_hist_test_t[o] = list(ot)
 
 
-def _update_cache(self, cache, r, o_candidate):
+def _update_cache(self, s_his_cache, r, o_candidate):
+    cache = s_his_cache
     """model.py:421-446: add (r, o) pairs to an entity's prediction cache, keeping pairs unique."""
     r = _as_int(r)
     cand = np.asarray(o_candidate.cpu() if isinstance(o_candidate, torch.Tensor) else o_candidate,

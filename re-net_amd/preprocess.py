@@ -95,3 +95,35 @@ def build_graph_dict(quads, num_rels):
     times, starts = np.unique(q[:, 3], return_index=True)
     ends = np.concatenate((starts[1:], [len(q)]))
     return {int(t): TimeGraph.from_triples(q[a:b, :3], num_rels) for t, a, b in zip(times, starts, ends)}
+
+
+def write_reference_pickles(data_dir, history_len=10):
+    """Command-line equivalent of running data/<DS>/get_history_graph.py in `data_dir`: reads stat.txt,
+    train.txt, valid.txt (optional), test.txt and writes train_graphs.txt and
+    {train,dev,test}_history_{sub,ob}.txt in the layout train.py:78-110 / test.py unpickle
+    ([histories, timestamps] nested lists; graphs as graph.TimeGraph instead of DGLGraph)."""
+    import os
+    import pickle
+    from utils import get_total_number, load_quadruples
+    num_e, num_r = get_total_number(data_dir, 'stat.txt')
+    splits = []
+    for name, out in (('train.txt', 'train'), ('valid.txt', 'dev'), ('test.txt', 'test')):
+        if os.path.isfile(os.path.join(data_dir, name)):
+            splits.append((out, load_quadruples(data_dir, name)[0]))
+    allq = np.concatenate([q for _, q in splits])
+    hs, ho = HistoryIndex(allq, 's', history_len), HistoryIndex(allq, 'o', history_len)
+    with open(os.path.join(data_dir, 'train_graphs.txt'), 'wb') as f:
+        pickle.dump(build_graph_dict(splits[0][1], num_r), f)
+    off = 0
+    for out, q in splits:
+        idx = np.arange(off, off + len(q))
+        off += len(q)
+        for tag, h in (('sub', hs), ('ob', ho)):
+            with open(os.path.join(data_dir, '%s_history_%s.txt' % (out, tag)), 'wb') as f:
+                pickle.dump(list(h.to_lists(idx)), f)
+
+
+if __name__ == '__main__':
+    import sys
+    write_reference_pickles(sys.argv[1] if len(sys.argv) > 1 else '.',
+                            int(sys.argv[2]) if len(sys.argv) > 2 else 10)

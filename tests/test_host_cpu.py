@@ -164,3 +164,75 @@ def test_synthetic_stream_shape():
     assert q[:, 0].max() < ne and q[:, 1].max() < nr and 1000 < len(q) / 12 < 2200
     q2, _, _, _ = synth.make_stream('ICEWS18', seed=999, num_t=12)
     assert np.array_equal(q, q2)
+
+
+@pytest.mark.reference
+def test_api_surface_matches_reference_classes():
+    """Same class names, constructor / method signatures (parameter names, order, defaults) as the
+    reference modules the drivers import -- what makes train.py / test.py run unchanged on top of us."""
+    import inspect
+    from oracle import ref_loader
+    if not ref_loader.available():
+        pytest.skip('reference tree not present')
+    ref = ref_loader.load()
+    import Aggregator as A
+    import RGCN as Rg
+    import global_model as GM
+    import model as M
+    pairs = [(ref.model.RENet, M.RENet, ['__init__', 'forward', 'init_history', 'pred_r_rank2', 'predict',
+                                        'evaluate', 'evaluate_filter', 'update_cache']),
+             (ref.global_model.RENet_global, GM.RENet_global, ['__init__', 'forward', 'predict', 'get_global_emb',
+                                                               'update_global_emb']),
+             (ref.Aggregator.RGCNAggregator, A.RGCNAggregator, ['__init__', 'forward', 'predict_batch', 'predict']),
+             (ref.Aggregator.RGCNAggregator_global, A.RGCNAggregator_global, ['__init__', 'forward', 'predict']),
+             (ref.RGCN.RGCNBlockLayer, Rg.RGCNBlockLayer, ['__init__', 'forward']),
+             (ref.RGCN.RGCNLayer, Rg.RGCNLayer, ['__init__'])]
+    for rc, mc, names in pairs:
+        for n in names:
+            rs, ms = inspect.signature(getattr(rc, n)), inspect.signature(getattr(mc, n))
+            rp = [(p.name, p.default) for p in rs.parameters.values()]
+            mp = [(p.name, p.default) for p in ms.parameters.values()]
+            assert rp == mp, (rc.__name__, n, rp, mp)
+    for fn in ('get_total_number', 'load_quadruples', 'make_batch', 'make_batch2', 'get_big_graph', 'get_data',
+               'get_true_distribution', 'soft_cross_entropy', 'cuda', 'move_dgl_to_cuda'):
+        rs = inspect.signature(getattr(ref.utils, fn))
+        ms = inspect.signature(getattr(U, fn))
+        assert list(rs.parameters) == list(ms.parameters), fn
+    # state_dict keys and shapes (checkpoint compatibility)
+    r_net = ref.model.RENet(50, 200, 7, dropout=0.5, seq_len=10, num_k=10)
+    m_net = M.RENet(50, 200, 7, dropout=0.5, seq_len=10, num_k=10)
+    assert {k: tuple(v.shape) for k, v in r_net.state_dict().items()} == \
+        {k: tuple(v.shape) for k, v in m_net.state_dict().items()}
+    r_g = ref.global_model.RENet_global(50, 200, 7, dropout=0.5, seq_len=10, num_k=10, maxpool=1)
+    m_g = GM.RENet_global(50, 200, 7, dropout=0.5, seq_len=10, num_k=10, maxpool=1)
+    assert {k: tuple(v.shape) for k, v in r_g.state_dict().items()} == \
+        {k: tuple(v.shape) for k, v in m_g.state_dict().items()}
+
+
+def test_preprocess_cli_writes_reference_layout(tmp_path):
+    import pickle
+    import preprocess as P
+    cfg, tr, va, te = fixtures.split_dataset('tiny')
+    for name, q in (('train.txt', tr), ('valid.txt', va), ('test.txt', te)):
+        with open(tmp_path / name, 'w') as f:
+            for s, r, o, t in q:
+                f.write('%d\t%d\t%d\t%d\t0\n' % (s, r, o, t))
+    with open(tmp_path / 'stat.txt', 'w') as f:
+        f.write('%d\t%d\t0\n' % (cfg['num_ent'], cfg['num_rels']))
+    P.write_reference_pickles(str(tmp_path))
+    gold = np.load(os.path.join(ROOT, 'tests', 'golden', 'prep_tiny.npz'))
+    for split, fn in (('train', 'train'), ('valid', 'dev'), ('test', 'test')):
+        for tag, name in (('s', 'sub'), ('o', 'ob')):
+            with open(tmp_path / ('%s_history_%s.txt' % (fn, name)), 'rb') as f:
+                mine = pickle.load(f)
+            ref = fixtures.unflatten_histories(gold['%s_%s_seq_ptr' % (split, tag)], gold['%s_%s_step_t' % (split, tag)],
+                                               gold['%s_%s_nbr_ptr' % (split, tag)], gold['%s_%s_nbr' % (split, tag)])
+            assert fixtures.histories_equal((mine[0], mine[1]), ref), (split, tag)
+    with open(tmp_path / 'train_graphs.txt', 'rb') as f:
+        gd = pickle.load(f)
+    assert list(gd.keys()) == gold['graph_t'].tolist()
+    k = len(gd) // 2
+    t = list(gd.keys())[k]
+    e0, e1 = gold['graph_edge_ptr'][k], gold['graph_edge_ptr'][k + 1]
+    src, dst, et = gd[t].edges(False)
+    assert np.array_equal(src, gold['graph_src'][e0:e1]) and np.array_equal(et, gold['graph_type_s'][e0:e1])

@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""Runs one of the reference's UNMODIFIED drivers (train.py / test.py / pretrain.py) on top of the
+MI355X modules: `re-net_amd/` is put first on sys.path so that the driver's top-level imports
+(`import utils`, `from model import RENet`, `from global_model import RENet_global`, train.py:5-8) resolve
+to this repository's implementation; runpy does not add the script's own directory.
+
+    cd <workdir with data/<DS>/ and models/>      # pickles made by `python re-net_amd/preprocess.py <dir>`
+    python tools/run_reference_driver.py /path/to/RE-Net/train.py -d YAGO --gpu 0 --n-hidden 200
+"""
+import os
+import runpy
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    if len(sys.argv) < 2:
+        raise SystemExit(__doc__)
+    script = os.path.abspath(sys.argv[1])
+    sys.path.insert(0, os.path.join(ROOT, 're-net_amd'))
+    sys.argv = [script] + sys.argv[2:]
+    runpy.run_path(script, run_name='__main__')
+
+
+if __name__ == '__main__':
+    main()
