@@ -147,6 +147,19 @@ def main():
         return
 
     # ---- roofline of the dominant kernel class (HIP events recorded on the launch stream) ---------
+    # `traffic`: HBM bytes per launch from the PMC pass of this same command (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate runs, FETCH doubled for 16 B/lane reads per MI355X_MICROARCH.md), committed as
+    # profiles/r01_pmc_traffic.json -- counters cannot be read from inside the process.
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
+            pmc = json.load(f).get('classes', {})
+    except (OSError, ValueError):
+        pmc = {}
+    same_workload = (args.shape == 'ICEWS18' and args.batch == 1024 and args.hidden == 200 and args.seq_len == 10)
+
+    def traffic_of(name):
+        return pmc[name]['hbm_bytes_per_launch'] if (same_workload and name in pmc) else None
     stats = timer.summary()
     g0 = prepared[args.warmup][0].g.host
     kernels = {}
@@ -165,17 +178,18 @@ def main():
         if st['flops']:
             ach = st['flops'] / (st['ms'] * 1e-3) / 1e12
             roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TF,
-                        'unit': 'TFLOP/s', 'frac': ach / MFMA_F32_PEAK_TF, 'traffic': None}
+                        'unit': 'TFLOP/s', 'frac': ach / MFMA_F32_PEAK_TF, 'traffic': traffic_of(dom)}
         else:
             ach = st['bytes'] / (st['ms'] * 1e-3) / 1e9
             roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': ach / HBM_PEAK_GBS, 'traffic': None}
+                        'frac': ach / HBM_PEAK_GBS, 'traffic': traffic_of(dom)}
     gather = None
     if 'rgcn_gather' in stats:
         st = stats['rgcn_gather']
         ach = st['bytes'] / (st['ms'] * 1e-3) / 1e9
         gather = {'kernel': 'rgcn_gather', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                  'frac': ach / HBM_PEAK_GBS, 'traffic': None, 'avg_us': st['ms'] * 1e3 / st['calls'],
+                  'frac': ach / HBM_PEAK_GBS, 'traffic': traffic_of('rgcn_gather'),
+                  'avg_us': st['ms'] * 1e3 / st['calls'],
                   'algorithmic_bytes_per_launch': st['bytes'] / st['calls']}
 
     # ---- CPU baseline: the oracle (restated reference path) on this box's host cores -------------
