@@ -159,6 +159,15 @@ int renet_gru_fwd(const float* Gi, const int32_t* step_off, int L, int H, const 
 int renet_gru_bwd(const float* dh_last, const int32_t* step_off, int L, int H, const float* Whh,
                   const float* saved, float* dGi, float* dGh, float* workspace,
                   size_t workspace_bytes, void* stream);
+/* n (1 or 2) independent GRUs over the SAME packed layout in one launch (RE-Net's `encoder` and
+ * `encoder_r`, model.py:86,94): every pointer argument is a HOST array of n device pointers;
+ * the backward workspace is n * renet_gru_workspace bytes. */
+int renet_gru_fwd_multi(int n, const float* const* Gi, const int32_t* step_off, int L, int H,
+                        const float* const* Whh, const float* const* bhh, float* const* h_last,
+                        float* const* saved, void* stream);
+int renet_gru_bwd_multi(int n, const float* const* dh_last, const int32_t* step_off, int L, int H,
+                        const float* const* Whh, const float* const* saved, float* const* dGi,
+                        float* const* dGh, float* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Score head (model.py:89-91, 98-100).

@@ -42,13 +42,23 @@ struct Cfg {
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
+// Up to MAXP independent GRUs with the same packed layout (RE-Net's `encoder` and `encoder_r` consume the
+// same batch, model.py:86,94) run in ONE launch: blockIdx.y selects the problem, so the two recurrences
+// -- each only ~60 workgroups -- share the chip instead of running back to back.
+constexpr int MAXP = 2;
+struct FwdProb { const float* Gi; const float* Whh; const float* bhh; float* h_last; float* saved; };
+struct FwdProbs { FwdProb p[MAXP]; };
+struct BwdProb { const float* dh_last; const float* WhhT; const float* saved; float* dGi; float* dGh; };
+struct BwdProbs { BwdProb p[MAXP]; };
+
 template <int H>
-__global__ __launch_bounds__(NT) void gru_fwd_kernel(const float* __restrict__ Gi, StepOff so, int L,
-                                                      const float* __restrict__ Whh,
-                                                      const float* __restrict__ bhh,
-                                                      float* __restrict__ h_last,
-                                                      float* __restrict__ saved) {
+__global__ __launch_bounds__(NT) void gru_fwd_kernel(FwdProbs ps, StepOff so, int L) {
     using C = Cfg<H>;
+    const float* __restrict__ Gi = ps.p[blockIdx.y].Gi;
+    const float* __restrict__ Whh = ps.p[blockIdx.y].Whh;
+    const float* __restrict__ bhh = ps.p[blockIdx.y].bhh;
+    float* __restrict__ h_last = ps.p[blockIdx.y].h_last;
+    float* __restrict__ saved = ps.p[blockIdx.y].saved;
     __shared__ __attribute__((aligned(16))) float Hs[MT * C::LDH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = blockIdx.x * MT;
@@ -144,11 +154,13 @@ __global__ __launch_bounds__(NT) void gru_fwd_kernel(const float* __restrict__ G
 // LDS as the A operand of   dh_prev = dh * z + dGh W_hh   (K = 3H, B fragments from W_hh^T [H, 3H]).
 // ---------------------------------------------------------------------------------------------
 template <int H>
-__global__ __launch_bounds__(NT) void gru_bwd_kernel(const float* __restrict__ dh_last, StepOff so, int L,
-                                                      const float* __restrict__ WhhT,   // [H, 3H]
-                                                      const float* __restrict__ saved,
-                                                      float* __restrict__ dGi, float* __restrict__ dGh) {
+__global__ __launch_bounds__(NT) void gru_bwd_kernel(BwdProbs ps, StepOff so, int L) {
     using C = Cfg<H>;
+    const float* __restrict__ dh_last = ps.p[blockIdx.y].dh_last;
+    const float* __restrict__ WhhT = ps.p[blockIdx.y].WhhT;          // [H, 3H]
+    const float* __restrict__ saved = ps.p[blockIdx.y].saved;
+    float* __restrict__ dGi = ps.p[blockIdx.y].dGi;
+    float* __restrict__ dGh = ps.p[blockIdx.y].dGh;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dHs = smem;                         // [MT][LDH]
     float* Gs = smem + MT * C::LDH;            // [MT][LDG]  dGh tile (k-padded with zeros)
@@ -237,17 +249,14 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }
 
 template <int H>
-int launch_fwd(const float* Gi, const StepOff& so, int L, int B, const float* Whh, const float* bhh,
-               float* h_last, float* saved, hipStream_t st) {
-    hipLaunchKernelGGL((gru_fwd_kernel<H>), dim3((B + MT - 1) / MT), dim3(NT), 0, st, Gi, so, L, Whh, bhh,
-                       h_last, saved);
+int launch_fwd(const FwdProbs& ps, int np, const StepOff& so, int L, int B, hipStream_t st) {
+    hipLaunchKernelGGL((gru_fwd_kernel<H>), dim3((B + MT - 1) / MT, np), dim3(NT), 0, st, ps, so, L);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
 
 template <int H>
-int launch_bwd(const float* dh_last, const StepOff& so, int L, int B, const float* WhhT, const float* saved,
-               float* dGi, float* dGh, hipStream_t st) {
+int launch_bwd(const BwdProbs& ps, int np, const StepOff& so, int L, int B, hipStream_t st) {
     using C = Cfg<H>;
     const size_t lds = (size_t)MT * (C::LDH + C::LDG) * sizeof(float);
     static bool attr_set = false;      // benign race: the attribute is idempotent
@@ -257,8 +266,7 @@ int launch_bwd(const float* dh_last, const StepOff& so, int L, int B, const floa
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gru_bwd_kernel<H>), dim3((B + MT - 1) / MT), dim3(NT), lds, st, dh_last, so, L, WhhT,
-                       saved, dGi, dGh);
+    hipLaunchKernelGGL((gru_bwd_kernel<H>), dim3((B + MT - 1) / MT, np), dim3(NT), lds, st, ps, so, L);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -282,44 +290,73 @@ size_t renet_gru_workspace(int B, int H) {
     return (size_t)3 * H * H * sizeof(float);                     // W_hh^T for the backward pass
 }
 
-int renet_gru_fwd(const float* Gi, const int32_t* step_off, int L, int H, const float* Whh,
-                  const float* bhh, float* h_last, float* saved, float* workspace,
-                  size_t workspace_bytes, void* stream) {
-    (void)workspace; (void)workspace_bytes;
+int renet_gru_fwd_multi(int n, const float* const* Gi, const int32_t* step_off, int L, int H,
+                        const float* const* Whh, const float* const* bhh, float* const* h_last,
+                        float* const* saved, void* stream) {
+    if (n < 1 || n > MAXP) return RENET_ERR_BADARG;
     if (L == 0) return RENET_OK;
     StepOff so;
     int B;
     if (!fill_offsets(step_off, L, so, B)) return RENET_ERR_BADARG;
     if (B == 0) return RENET_OK;
+    FwdProbs ps;
+    for (int i = 0; i < MAXP; ++i) {
+        const int k = i < n ? i : 0;
+        ps.p[i].Gi = Gi[k]; ps.p[i].Whh = Whh[k]; ps.p[i].bhh = bhh[k]; ps.p[i].h_last = h_last[k];
+        ps.p[i].saved = saved[k];
+    }
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
-        case 100: return launch_fwd<100>(Gi, so, L, B, Whh, bhh, h_last, saved, st);
-        case 200: return launch_fwd<200>(Gi, so, L, B, Whh, bhh, h_last, saved, st);
-        case 400: return launch_fwd<400>(Gi, so, L, B, Whh, bhh, h_last, saved, st);
+        case 100: return launch_fwd<100>(ps, n, so, L, B, st);
+        case 200: return launch_fwd<200>(ps, n, so, L, B, st);
+        case 400: return launch_fwd<400>(ps, n, so, L, B, st);
         default: return RENET_ERR_UNSUPPORTED;
     }
 }
 
-int renet_gru_bwd(const float* dh_last, const int32_t* step_off, int L, int H, const float* Whh,
-                  const float* saved, float* dGi, float* dGh, float* workspace,
+int renet_gru_fwd(const float* Gi, const int32_t* step_off, int L, int H, const float* Whh,
+                  const float* bhh, float* h_last, float* saved, float* workspace,
                   size_t workspace_bytes, void* stream) {
+    (void)workspace; (void)workspace_bytes;
+    return renet_gru_fwd_multi(1, &Gi, step_off, L, H, &Whh, &bhh, &h_last, &saved, stream);
+}
+
+int renet_gru_bwd_multi(int n, const float* const* dh_last, const int32_t* step_off, int L, int H,
+                        const float* const* Whh, const float* const* saved, float* const* dGi,
+                        float* const* dGh, float* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 1 || n > MAXP) return RENET_ERR_BADARG;
     if (L == 0) return RENET_OK;
     StepOff so;
     int B;
     if (!fill_offsets(step_off, L, so, B)) return RENET_ERR_BADARG;
     if (B == 0) return RENET_OK;
     if (H != 100 && H != 200 && H != 400) return RENET_ERR_UNSUPPORTED;
-    if (workspace_bytes < renet_gru_workspace(B, H)) return RENET_ERR_WORKSPACE;
+    if (workspace_bytes < (size_t)n * renet_gru_workspace(B, H)) return RENET_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    float* WhhT = workspace;
-    hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, st, Whh, 3 * H, H,
-                       WhhT);
-    RENET_LAUNCH_CHECK();
-    switch (H) {
-        case 100: return launch_bwd<100>(dh_last, so, L, B, WhhT, saved, dGi, dGh, st);
-        case 200: return launch_bwd<200>(dh_last, so, L, B, WhhT, saved, dGi, dGh, st);
-        default: return launch_bwd<400>(dh_last, so, L, B, WhhT, saved, dGi, dGh, st);
+    BwdProbs ps;
+    for (int i = 0; i < MAXP; ++i) {
+        const int k = i < n ? i : 0;
+        float* WhhT = workspace + (size_t)k * 3 * H * H;
+        if (i < n) {
+            hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, st, Whh[k],
+                               3 * H, H, WhhT);
+            RENET_LAUNCH_CHECK();
+        }
+        ps.p[i].dh_last = dh_last[k]; ps.p[i].WhhT = WhhT; ps.p[i].saved = saved[k]; ps.p[i].dGi = dGi[k];
+        ps.p[i].dGh = dGh[k];
     }
+    switch (H) {
+        case 100: return launch_bwd<100>(ps, n, so, L, B, st);
+        case 200: return launch_bwd<200>(ps, n, so, L, B, st);
+        default: return launch_bwd<400>(ps, n, so, L, B, st);
+    }
+}
+
+int renet_gru_bwd(const float* dh_last, const int32_t* step_off, int L, int H, const float* Whh,
+                  const float* saved, float* dGi, float* dGh, float* workspace,
+                  size_t workspace_bytes, void* stream) {
+    return renet_gru_bwd_multi(1, &dh_last, step_off, L, H, &Whh, &saved, &dGi, &dGh, workspace,
+                               workspace_bytes, stream);
 }
 
 }  // extern "C"

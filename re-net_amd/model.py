@@ -124,6 +124,7 @@ class RENet(nn.Module):
             perm = g.host.perm
             prep.s_idx, prep.r_idx, prep.plan_s, prep.plan_r = g.s_sorted, g.r_sorted, g.plan_s, g.plan_r
             prep.batch_sizes = torch.from_numpy(g.host.batch_sizes)
+            prep.step_off = ops.host_offsets(g.host.step_off)
         prep.perm = perm
         prep.o_idx = torch.from_numpy(o[perm].astype(np.int32)).to(dev)
         return prep
@@ -140,8 +141,10 @@ class RENet(nn.Module):
             s_q = torch.zeros(b, self.h_dim, device=dev)
         else:
             x, xr = self.aggregator.encode(g, self.ent_embeds, rel_embeds, reverse=not subject)
-            _, s_h = self.encoder(PackedSequence(x, prep.batch_sizes), total_rows=b)      # model.py:86-88
-            _, s_q = self.encoder_r(PackedSequence(xr, prep.batch_sizes), total_rows=b)   # model.py:94-96
+            e, er = self.encoder, self.encoder_r                                      # model.py:86-88, 94-96
+            s_h, s_q = ops.DualGRUFn.apply(x, xr, e.weight_ih_l0, e.weight_hh_l0, e.bias_ih_l0, e.bias_hh_l0,
+                                           er.weight_ih_l0, er.weight_hh_l0, er.bias_ih_l0, er.bias_hh_l0,
+                                           prep.step_off, b)
             s_h, s_q = s_h[0], s_q[0]
         p = self.drop_p if self.training else 0.0
         loss_sub = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_h, rel_embeds, prep.r_idx,
@@ -161,7 +164,8 @@ class RENet(nn.Module):
 
 class PreparedBatch(object):
     """Device-resident inputs of one direction of one step (see RENet.prepare)."""
-    __slots__ = ('g', 'subject', 'b', 'perm', 's_idx', 'r_idx', 'o_idx', 'plan_s', 'plan_r', 'batch_sizes')
+    __slots__ = ('g', 'subject', 'b', 'perm', 's_idx', 'r_idx', 'o_idx', 'plan_s', 'plan_r', 'batch_sizes',
+                 'step_off')
 
 
 def _device_plan(idx, device):

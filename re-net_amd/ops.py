@@ -136,6 +136,44 @@ class GRUFn(Function):
         return dx, d_wih, d_whh, d_bih, d_bhh, None, None
 
 
+class DualGRUFn(Function):
+    """RE-Net's two history encoders (`encoder` 4D->D and `encoder_r` 3D->D, model.py:86,94) over the same
+    packed batch: input projections as two GEMMs, both recurrences in ONE persistent launch."""
+
+    @staticmethod
+    def forward(ctx, x, xr, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, step_off, total_rows):
+        ts = [_c(t) for t in (x, xr, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)]
+        x, xr, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r = ts
+        hdim = w_hh.shape[1]
+        gi = K.gemm(x, w_ih, tb=True, bias=b_ih)
+        gir = K.gemm(xr, w_ih_r, tb=True, bias=b_ih_r)
+        (h, q), (sv, svr) = K.gru_fwd_multi([gi, gir], step_off, hdim, [w_hh, w_hh_r], [b_hh, b_hh_r])
+        nnz = h.shape[0]
+        outs = []
+        for t in (h, q):
+            if total_rows > nnz:
+                full = torch.zeros(total_rows, hdim, device=x.device, dtype=torch.float32)
+                full[:nnz] = t
+                t = full
+            outs.append(t.unsqueeze(0))
+        ctx.step_off, ctx.nnz, ctx.hdim = step_off, nnz, hdim
+        ctx.save_for_backward(x, xr, w_ih, w_hh, w_ih_r, w_hh_r, sv, svr)
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, dh, dq):
+        x, xr, w_ih, w_hh, w_ih_r, w_hh_r, sv, svr = ctx.saved_tensors
+        hdim, nnz = ctx.hdim, ctx.nnz
+        (d_gi, d_gir), (d_gh, d_ghr) = K.gru_bwd_multi([_c(dh[0, :nnz]), _c(dq[0, :nnz])], ctx.step_off, hdim,
+                                                       [w_hh, w_hh_r], [sv, svr])
+        res = []
+        for xx, wi, dgi, dgh, s_ in ((x, w_ih, d_gi, d_gh, sv), (xr, w_ih_r, d_gir, d_ghr, svr)):
+            res.append((K.gemm(dgi, wi), K.gemm(dgi, xx, ta=True), K.gemm(dgh, s_[:, 4 * hdim:], ta=True),
+                        K.colsum(dgi), K.colsum(dgh)))
+        (dx, dwi, dwh, dbi, dbh), (dxr, dwir, dwhr, dbir, dbhr) = res
+        return dx, dxr, dwi, dwh, dbi, dbh, dwir, dwhr, dbir, dbhr, None, None
+
+
 class HeadCEFn(Function):
     """model.py:89-91 / 98-100: mean CE( Linear( dropout([a[ia] | hmid | c[ic]]) ), target ).
     The logits never make a second HBM round trip as a separate softmax: the CE kernel turns them

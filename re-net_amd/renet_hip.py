@@ -47,6 +47,10 @@ _SIGNATURES = {
                               c_void_p, c_size_t, c_void_p]),
     'renet_gru_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_size_t, c_void_p]),
+    'renet_gru_fwd_multi': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    'renet_gru_bwd_multi': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_concat3_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                                   c_u64, c_void_p, c_void_p]),
     'renet_concat3_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_u64, c_void_p, c_void_p,
@@ -314,6 +318,41 @@ def gru_bwd(dh_last, step_off_host, hdim, w_hh, saved):
     _check(lib().renet_gru_bwd(_f32(dh_last), ctypes.cast(step_off_host, c_void_p), L, hdim, _f32(w_hh),
                                _f32(saved), _f32(d_gi), _f32(d_gh), ws.data_ptr(), nbytes, _stream()), 'gru_bwd')
     return d_gi, d_gh
+
+
+def _ptrs(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def gru_fwd_multi(gis, step_off_host, hdim, w_hhs, b_hhs):
+    """n GRUs over the same packed layout in one launch -> ([h_last...], [saved...])."""
+    L = len(step_off_host) - 1
+    b = step_off_host[1] - step_off_host[0] if L > 0 else 0
+    dev = gis[0].device
+    hs = [torch.empty(b, hdim, device=dev, dtype=torch.float32) for _ in gis]
+    svs = [torch.empty(g.shape[0], 5 * hdim, device=dev, dtype=torch.float32) for g in gis]
+    for t in list(gis) + list(w_hhs) + list(b_hhs):
+        _f32(t)
+    _check(lib().renet_gru_fwd_multi(len(gis), _ptrs(gis), ctypes.cast(step_off_host, c_void_p), L, hdim,
+                                     _ptrs(w_hhs), _ptrs(b_hhs), _ptrs(hs), _ptrs(svs), _stream()),
+           'gru_fwd_multi')
+    return hs, svs
+
+
+def gru_bwd_multi(dh_lasts, step_off_host, hdim, w_hhs, saveds):
+    L = len(step_off_host) - 1
+    n = len(dh_lasts)
+    dev = saveds[0].device
+    d_gis = [torch.empty(s.shape[0], 3 * hdim, device=dev, dtype=torch.float32) for s in saveds]
+    d_ghs = [torch.empty(s.shape[0], 3 * hdim, device=dev, dtype=torch.float32) for s in saveds]
+    for t in list(dh_lasts) + list(w_hhs) + list(saveds):
+        _f32(t)
+    nbytes = n * lib().renet_gru_workspace(dh_lasts[0].shape[0], hdim)
+    ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
+    _check(lib().renet_gru_bwd_multi(n, _ptrs(dh_lasts), ctypes.cast(step_off_host, c_void_p), L, hdim,
+                                     _ptrs(w_hhs), _ptrs(saveds), _ptrs(d_gis), _ptrs(d_ghs), ws.data_ptr(),
+                                     nbytes, _stream()), 'gru_bwd_multi')
+    return d_gis, d_ghs
 
 
 def concat3_fwd(a, ia, hmid, c, ic, drop_p, seed):
