@@ -80,13 +80,59 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     }
 }
 
+// Branch-free tile load: every thread always issues its 4 global_load_dwordx4.  Out-of-range rows / k
+// are handled by CLAMPING the address into the matrix and fixing the value up afterwards (zero, or a
+// component shift for the one float4 that straddles the end of the contiguous dimension), so the
+// compiler can issue all loads back to back and overlap them with the MFMAs -- per-element predication
+// (the generic loader above) costs 15-25 % on the shapes of this workload, whose N = 600 / 200 always
+// has a partial tile.  gfx950 global loads only need dword alignment, so odd leading dimensions
+// (dW_lin: lda = 23033) take this path too.  Needs >= 4 elements along the contiguous dimension.
+__device__ __forceinline__ float4 shift_tail(float4 v, int d) {
+    // element j of the result = v[j + d] if j + d < 4 else 0      (d = 1..3)
+    if (d == 1) return make_float4(v.y, v.z, v.w, 0.f);
+    if (d == 2) return make_float4(v.z, v.w, 0.f, 0.f);
+    return make_float4(v.w, 0.f, 0.f, 0.f);
+}
+
 template <bool CONTIG_K>
-__device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const float4 (&r)[4]) {
+__device__ __forceinline__ void load_tile_any(const float* __restrict__ P, int ld, int rows, int K, int row0,
+                                              int k0, int tid, bool small, float4 (&r)[4]) {
+    if (small) {
+        load_tile<CONTIG_K>(P, ld, rows, K, row0, k0, tid, false, r);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = tid + THREADS * i;
-        if constexpr (CONTIG_K) *reinterpret_cast<float4*>(&S[(f >> 3) * LDK + ((f & 7) << 2)]) = r[i];
-        else *reinterpret_cast<float4*>(&S[(f >> 5) * LDR + ((f & 31) << 2)]) = r[i];
+        // c = index along the contiguous dimension (extent C), o = index along the other one (extent O)
+        const int c = CONTIG_K ? k0 + ((f & 7) << 2) : row0 + ((f & 31) << 2);
+        const int o = CONTIG_K ? row0 + (f >> 3) : k0 + (f >> 5);
+        const int C = CONTIG_K ? K : rows;
+        const int O = CONTIG_K ? rows : K;
+        r[i] = *reinterpret_cast<const float4*>(P + (size_t)min(o, O - 1) * ld + min(c, C - 4));
+    }
+}
+
+// registers -> LDS.  The out-of-range fix-up of the clamped loads happens HERE (one iteration after the
+// load was issued), never right behind the load: a select on a just-loaded value would make the compiler
+// wait for the load before the MFMA phase instead of after it.
+template <bool CONTIG_K>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, int rows, int K, int row0, int k0, int tid,
+                                           bool small, const float4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + THREADS * i;
+        float4 v = r[i];
+        if (!small) {
+            const int c = CONTIG_K ? k0 + ((f & 7) << 2) : row0 + ((f & 31) << 2);
+            const int o = CONTIG_K ? row0 + (f >> 3) : k0 + (f >> 5);
+            const int C = CONTIG_K ? K : rows;
+            const int O = CONTIG_K ? rows : K;
+            if (o >= O || c >= C) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            else if (c > C - 4) v = shift_tail(v, c - (C - 4));
+        }
+        if constexpr (CONTIG_K) *reinterpret_cast<float4*>(&S[(f >> 3) * LDK + ((f & 7) << 2)]) = v;
+        else *reinterpret_cast<float4*>(&S[(f >> 5) * LDR + ((f & 31) << 2)]) = v;
     }
 }
 
@@ -128,15 +174,18 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    (void)a_vec; (void)b_vec;
+    const bool a_full = (g.K < 4) || (g.M < 4);        // `small`: too short to clamp -> generic loader
+    const bool b_full = (g.K < 4) || (g.N < 4);
     float4 ra[4], rb[4];
     if (kt0 < kt1) {
-        load_tile<A_CK>(g.A, g.lda, g.M, g.K, m0, kt0 * BK, tid, a_vec, ra);
-        load_tile<B_CK>(g.B, g.ldb, g.N, g.K, n0, kt0 * BK, tid, b_vec, rb);
-        store_tile<A_CK>(smem[0][0], tid, ra);
-        store_tile<B_CK>(smem[0][1], tid, rb);
+        load_tile_any<A_CK>(g.A, g.lda, g.M, g.K, m0, kt0 * BK, tid, a_full, ra);
+        load_tile_any<B_CK>(g.B, g.ldb, g.N, g.K, n0, kt0 * BK, tid, b_full, rb);
+        store_tile<A_CK>(smem[0][0], g.M, g.K, m0, kt0 * BK, tid, a_full, ra);
+        store_tile<B_CK>(smem[0][1], g.N, g.K, n0, kt0 * BK, tid, b_full, rb);
         if (kt0 + 1 < kt1) {
-            load_tile<A_CK>(g.A, g.lda, g.M, g.K, m0, (kt0 + 1) * BK, tid, a_vec, ra);
-            load_tile<B_CK>(g.B, g.ldb, g.N, g.K, n0, (kt0 + 1) * BK, tid, b_vec, rb);
+            load_tile_any<A_CK>(g.A, g.lda, g.M, g.K, m0, (kt0 + 1) * BK, tid, a_full, ra);
+            load_tile_any<B_CK>(g.B, g.ldb, g.N, g.K, n0, (kt0 + 1) * BK, tid, b_full, rb);
         }
     }
     __syncthreads();
@@ -147,12 +196,12 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(GemmArgs g) {
     for (int kt = kt0; kt < kt1; ++kt) {
         const int cur = (kt - kt0) & 1;
         if (kt + 1 < kt1) {                    // tile t+1: registers -> the other LDS buffer
-            store_tile<A_CK>(smem[cur ^ 1][0], tid, ra);
-            store_tile<B_CK>(smem[cur ^ 1][1], tid, rb);
+            store_tile<A_CK>(smem[cur ^ 1][0], g.M, g.K, m0, (kt + 1) * BK, tid, a_full, ra);
+            store_tile<B_CK>(smem[cur ^ 1][1], g.N, g.K, n0, (kt + 1) * BK, tid, b_full, rb);
         }
         if (kt + 2 < kt1) {                    // tile t+2: global -> registers, lands during the MFMAs below
-            load_tile<A_CK>(g.A, g.lda, g.M, g.K, m0, (kt + 2) * BK, tid, a_vec, ra);
-            load_tile<B_CK>(g.B, g.ldb, g.N, g.K, n0, (kt + 2) * BK, tid, b_vec, rb);
+            load_tile_any<A_CK>(g.A, g.lda, g.M, g.K, m0, (kt + 2) * BK, tid, a_full, ra);
+            load_tile_any<B_CK>(g.B, g.ldb, g.N, g.K, n0, (kt + 2) * BK, tid, b_full, rb);
         }
         const float* As = smem[cur][0];
         const float* Bs = smem[cur][1];

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'librenet_hip.so')
+LIB_PATH = os.environ.get('RENET_HIP_LIB', os.path.join(_HERE, 'csrc', 'librenet_hip.so'))   # env: A/B builds
 
 _lib = None
 
@@ -213,20 +213,19 @@ def auto_split_k(m, n, k):
     """split-K factor when the output has too few 128x128 tiles to fill 256 CUs (weight-gradient and
     dX-of-the-head shapes): aim at ~2 workgroups per CU, keep >= 4 k-tiles per slice."""
     tiles = ((m + 127) // 128) * ((n + 127) // 128)
-    if tiles >= 200:
+    if tiles >= 512:
         return 1
     ktiles = (k + 31) // 32
-    smax = int(max(1, min(max(ktiles // 4, 1), 128)))
-    # 2 workgroups are resident per CU (73.7 KB LDS each): pick the split whose workgroup count fills
-    # whole rounds of 512 best (e.g. 40 tiles: 12 slices = 480 WGs in one round, not 13 = 520 in two)
-    best, best_u = 1, 0.0
+    # 2 workgroups are resident per CU (73.7 KB LDS each) => rounds of 512.  Swept on MI355X
+    # (tools/gemm_sweep.py): the best split fills one or two rounds almost exactly (40 tiles -> 12 slices =
+    # 480 workgroups; 35 -> 14; 300 -> 3) and more slices only add partial-sum traffic.
+    smax = int(max(1, min(128, ktiles // 6, max(1024 // tiles, 1))))
+    best, best_score = 1, -1.0
     for s in range(1, smax + 1):
         wgs = tiles * s
-        util = wgs / float(((wgs + 511) // 512) * 512)
-        if wgs < 256:
-            util *= wgs / 256.0
-        if util > best_u + 1e-9:
-            best, best_u = s, util
+        score = wgs / float(((wgs + 511) // 512) * 512) - 0.004 * s
+        if score > best_score + 1e-12:
+            best, best_score = s, score
     return best
 
 
