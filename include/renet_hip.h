@@ -68,6 +68,9 @@ int renet_segment_add(const float* src, const int32_t* order, const int32_t* seg
  * heavy_rows[n_heavy] (optional, may be NULL/0) lists the rows whose in-degree exceeds heavy_thresh:
  * the row-group kernel skips them and a second launch reduces each with a whole workgroup, so a
  * Zipf-tail hub row cannot serialise one wave for the entire launch.
+ * src_limit > 0 skips edges whose source row is >= src_limit and addend_rows > 0 restricts the addend to
+ * rows < addend_rows (0 = no restriction): used by the backward of a layer that was only evaluated on a
+ * prefix of the rows (RE-Net reads the second RGCN layer only at the subject rows, Aggregator.py:139-140).
  * The backward wrt x uses the same CSR: RE-Net graphs hold both directions of every fact with paired
  * types (utils.py:74-76), so the transposed graph is the same structure with type_shift = num_rels.
  * ---------------------------------------------------------------------------------------------- */
@@ -75,7 +78,7 @@ int renet_rgcn_gather(const float* x, int D, const int32_t* row_ptr, const int32
                       const int32_t* etype, const float* scale, const float* W, int T, int type_shift,
                       int transpose_w, const float* addend, float drop_p, uint64_t seed, int relu,
                       float* out, int N, const int32_t* heavy_rows, int n_heavy, int heavy_thresh,
-                      void* stream);
+                      int src_limit, int addend_rows, void* stream);
 
 /* Backward prologue of one RGCN layer (element-wise, RGCN.py:42-50 + :93-94 reversed):
  *   g_pre = g_out * (relu ? out > 0 : 1);  gn = g_pre * norm[v];  g_loop = g_pre * dropmask       */

@@ -97,8 +97,10 @@ class RGCNAggregator(nn.Module):
         """Device side: h0 gather, two RGCN layers, packed sequence assembly (Aggregator.py:136-165)."""
         g.ndata['h'] = ops.GatherRowsFn.apply(ent_embeds, g.node_ent, g.plan_node_ent)      # utils.py:239
         self.rgcn1(g, reverse)
+        g.out_rows = g.nA               # only the subject rows of layer 2 are ever read (Aggregator.py:139-140)
         self.rgcn2(g, reverse)
-        h2 = g.ndata.pop('h')
+        g.out_rows = None
+        h2 = g.ndata.pop('h')           # [nA, D]; subj_row < nA by construction
         p = self.drop_p if self.training else 0.0
         sx, sxr = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
         return ops.SeqAssembleFn.apply(h2, ent_embeds, rel_embeds, g.glob, g, p, sx, sxr)

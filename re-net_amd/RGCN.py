@@ -50,7 +50,9 @@ class RGCNBlockLayer(RGCNLayer):
 
     def forward(self, g, reverse):
         p = self.drop_p if self.training else 0.0
+        # g.out_rows (set by the aggregator for the LAST layer) = evaluate only the first out_rows rows
         h = ops.RGCNLayerFn.apply(g.ndata['h'], self.weight, self.loop_weight, g, bool(reverse),
-                                  self.activation is not None, p, ops.next_seed() if p > 0 else 0)
+                                  self.activation is not None, p, ops.next_seed() if p > 0 else 0,
+                                  getattr(g, 'out_rows', None))
         g.ndata['h'] = h
         return g

@@ -62,6 +62,8 @@ struct GatherArgs {
     float* out;
     const int32_t* heavy;       // rows with in-degree > heavy_thresh, handled by rgcn_gather_heavy_kernel
     int n_heavy, heavy_thresh;
+    int src_limit;              // edges whose source row is >= src_limit are skipped (pruned layer-2 backward)
+    int addend_rows;            // rows >= addend_rows have no addend
     int N, T, shift, relu;
     DropCfg drop;
 };
@@ -69,7 +71,7 @@ struct GatherArgs {
 template <int CH>
 __device__ __forceinline__ void gather_epilogue(const GatherArgs& a, int v, int ch, float4 o, float sc) {
     o = f4_scale(o, sc);
-    if (a.addend) {
+    if (a.addend && v < a.addend_rows) {
         float4 ad = reinterpret_cast<const float4*>(a.addend)[(size_t)v * CH + ch];
         ad = f4_mul(ad, renet_drop4(a.drop, (uint64_t)v * CH + ch));
         o = f4_add(o, ad);
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void rgcn_gather_kernel(GatherArgs a) {
             float4 wv[UNR][NCH][WCH];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                if (k0 + u < cnt) {
+                if (k0 + u < cnt && __builtin_amdgcn_readlane(my_col, k0 + u) < a.src_limit) {
                     const int src = __builtin_amdgcn_readlane(my_col, k0 + u);   // wave-uniform -> SGPR base
                     const int t = __builtin_amdgcn_readlane(my_t, k0 + u);
                     const float4* xr = x4 + (size_t)src * CH;
@@ -194,9 +196,11 @@ __global__ __launch_bounds__(kThreads) void rgcn_gather_kernel(GatherArgs a) {
                 if (k0 + u < cnt && e == eb + k0 + u) {
                     while (e >= row_end) flush();
                     if (!row_heavy) {
+                        if (__builtin_amdgcn_readlane(my_col, k0 + u) < a.src_limit) {
 #pragma unroll
-                        for (int c = 0; c < NCH; ++c)
-                            if (lane + 64 * c < CH) blockmul<SI, TR>(xv[u][c], wv[u][c], acc[c]);
+                            for (int c = 0; c < NCH; ++c)
+                                if (lane + 64 * c < CH) blockmul<SI, TR>(xv[u][c], wv[u][c], acc[c]);
+                        }
                         ++e;
                     }
                 }
@@ -228,7 +232,7 @@ __device__ __forceinline__ void gather_heavy_row(const GatherArgs& a, int v) {
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int ee = e + u * kWaves;
-            if (ee < e1) {
+            if (ee < e1 && a.col[ee] < a.src_limit) {
                 const int src = a.col[ee];
                 int t = a.etype[ee] + a.shift;
                 if (t >= a.T) t -= a.T;
@@ -245,7 +249,7 @@ __device__ __forceinline__ void gather_heavy_row(const GatherArgs& a, int v) {
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            if (e + u * kWaves < e1) {
+            if (e + u * kWaves < e1 && a.col[e + u * kWaves] < a.src_limit) {
 #pragma unroll
                 for (int c = 0; c < NCH; ++c)
                     if (lane + 64 * c < CH) blockmul<SI, TR>(xv[u][c], wv[u][c], acc[c]);
@@ -510,7 +514,7 @@ int renet_rgcn_gather(const float* x, int D, const int32_t* row_ptr, const int32
                       const int32_t* etype, const float* scale, const float* W, int T, int type_shift,
                       int transpose_w, const float* addend, float drop_p, uint64_t seed, int relu,
                       float* out, int N, const int32_t* heavy_rows, int n_heavy, int heavy_thresh,
-                      void* stream) {
+                      int src_limit, int addend_rows, void* stream) {
     if (!renet_dim_ok(D)) return RENET_ERR_UNSUPPORTED;
     if (n_heavy < 0 || (n_heavy > 0 && (!heavy_rows || heavy_thresh < 1))) return RENET_ERR_BADARG;
     if (N < 0 || T <= 0 || type_shift < 0 || type_shift >= T || drop_p < 0.f || drop_p >= 1.f)
@@ -520,6 +524,8 @@ int renet_rgcn_gather(const float* x, int D, const int32_t* row_ptr, const int32
     a.x = x; a.row_ptr = row_ptr; a.col = col; a.etype = etype; a.scale = scale; a.W = W;
     a.addend = addend; a.out = out; a.N = N; a.T = T; a.shift = type_shift; a.relu = relu;
     a.heavy = heavy_rows; a.n_heavy = n_heavy;
+    a.src_limit = src_limit > 0 ? src_limit : 0x7fffffff;
+    a.addend_rows = addend_rows > 0 ? addend_rows : 0x7fffffff;
     a.heavy_thresh = n_heavy > 0 ? heavy_thresh : 0x7fffffff;
     a.drop = make_drop(drop_p, seed);
     hipStream_t st = (hipStream_t)stream;

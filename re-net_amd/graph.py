@@ -206,7 +206,8 @@ class HostBatch(object):
     """Everything one direction of one training/inference batch needs, as numpy arrays."""
     INT_FIELDS = ('node_ent', 'row_ptr', 'col', 'etype', 'e_src', 'e_dst', 'chunk_ptr', 'chunk_type',
                   'type_chunk_ptr', 'subj_row', 'row_ent', 'row_rel', 'glob_row', 's_sorted', 'r_sorted',
-                  'step_off', 'heavy_rows')
+                  'step_off', 'heavy_rows', 'heavy_rows_out', 'e_src2', 'e_dst2', 'chunk_ptr2', 'chunk_type2',
+                  'type_chunk_ptr2')
     PLANS = ('plan_node_ent', 'plan_subj_row', 'plan_s', 'plan_r')
 
     def set_edges(self, n, src, dst, et, num_types):
@@ -238,6 +239,20 @@ class HostBatch(object):
         self.chunk_type = ctype.astype(np.int32)
         self.chunk_ptr = np.concatenate((tstart[ctype] + within * CHUNK, [E])).astype(np.int32)
         self.n_chunks = int(len(ctype))
+        return self
+
+    def set_out_rows(self, n_out, src, dst, et):
+        """Extra layouts for evaluating a layer only on rows [0, n_out): the hub rows among them and the
+        relation-bucketed chunk list restricted to edges whose destination is < n_out (its dW)."""
+        self.nA = int(n_out)
+        self.E_out = int(self.row_ptr[n_out])          # edges into rows < n_out (== edges out of them: paired)
+        self.heavy_rows_out = self.heavy_rows[self.heavy_rows < n_out]
+        m = np.asarray(dst) < n_out
+        sub = HostBatch().set_edges(self.N, np.asarray(src)[m], np.asarray(dst)[m], np.asarray(et)[m],
+                                    self.num_types)
+        self.e_src2, self.e_dst2 = sub.e_src, sub.e_dst
+        self.chunk_ptr2, self.chunk_type2 = sub.chunk_ptr, sub.chunk_type
+        self.type_chunk_ptr2, self.n_chunks2 = sub.type_chunk_ptr, sub.n_chunks
         return self
 
     @classmethod
@@ -296,9 +311,18 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None):
     keys = np.unique(np.concatenate((key_subj, key_nbr)))
     N = len(keys)
     hb.N = N
-    hb.node_ent = (keys % num_ent).astype(np.int32)
-    node_slot = keys // num_ent
-    hb.graph_off = np.searchsorted(node_slot, np.arange(Tb + 1)).astype(np.int64)
+    # Row numbering: the rows that are read after the LAST RGCN layer -- the (subject, t) rows,
+    # Aggregator.py:139-140 -- come first (rows [0, nA)), so that layer can be evaluated on a row prefix.
+    # Every other node is an in-neighbour of a subject row, so layer 1 still needs all N rows.
+    subj_pos = np.searchsorted(keys, key_subj)
+    is_a = np.zeros(N, dtype=bool)
+    is_a[subj_pos] = True
+    order_new = np.concatenate((np.nonzero(is_a)[0], np.nonzero(~is_a)[0]))
+    new_id = np.empty(N, dtype=np.int64)
+    new_id[order_new] = np.arange(N)
+    hb.nA = int(is_a.sum())
+    hb.node_ent = (keys % num_ent)[order_new].astype(np.int32)
+    hb.node_slot = (keys // num_ent)[order_new]
 
     # node-induced edges of every member graph (utils.py:115-131)
     if Tb:
@@ -311,7 +335,7 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None):
         ps = np.minimum(np.searchsorted(keys, ks), N - 1)
         po = np.minimum(np.searchsorted(keys, ko), N - 1)
         keep = (keys[ps] == ks) & (keys[po] == ko)
-        ls, lo, rr = ps[keep], po[keep], store.trip_r[flat][keep]
+        ls, lo, rr = new_id[ps[keep]], new_id[po[keep]], store.trip_r[flat][keep]
     else:
         ls = lo = rr = np.zeros(0, np.int64)
     src = np.concatenate((ls, lo))
@@ -321,6 +345,7 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None):
     hb.E = E
 
     hb.set_edges(N, src, dst, et, 2 * num_rels)
+    hb.set_out_rows(hb.nA, src, dst, et)
 
     # packed (time-major) layout: row p = off[j] + i  <->  step j of sorted sequence i
     bs = (ln[None, :] > np.arange(L)[:, None]).sum(axis=1) if L else np.zeros(0, np.int64)
@@ -331,7 +356,7 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None):
     inv = np.empty(S, dtype=np.int64)
     inv[p_of_k] = np.arange(S)
     hb.packed_from_seqmajor = inv                                    # packed row p -> seq-major k
-    subj_row_k = np.searchsorted(keys, key_subj)
+    subj_row_k = new_id[subj_pos]
     hb.subj_row_seqmajor = subj_row_k
     hb.subj_row = subj_row_k[inv].astype(np.int32)
     hb.row_seq = step_seq[inv].astype(np.int32)
@@ -409,9 +434,14 @@ class DeviceGraph(object):
         self.norm = torch.from_numpy(hb.norm).to(device)
         self.ndata = {}                  # 'h' lives here, as on the reference's DGL graph
         self.heavy_thresh = HEAVY
-        if getattr(self, 'heavy_rows', None) is not None and self.heavy_rows.numel() == 0:
-            self.heavy_rows = None
-        for f in ('N', 'E', 'S', 'B', 'nnz', 'L', 'n_chunks', 'num_types', 'G'):
+        for f in ('heavy_rows', 'heavy_rows_out'):
+            if getattr(self, f, None) is not None and getattr(self, f).numel() == 0:
+                setattr(self, f, None)
+        if not hasattr(self, 'heavy_rows_out'):
+            self.heavy_rows_out = None
+        if not hasattr(self, 'nA'):
+            self.nA = getattr(self, 'N', None)
+        for f in ('N', 'E', 'S', 'B', 'nnz', 'L', 'n_chunks', 'n_chunks2', 'nA', 'E_out', 'num_types', 'G'):
             if hasattr(hb, f):
                 setattr(self, f, getattr(hb, f))
         self.host = hb

@@ -38,38 +38,52 @@ class GatherRowsFn(Function):
 
 
 class RGCNLayerFn(Function):
-    """One RGCNBlockLayer (RGCN.py:33-51,79-94): self-loop GEMM + fused gather-SpMM epilogue."""
+    """One RGCNBlockLayer (RGCN.py:33-51,79-94): self-loop GEMM + fused gather-SpMM epilogue.
+    n_out < N evaluates the layer only for the first n_out rows (the batch builder numbers the rows that
+    are read afterwards -- the subject rows, Aggregator.py:139-140 -- first); exact for those rows."""
 
     @staticmethod
-    def forward(ctx, h, weight, loop_weight, g, reverse, relu, drop_p, seed):
+    def forward(ctx, h, weight, loop_weight, g, reverse, relu, drop_p, seed, n_out):
         h, weight, loop_weight = _c(h), _c(weight), _c(loop_weight)
+        n = h.shape[0]
+        n_out = n if (n_out is None or n_out >= n) else int(n_out)
+        pruned = n_out < n
         shift = g.num_types // 2 if reverse else 0                     # type_o = type_s +- R (utils.py:75-76)
-        out = K.gemm(h, loop_weight)                                   # RGCN.py:35
+        out = K.gemm(h[:n_out], loop_weight)                           # RGCN.py:35
         K.rgcn_gather(h, g.row_ptr, g.col, g.etype, g.norm, weight, shift, False, out, drop_p, seed, relu, out,
-                      g.heavy_rows, g.heavy_thresh)
-        ctx.g, ctx.relu, ctx.drop_p, ctx.seed, ctx.shift = g, relu, drop_p, seed, shift
+                      g.heavy_rows_out if pruned else g.heavy_rows, g.heavy_thresh,
+                      n_edges=g.E_out if pruned else None)
+        ctx.g, ctx.relu, ctx.drop_p, ctx.seed, ctx.shift, ctx.n_out = g, relu, drop_p, seed, shift, n_out
         ctx.save_for_backward(h, weight, loop_weight, out)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         h, weight, loop_weight, out = ctx.saved_tensors
-        g = ctx.g
+        g, n_out = ctx.g, ctx.n_out
         g_out = _c(g_out)
         n, d = h.shape
-        gn = torch.empty_like(h)
-        g_loop = torch.empty_like(h)
+        pruned = n_out < n
+        gn = torch.empty(n_out, d, device=h.device, dtype=torch.float32)
+        g_loop = torch.empty(n_out, d, device=h.device, dtype=torch.float32)
         K.rgcn_bwd_prep(g_out, out, g.norm, ctx.relu, ctx.drop_p, ctx.seed, gn, g_loop)
-        dh = K.gemm(g_loop, loop_weight, tb=True)                      # g_loop @ W_loop^T
-        d_loop = K.gemm(h, g_loop, ta=True)                            # h^T @ g_loop (auto split-K)
-        # dh += sum over out-edges W[type]^T gn[dst]  == same CSR rows, the PAIRED edge's type
+        dh = torch.empty(n, d, device=h.device, dtype=torch.float32)
+        K.gemm(g_loop, loop_weight, tb=True, out=dh[:n_out])           # g_loop @ W_loop^T (rows < n_out)
+        d_loop = K.gemm(h[:n_out], g_loop, ta=True)                    # h^T @ g_loop (auto split-K)
+        # dh += sum over out-edges W[type]^T gn[dst]  == same CSR rows, the PAIRED edge's type; with a pruned
+        # forward only destinations < n_out carry gradient: skip the other sources, no addend past n_out
         pair_shift = (ctx.shift + g.num_types // 2) % g.num_types
         K.rgcn_gather(gn, g.row_ptr, g.col, g.etype, None, weight, pair_shift, True, dh, 0.0, 0, False, dh,
-                      g.heavy_rows, g.heavy_thresh)
+                      g.heavy_rows, g.heavy_thresh, n_out if pruned else 0, n_out if pruned else 0,
+                      n_edges=g.E_out if pruned else None)
         d_w = torch.empty_like(weight)
-        K.rgcn_bwd_w(h, gn, g.e_src, g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr,
-                     g.num_types, ctx.shift, d_w)
-        return dh, d_w, d_loop, None, None, None, None, None
+        if pruned:
+            K.rgcn_bwd_w(h, gn, g.e_src2, g.e_dst2, g.chunk_ptr2, g.chunk_type2, g.n_chunks2, g.type_chunk_ptr2,
+                         g.num_types, ctx.shift, d_w)
+        else:
+            K.rgcn_bwd_w(h, gn, g.e_src, g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr,
+                         g.num_types, ctx.shift, d_w)
+        return dh, d_w, d_loop, None, None, None, None, None, None
 
 
 class SeqAssembleFn(Function):

@@ -165,7 +165,8 @@ def segment_add(src, plan, dst):
 
 
 def rgcn_gather(x, row_ptr, col, etype, scale, weight, type_shift, transpose_w, addend, drop_p, seed,
-                relu, out, heavy_rows=None, heavy_thresh=0):
+                relu, out, heavy_rows=None, heavy_thresh=0, src_limit=0, addend_rows=0, n_edges=None):
+    """n_edges: edges actually walked by this launch (pruned launches), for the byte accounting only."""
     n, d = x.shape[0], x.shape[1]
     t0 = _timer.begin() if _timer is not None else None
     _check(lib().renet_rgcn_gather(_f32(x), d, _i32(row_ptr), _i32(col), _i32(etype), _f32(scale),
@@ -173,11 +174,12 @@ def rgcn_gather(x, row_ptr, col, etype, scale, weight, type_shift, transpose_w, 
                                    _f32(addend), float(drop_p), int(seed), int(relu), _f32(out),
                                    out.shape[0], _i32(heavy_rows) if heavy_rows is not None else None,
                                    heavy_rows.numel() if heavy_rows is not None else 0, int(heavy_thresh),
-                                   _stream()), 'rgcn_gather')
+                                   int(src_limit), int(addend_rows), _stream()), 'rgcn_gather')
     if t0 is not None:
         # algorithmic bytes: per edge one source row + src + type index; per node one output
         # row + row_ptr + norm (+ the fused addend row); the relation weight table once
-        e, nn = col.numel(), out.shape[0]
+        nn = out.shape[0]
+        e = col.numel() if n_edges is None else int(n_edges)
         nbytes = e * (d * 4 + 8) + nn * (d * 4 + 8) + weight.numel() * 4 + (nn * d * 4 if addend is not None else 0)
         _timer.end('rgcn_gather', t0, nbytes=float(nbytes))
     return out

@@ -86,7 +86,7 @@ def test_rgcn_layer_matches_reference_golden(dev, d):
             h = _to(p['h'], dev).requires_grad_(True)
             w = _to(p['weight'], dev).requires_grad_(True)
             lw = _to(p['loop_weight'], dev).requires_grad_(True)
-            y = ops.RGCNLayerFn.apply(h, w, lw, g, bool(reverse), bool(relu), 0.0, 0)
+            y = ops.RGCNLayerFn.apply(h, w, lw, g, bool(reverse), bool(relu), 0.0, 0, None)
             (y * _to(p['gout'], dev)).sum().backward()
             tag = 'relu%d_rev%d_' % (relu, reverse)
             np.testing.assert_allclose(y.detach().cpu().numpy(), gold[tag + 'out'], rtol=RTOL, atol=ATOL)
@@ -499,3 +499,33 @@ def test_aggregator_predict_with_appended_graph_matches_oracle(dev):
                                                 rel_d, gd, net.global_emb, reverse=reverse)
         np.testing.assert_allclose(inp.cpu().numpy(), x[0].numpy(), rtol=RTOL, atol=ATOL)
         np.testing.assert_allclose(inp_r.cpu().numpy(), xr[0].numpy(), rtol=RTOL, atol=ATOL)
+
+
+def test_pruned_last_layer_equals_full_layer_on_kept_rows(dev):
+    """RGCNLayerFn with n_out < N (layer evaluated on the subject-row prefix only) vs the full layer:
+    identical outputs on the kept rows and identical gradients for a loss that only reads those rows."""
+    import graph as G
+    import ops
+    import preprocess as P
+    import synth
+    quads, ne, nr, _ = synth.make_stream('ICEWS18', seed=5, num_t=40)
+    gd = P.build_graph_dict(quads, nr)
+    hs = P.HistoryIndex(quads, 's', 10)
+    idx = np.random.RandomState(1).permutation(len(quads))[:512]
+    hb = G.build_batch(G.store_for(gd), ne, nr, quads[idx, 0], quads[idx, 1], hs.take(idx), sort=True)
+    g = G.DeviceGraph(hb, dev)
+    assert 0 < hb.nA < hb.N
+    d = 200
+    torch.manual_seed(3)
+    gout = torch.randn(hb.nA, d, device=dev)
+    res = []
+    for n_out in (None, hb.nA):
+        h = (torch.randn(hb.N, d, device=dev, generator=torch.Generator(device=dev).manual_seed(1))).requires_grad_(True)
+        w = (torch.randn(2 * nr, 2 * d, device=dev, generator=torch.Generator(device=dev).manual_seed(2)) * 0.1).requires_grad_(True)
+        lw = (torch.randn(d, d, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) * 0.1).requires_grad_(True)
+        y = ops.RGCNLayerFn.apply(h, w, lw, g, True, False, 0.0, 0, n_out)
+        (y[:hb.nA] * gout).sum().backward()
+        res.append((y[:hb.nA].detach(), h.grad, w.grad, lw.grad))
+    for a, b in zip(res[0], res[1]):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1.0), (a.shape, float((a - b).abs().max()), scale)

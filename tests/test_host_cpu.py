@@ -62,7 +62,11 @@ def test_batch_builder_matches_oracle(name, lo, hi, sort):
         return
     ot = np.repeat(np.asarray(bg.graph_t), np.diff(np.asarray(bg.graph_off + [bg.num_nodes])))
     okeys = _keys(ot, bg.ent)
-    slot_t = hb.graph_t[np.searchsorted(hb.graph_off, np.arange(hb.N), side='right') - 1]
+    slot_t = hb.graph_t[hb.node_slot]
+    # rows read after the last RGCN layer (the subject rows) are numbered first
+    assert hb.nA == len(np.unique(hb.subj_row)) and hb.subj_row.max() < hb.nA
+    m2 = np.repeat(np.arange(hb.N), np.diff(hb.row_ptr)) < hb.nA
+    assert len(hb.e_src2) == int(m2.sum()) and np.all(hb.e_dst2 < hb.nA) and hb.chunk_ptr2[-1] == len(hb.e_src2)
     mkeys = _keys(slot_t, hb.node_ent)
     assert set(mkeys) == set(okeys) and len(set(mkeys)) == hb.N
     oe = Counter((okeys[a], okeys[b], int(t)) for a, b, t in zip(bg.src, bg.dst, bg.type_s))
