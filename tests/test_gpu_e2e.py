@@ -1,0 +1,89 @@
+"""End-to-end parity on REAL data (a prefix of YAGO): training from the same seed with train.py's loop
+(seeds train.py:29-31, step :127-143) and filtered validation (train.py:151-185) on the HIP path vs the
+same loop run with the UNMODIFIED reference modules on CPU (tools/make_e2e_golden.py -> tests/golden/).
+North-star criterion: filtered MRR within +-0.002 of the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import O, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_yago_prefix_training_and_filtered_mrr_match_reference():
+    from sklearn.utils import shuffle
+    import global_model as GM
+    import model as M
+    import preprocess as P
+    import utils as U
+    data = np.load(os.path.join(GOLDEN, 'yago_prefix.npz'))
+    gold = np.load(os.path.join(GOLDEN, 'e2e_yago.npz'))
+    tr, va, te = data['train'], data['valid'], data['test']
+    num_ent, num_rels = int(data['num_ent']), int(data['num_rels'])
+    h, seq_len, batch, num_k = int(gold['h']), int(gold['seq_len']), int(gold['batch']), int(gold['num_k'])
+    dev = torch.device('cuda:0')
+    allq = np.concatenate((tr, va, te))
+    hs, ho = P.HistoryIndex(allq, 's', 10), P.HistoryIndex(allq, 'o', 10)
+    rng_tr = np.arange(len(tr))
+    rng_va = np.arange(len(tr), len(tr) + len(va))
+    rng_te = np.arange(len(tr) + len(va), len(allq))
+    sh, sht = hs.to_lists(rng_tr)
+    oh, oht = ho.to_lists(rng_tr)
+    graph_dict = U.build_graph_dict(tr, num_rels)
+    np.random.seed(999)                                       # train.py:29-31
+    torch.manual_seed(999)
+    net = M.RENet(num_ent, h, num_rels, dropout=float(gold['dropout']), model=0, seq_len=seq_len, num_k=num_k)
+    gnet = GM.RENet_global(num_ent, h, num_rels, dropout=float(gold['dropout']), model=0, seq_len=seq_len,
+                           num_k=num_k, maxpool=int(gold['maxpool']))
+    net.to(dev)
+    gnet.to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=float(gold['lr']), weight_decay=float(gold['wd']))
+    with torch.no_grad():
+        net.global_emb = gnet.get_global_emb(np.unique(tr[:, 3]), graph_dict)
+    net.graph_dict = graph_dict
+    step_losses, epoch_losses = [], []
+    for ep in range(int(gold['epochs'])):
+        net.train()
+        d_, a, b, c, d2 = shuffle(tr, sh, sht, oh, oht)        # train.py:127 (same RNG stream as the reference run)
+        tot = 0.0
+        for bd, bs, bst, bo, bot in U.make_batch2(d_, a, b, c, d2, batch):
+            bd = torch.from_numpy(bd).long().to(dev)
+            loss = net(bd, (bs, bst), (bo, bot), graph_dict, subject=True) + \
+                net(bd, (bs, bst), (bo, bot), graph_dict, subject=False)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(net.parameters(), float(gold['grad_norm']))
+            opt.step()
+            opt.zero_grad()
+            step_losses.append(loss.item())
+            tot += step_losses[-1]
+        epoch_losses.append(tot / (len(tr) / batch))
+    step_losses = np.asarray(step_losses)
+    # identical init + identical batches: the first step must agree to fp32 rounding, later steps drift slowly
+    assert abs(step_losses[0] - gold['step_loss'][0]) < 1e-4 * gold['step_loss'][0]
+    np.testing.assert_allclose(step_losses, gold['step_loss'], rtol=5e-3)
+    np.testing.assert_allclose(epoch_losses, gold['epoch_loss'], rtol=2e-3)
+
+    net.eval()
+    gnet.eval()
+    samples = [torch.from_numpy(x).to(dev) for x in gold['samples']]
+    net.sample_entities = lambda prob: samples.pop(0)
+    total = torch.from_numpy(allq).to(dev)
+    valid = torch.from_numpy(va)
+    vs, vo, ts, to = hs.to_lists(rng_va), ho.to_lists(rng_va), hs.to_lists(rng_te), ho.to_lists(rng_te)
+    ranks = []
+    with torch.no_grad():
+        net.init_history(tr, (sh, sht), (oh, oht), valid, vs, vo, te, ts, to)
+        net.latest_time = valid[0][3]
+        for i in range(len(va)):
+            rk, _ = net.evaluate_filter(valid[i], (vs[0][i], vs[1][i]), (vo[0][i], vo[1][i]), gnet, total)
+            ranks.append(rk)
+    ranks = np.asarray(ranks)
+    mine, ref = O.mrr_hits(ranks.reshape(-1)), O.mrr_hits(gold['ranks'].reshape(-1))
+    print('filtered MRR mine %.6f reference %.6f | hits@10 %.4f / %.4f' % (mine['mrr'], ref['mrr'], mine['hits@10'],
+                                                                            ref['hits@10']))
+    assert abs(mine['mrr'] - ref['mrr']) <= 0.002, (mine, ref)
+    for k in ('hits@1', 'hits@3', 'hits@10'):
+        assert abs(mine[k] - ref[k]) <= 0.01, (k, mine[k], ref[k])
