@@ -13,14 +13,17 @@ from helpers import O, GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-def test_yago_prefix_training_and_filtered_mrr_match_reference():
+@pytest.mark.parametrize('tag', ['', '_big'])
+def test_yago_prefix_training_and_filtered_mrr_match_reference(tag):
     from sklearn.utils import shuffle
+    if not os.path.isfile(os.path.join(GOLDEN, 'e2e_yago%s.npz' % tag)):
+        pytest.skip('fixture e2e_yago%s.npz not generated' % tag)
     import global_model as GM
     import model as M
     import preprocess as P
     import utils as U
-    data = np.load(os.path.join(GOLDEN, 'yago_prefix.npz'))
-    gold = np.load(os.path.join(GOLDEN, 'e2e_yago.npz'))
+    data = np.load(os.path.join(GOLDEN, 'yago_prefix%s.npz' % tag))
+    gold = np.load(os.path.join(GOLDEN, 'e2e_yago%s.npz' % tag))
     tr, va, te = data['train'], data['valid'], data['test']
     num_ent, num_rels = int(data['num_ent']), int(data['num_rels'])
     h, seq_len, batch, num_k = int(gold['h']), int(gold['seq_len']), int(gold['batch']), int(gold['num_k'])

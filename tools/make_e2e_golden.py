@@ -40,10 +40,11 @@ def main():
     n_train_t = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     n_valid_t = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     epochs = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    tag = sys.argv[4] if len(sys.argv) > 4 else ''
     ref = ref_loader.load()
     from sklearn.utils import shuffle
     num_ent, num_rels, tr, va, te = load_yago(n_train_t, n_valid_t)
-    np.savez_compressed(os.path.join(OUT, 'yago_prefix.npz'), train=tr, valid=va, test=te,
+    np.savez_compressed(os.path.join(OUT, 'yago_prefix%s.npz' % tag), train=tr, valid=va, test=te,
                         num_ent=num_ent, num_rels=num_rels)
     print('YAGO prefix: train %d valid %d test %d quads' % (len(tr), len(va), len(te)), flush=True)
     # histories exactly as data/YAGO/get_history_graph.py builds them (restated + pinned in oracle tests)
@@ -113,7 +114,7 @@ def main():
     ranks = np.asarray(ranks)
     m = O.mrr_hits(ranks.reshape(-1))
     print('reference: filtered MRR %.6f hits@1/3/10 %.4f %.4f %.4f' % (m['mrr'], m['hits@1'], m['hits@3'], m['hits@10']))
-    np.savez_compressed(os.path.join(OUT, 'e2e_yago.npz'), epoch_loss=np.asarray(losses),
+    np.savez_compressed(os.path.join(OUT, 'e2e_yago%s.npz' % tag), epoch_loss=np.asarray(losses),
                         step_loss=np.asarray(step_losses), ranks=ranks, valid_loss=np.asarray(vlosses),
                         samples=np.stack([x.numpy() for x in samples]) if samples else np.zeros((0, CFG['num_k'])),
                         epochs=epochs, **{k: np.asarray(v) for k, v in CFG.items()})
