@@ -81,8 +81,9 @@ def main():
     net.global_emb = {int(t): torch.randn(1, 1, args.hidden, generator=gen) * 0.1 for t in graph_dict}
     net.to(dev)
     net.train()
-    flat = parallel.FlatGrads(net)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=1e-5)      # train.py:61
+    # train.py:61,140-142: Adam(lr 1e-3, wd 1e-5) + clip_grad_norm_(1.0) + zero_grad, fused on flat buffers
+    opt = parallel.HipAdam(net, lr=1e-3, weight_decay=1e-5, max_norm=1.0)
+    flat = opt.grads
     perm = np.random.RandomState(999).permutation(len(quads))
 
     def prepare(step):
@@ -94,10 +95,7 @@ def main():
     def train_step(ps, po):
         loss = net.loss_prepared(ps) + net.loss_prepared(po)
         loss.backward()
-        flat.allreduce_mean()
-        flat.clip_(1.0)
-        opt.step()
-        flat.zero()
+        opt.step()                       # gradient all-reduce (N>1) -> clip -> Adam -> zero_grad
         return loss
 
     n_total = args.warmup + args.steps

@@ -198,6 +198,16 @@ int renet_segment_pool_fwd(const float* h, const int32_t* seg_ptr, int G, int D,
 int renet_segment_pool_bwd(const float* dout, const int32_t* seg_ptr, const int32_t* argmax, int G,
                            int D, int is_max, int N, float* dh, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused clip_grad_norm_ + Adam (+ weight decay) + zero_grad over flat buffers (train.py:140-142).
+ * p, g, m, v: n floats each (16-byte aligned); `step` is the 1-based step count (bias correction);
+ * max_norm <= 0 disables clipping; grad_norm_out (optional device float) receives the pre-clip norm.
+ * torch.optim.Adam semantics (L2 weight decay added to the clipped gradient). */
+size_t renet_adam_workspace(size_t n);
+int renet_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, float max_norm, int step, int zero_grad, float* workspace,
+                    size_t workspace_bytes, float* grad_norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

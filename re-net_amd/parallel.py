@@ -15,19 +15,26 @@ import torch
 import torch.distributed as dist
 
 
+def flat_layout(params):
+    """Offsets (in floats) of every parameter inside a flat buffer; each starts on a 16-byte boundary so
+    that the float4 kernels can address the views directly.  Returns (offsets, total)."""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + 3) & ~3
+    return offs, off
+
+
 class FlatGrads(object):
     """Makes every parameter's .grad a view into one contiguous buffer."""
 
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
-        total = sum(p.numel() for p in self.params)
+        self.offsets, total = flat_layout(self.params)
         dev = self.params[0].device if self.params else torch.device('cpu')
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+        for p, off in zip(self.params, self.offsets):
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
 
     def zero(self):
         self.flat.zero_()
@@ -35,11 +42,9 @@ class FlatGrads(object):
     def check_views(self):
         """autograd accumulates in place into an existing .grad; verify nobody replaced the views."""
         base = self.flat.data_ptr()
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != base + 4 * off:
                 return False
-            off += p.numel()
         return True
 
     def allreduce_mean(self, group=None):
@@ -63,3 +68,43 @@ def shard_indices(perm, step, rank, world, batch_size):
     n = len(perm)
     start = (k * batch_size) % max(n - batch_size + 1, 1)
     return perm[start:start + batch_size]
+
+
+class FlatParams(object):
+    """Moves every parameter of `module` into ONE contiguous buffer (param.data become views), in the same
+    order as FlatGrads, so that the optimizer is a single fused kernel over flat buffers."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.offsets, total = flat_layout(self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.numel = total
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                n = p.numel()
+                self.flat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat[off:off + n].view_as(p)
+
+
+class HipAdam(object):
+    """torch.optim.Adam(lr, weight_decay) + clip_grad_norm_(max_norm) + zero_grad as ONE fused HIP step on
+    the flat buffers (renet_adam_step).  Matches train.py:61,140-142."""
+
+    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0):
+        import renet_hip as K
+        self.K = K
+        self.params = FlatParams(module)
+        self.grads = FlatGrads(module)            # same layout (flat_layout) as the parameters
+        self.m = torch.zeros_like(self.params.flat)
+        self.v = torch.zeros_like(self.params.flat)
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
+        self.t = 0
+        self.norm = torch.zeros(1, device=self.m.device, dtype=torch.float32)
+
+    def step(self):
+        """all-reduce (if distributed) -> clip -> Adam -> zero_grad."""
+        self.grads.allreduce_mean()
+        self.t += 1
+        self.K.adam_step(self.params.flat, self.grads.flat, self.m, self.v, self.lr, self.betas[0], self.betas[1],
+                         self.eps, self.wd, self.max_norm, self.t, True, self.norm)

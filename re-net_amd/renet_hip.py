@@ -58,6 +58,9 @@ _SIGNATURES = {
     'renet_dropout': (c_int, [c_void_p, c_size_t, c_float, c_u64, c_void_p, c_void_p]),
     'renet_softmax_ce': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                  c_void_p]),
+    'renet_adam_workspace': (c_size_t, [c_size_t]),
+    'renet_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,
+                                c_float, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     'renet_segment_pool_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'renet_segment_pool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),
@@ -406,3 +409,13 @@ def segment_pool_bwd(dout, seg_ptr, arg, num_graphs, is_max, n):
     _check(lib().renet_segment_pool_bwd(_f32(dout), _i32(seg_ptr), _i32(arg), num_graphs, d, int(is_max), n,
                                         _f32(dh), _stream()), 'segment_pool_bwd')
     return dh
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, max_norm, step, zero_grad=True, norm_out=None):
+    """Fused clip + Adam + zero_grad on flat fp32 buffers (in place)."""
+    n = p.numel()
+    nbytes = lib().renet_adam_workspace(n)
+    ws = torch.empty(nbytes // 4, device=p.device, dtype=torch.float32)
+    _check(lib().renet_adam_step(_f32(p), _f32(g), _f32(m), _f32(v), n, float(lr), float(beta1), float(beta2),
+                                 float(eps), float(weight_decay), float(max_norm), int(step), int(zero_grad),
+                                 ws.data_ptr(), nbytes, _f32(norm_out), _stream()), 'adam_step')

@@ -529,3 +529,29 @@ def test_pruned_last_layer_equals_full_layer_on_kept_rows(dev):
     for a, b in zip(res[0], res[1]):
         scale = float(a.abs().max())
         assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1.0), (a.shape, float((a - b).abs().max()), scale)
+
+
+def test_fused_adam_matches_torch_adam_with_clipping(dev):
+    """renet_adam_step (clip + Adam + weight decay + zero_grad on flat buffers) vs
+    clip_grad_norm_ + torch.optim.Adam (train.py:61,140-142)."""
+    import parallel
+    torch.manual_seed(11)
+
+    def make():
+        torch.manual_seed(5)
+        return torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Tanh(), torch.nn.Linear(53, 23033 % 97)).to(dev)
+    ref, mine = make(), make()
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-2, weight_decay=1e-5)
+    opt = parallel.HipAdam(mine, lr=1e-2, weight_decay=1e-5, max_norm=0.05)
+    for step in range(4):
+        x = torch.randn(64, 37, device=dev)
+        for net in (ref, mine):
+            (net(x) ** 2).mean().backward()
+        nref = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.05)
+        opt_ref.step()
+        opt_ref.zero_grad()
+        opt.step()
+        assert abs(float(opt.norm) - float(nref)) < 1e-5 * float(nref)
+        assert float(opt.grads.flat.abs().max()) == 0.0 and opt.grads.check_views()
+        for a, b in zip(ref.parameters(), mine.parameters()):
+            torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-7)

@@ -33,6 +33,15 @@ def _data(step, rank, world):
     return x[idx], y[idx], idx
 
 
+def _flat(net):
+    """gradients in parallel.flat_layout order (every tensor padded to a multiple of 4 floats)"""
+    parts = []
+    for p in net.parameters():
+        g = p.grad.reshape(-1)
+        parts.append(torch.cat((g, torch.zeros((-g.numel()) % 4))))
+    return torch.cat(parts)
+
+
 def _worker(rank, world, port, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -67,7 +76,7 @@ def test_flat_allreduce_equals_accumulation(tmp_path):
             x, y, idx = _data(step, rank, world)
             seen.append(set(idx.tolist()))
             torch.nn.functional.cross_entropy(net(x), y).backward()
-            grads.append(torch.cat([p.grad.reshape(-1) for p in net.parameters()]))
+            grads.append(_flat(net))
         assert not (seen[0] & seen[1]), 'ranks must see disjoint slices of the shuffled order'
         ref = (grads[0] + grads[1]) / world
         norm = ref.norm()
@@ -84,5 +93,4 @@ def test_single_process_paths_are_noops():
     before = flat.flat.clone()
     flat.allreduce_mean()                      # no process group: must not touch the gradient
     assert torch.equal(before, flat.flat) and flat.check_views()
-    ref = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
-    assert torch.equal(ref, flat.flat)
+    assert torch.equal(_flat(net), flat.flat)
