@@ -129,15 +129,40 @@ def main():
         elapsed = float(tmax.item())
     value = args.batch * world * args.steps / elapsed
 
-    # ---- end-to-end rate with the host builder in the loop (extra, not `value`) -------------------
-    e2e = None
+    # ---- end-to-end rates with the host builder in the loop (extras, never `value`) ----------------
+    #  e2e_inline : builder on the training thread (one batch at a time)
+    #  e2e_value  : builder in forked worker processes (pipeline.BatchPrefetcher), uploads on this thread
+    e2e = e2e_inline = None
+    e2e_workers = 0
     if args.e2e_steps > 0:
         sync_all()
         t0 = time.perf_counter()
         for k in range(args.e2e_steps):
             train_step(*prepare(n_total + k))
         sync_all()
-        e2e = args.batch * world * args.e2e_steps / (time.perf_counter() - t0)
+        e2e_inline = args.batch * world * args.e2e_steps / (time.perf_counter() - t0)
+        import pipeline
+
+        def host_step(step):
+            idx = parallel.shard_indices(perm, step, rank, world, args.batch)
+            b = quads[idx]
+            return (net.host_batch(b, hist_s.take(idx), graph_dict, subject=True),
+                    net.host_batch(b, hist_o.take(idx), graph_dict, subject=False))
+        n_pipe = max(40, 8 * args.e2e_steps)
+        e2e_workers = max(1, min(24, (os.cpu_count() or 2) // (2 * world)))
+        pf = pipeline.BatchPrefetcher(host_step, range(n_total + 100, n_total + 100 + n_pipe), e2e_workers)
+        it = iter(pf)
+        first = [next(it) for _ in range(4)]                    # let the workers fill the pipe
+        for hs_, ho_ in first:
+            train_step(net.prepare_from_host(hs_), net.prepare_from_host(ho_))
+        sync_all()
+        t0 = time.perf_counter()
+        done = 0
+        for hs_, ho_ in it:
+            train_step(net.prepare_from_host(hs_), net.prepare_from_host(ho_))
+            done += 1
+        sync_all()
+        e2e = args.batch * world * done / (time.perf_counter() - t0)
 
     if rank != 0:
         if world > 1:
@@ -207,7 +232,8 @@ def main():
                    'batch_graph': {'nodes': int(g0.N), 'edges': int(g0.E), 'history_steps': int(g0.S),
                                    'nonempty': int(g0.nnz)}},
         'roofline': roofline, 'roofline_rgcn_gather': gather, 'kernels': kernels, 'cpu_baseline': cpu,
-        'host_build_ms': host_build_ms, 'e2e_value': e2e, 'last_loss': last_loss,
+        'host_build_ms': host_build_ms, 'e2e_value': e2e, 'e2e_workers': e2e_workers, 'e2e_inline': e2e_inline,
+        'last_loss': last_loss,
     }
     print(json.dumps(out))
     if world > 1:

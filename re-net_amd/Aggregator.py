@@ -50,6 +50,15 @@ class GlobalEmbTable(object):
 
     def invalidate(self):
         self._key = None
+        self._host_key = None
+
+    def get_host(self, global_emb):
+        """Host-only view (sorted timestamps for `index`); no device access."""
+        key = (id(global_emb), len(global_emb))
+        if key != getattr(self, '_host_key', None):
+            self.times = np.asarray(sorted(int(t) for t in global_emb.keys()), dtype=np.int64)
+            self._host_key = key
+        return self
 
     def index(self, t):
         t = np.asarray(t, dtype=np.int64)

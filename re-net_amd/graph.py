@@ -126,6 +126,18 @@ def store_for(graph_dict):
     return st
 
 
+_scratch = {}
+
+
+def _lookup_table(n):
+    """Reusable int32 scratch table pre-filled with -1 (callers restore the entries they touch)."""
+    t = _scratch.get('table')
+    if t is None or len(t) < n:
+        t = np.full(max(n, 1 << 20), -1, dtype=np.int32)
+        _scratch['table'] = t
+    return t
+
+
 def ragged_arange(starts, counts):
     """concat([arange(s, s + c) for s, c in zip(starts, counts)]) without a Python loop."""
     counts = np.asarray(counts, dtype=np.int64)
@@ -219,7 +231,7 @@ class HostBatch(object):
         et = np.asarray(et, dtype=np.int64)
         E = len(src)
         self.N, self.E, self.num_types = int(n), E, int(num_types)
-        order = np.lexsort((et, dst))
+        order = np.argsort(dst * np.int64(num_types) + et, kind='stable')     # by destination, then type
         self.col = src[order].astype(np.int32)
         self.etype = et[order].astype(np.int32)
         deg = np.bincount(dst, minlength=n)
@@ -332,10 +344,14 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None):
         eslot = np.repeat(np.arange(Tb, dtype=np.int64), tcnt)
         ks = eslot * num_ent + store.trip_s[flat]
         ko = eslot * num_ent + store.trip_o[flat]
-        ps = np.minimum(np.searchsorted(keys, ks), N - 1)
-        po = np.minimum(np.searchsorted(keys, ko), N - 1)
-        keep = (keys[ps] == ks) & (keys[po] == ko)
-        ls, lo, rr = new_id[ps[keep]], new_id[po[keep]], store.trip_r[flat][keep]
+        # membership by direct lookup ((slot, entity) -> new row id, -1 = not in the batch's node set): two
+        # random gathers instead of two binary searches over ~370k endpoints
+        table = _lookup_table(Tb * num_ent)
+        table[keys] = new_id.astype(np.int32)
+        ps, po = table[ks], table[ko]
+        table[keys] = -1                                          # leave the scratch table clean
+        keep = (ps >= 0) & (po >= 0)
+        ls, lo, rr = ps[keep].astype(np.int64), po[keep].astype(np.int64), store.trip_r[flat][keep]
     else:
         ls = lo = rr = np.zeros(0, np.int64)
     src = np.concatenate((ls, lo))
@@ -395,11 +411,17 @@ def build_full_graphs(graph_dict, times):
     return hb
 
 
-class DeviceGraph(object):
-    """Device-resident view of a HostBatch: ONE int32 upload + ONE float32 upload, sliced into views."""
+SCALARS = ('N', 'E', 'S', 'B', 'nnz', 'L', 'n_chunks', 'n_chunks2', 'nA', 'E_out', 'num_types', 'G')
 
-    def __init__(self, hb, device):
-        ints, names, plan_names = [], [], []
+
+class PackedBatch(object):
+    """A HostBatch flattened for transport: ONE int32 buffer (every index array, 16-byte aligned slices),
+    the fp32 `norm`, and a small picklable directory.  Built on the host (possibly in a worker process of
+    pipeline.BatchPrefetcher); DeviceGraph uploads it with one H2D copy per buffer."""
+    __slots__ = ('ints', 'norm', 'names', 'offs', 'sizes', 'plan_segments', 'scalars', 'host_small')
+
+    def __init__(self, hb):
+        ints, names, self.plan_segments = [], [], {}
         for f in HostBatch.INT_FIELDS + ('seg_ptr',):
             if hasattr(hb, f):
                 names.append(f)
@@ -407,11 +429,10 @@ class DeviceGraph(object):
         for pn in HostBatch.PLANS:
             if hasattr(hb, pn):
                 p = getattr(hb, pn)
-                plan_names.append(pn)
+                self.plan_segments[pn] = p.num_segments
                 for sub in ('order', 'seg_ptr', 'target'):
                     names.append(pn + '.' + sub)
                     ints.append(np.ascontiguousarray(getattr(p, sub), dtype=np.int32).reshape(-1))
-        # keep every view 16-byte aligned
         sizes = [len(a) for a in ints]
         padded = [(n + 3) & ~3 for n in sizes]
         buf = np.zeros(int(sum(padded)) + 4, dtype=np.int32)
@@ -420,18 +441,41 @@ class DeviceGraph(object):
             buf[o:o + n] = a
             offs.append(o)
             o += pn_
-        dev = torch.from_numpy(buf).to(device, non_blocking=False)
+        self.ints, self.names, self.offs, self.sizes = buf, names, offs, sizes
+        self.norm = np.ascontiguousarray(hb.norm, dtype=np.float32)
+        self.scalars = {f: getattr(hb, f) for f in SCALARS if hasattr(hb, f)}
+        # the few host-side arrays the model still needs after the upload (labels permutation, packing)
+        self.host_small = {f: getattr(hb, f) for f in ('perm', 'lens', 'batch_sizes', 'step_off',
+                                                       'packed_from_seqmajor', 'node_slot', 'graph_t')
+                           if hasattr(hb, f)}
+
+
+class _HostView(object):
+    """What remains of a HostBatch on the consumer side of a PackedBatch."""
+
+    def __init__(self, pb):
+        self.__dict__.update(pb.scalars)
+        self.__dict__.update(pb.host_small)
+
+
+class DeviceGraph(object):
+    """Device-resident view of a HostBatch / PackedBatch: ONE int32 upload + ONE float32 upload, sliced
+    into views."""
+
+    def __init__(self, hb, device):
+        pb = hb if isinstance(hb, PackedBatch) else PackedBatch(hb)
+        dev = torch.from_numpy(pb.ints).to(device, non_blocking=False)
         self._buf = dev
-        views = {nm: dev[o_:o_ + n] for nm, o_, n in zip(names, offs, sizes)}
-        for nm in names:
+        views = {nm: dev[o_:o_ + n] for nm, o_, n in zip(pb.names, pb.offs, pb.sizes)}
+        for nm in pb.names:
             if '.' not in nm:
                 setattr(self, nm, views[nm])
-        for pn in plan_names:
+        for pn, nseg in pb.plan_segments.items():
             p = SegPlan()
             p.order, p.seg_ptr, p.target = views[pn + '.order'], views[pn + '.seg_ptr'], views[pn + '.target']
-            p.num_segments = getattr(hb, pn).num_segments
+            p.num_segments = nseg
             setattr(self, pn, p)
-        self.norm = torch.from_numpy(hb.norm).to(device)
+        self.norm = torch.from_numpy(pb.norm).to(device)
         self.ndata = {}                  # 'h' lives here, as on the reference's DGL graph
         self.heavy_thresh = HEAVY
         for f in ('heavy_rows', 'heavy_rows_out'):
@@ -439,9 +483,8 @@ class DeviceGraph(object):
                 setattr(self, f, None)
         if not hasattr(self, 'heavy_rows_out'):
             self.heavy_rows_out = None
+        for f, v in pb.scalars.items():
+            setattr(self, f, v)
         if not hasattr(self, 'nA'):
             self.nA = getattr(self, 'N', None)
-        for f in ('N', 'E', 'S', 'B', 'nnz', 'L', 'n_chunks', 'n_chunks2', 'nA', 'E_out', 'num_types', 'G'):
-            if hasattr(hb, f):
-                setattr(self, f, getattr(hb, f))
-        self.host = hb
+        self.host = hb if not isinstance(hb, PackedBatch) else _HostView(pb)

@@ -103,31 +103,54 @@ class RENet(nn.Module):
             return triplets[:, 0], triplets[:, 1], triplets[:, 2], self.rel_embeds[:self.num_rels], False
         return triplets[:, 2], triplets[:, 1], triplets[:, 0], self.rel_embeds[self.num_rels:], True
 
-    def prepare(self, triplets, hist, graph_dict, subject=True):
-        """Host half of one direction of a training step: batch graph + packed layout + plans, uploaded
-        once (graph.DeviceGraph).  Everything `loss_prepared` needs is device-resident afterwards, so an
-        input pipeline can run this ahead of the step (bench.py does).  hist: (histories, timestamps) in
-        the reference's nested-list layout, or a graph.FlatHistory."""
+    def host_batch(self, triplets, hist, graph_dict, subject=True):
+        """Pure host work of one direction of a step (no device access: safe in a worker process of
+        pipeline.BatchPrefetcher): returns a picklable dict with the packed batch graph (or None when every
+        history is empty) and the small label arrays."""
         trip = triplets.detach().cpu().numpy() if isinstance(triplets, torch.Tensor) else np.asarray(triplets)
         s, r, o, _, _ = self._direction(trip, subject)
+        agg = self.aggregator
+        fh = hist if isinstance(hist, G.FlatHistory) else G.FlatHistory.from_lists(hist[0], hist[1])
+        out = {'subject': bool(subject), 'b': len(s), 's': s.astype(np.int32), 'r': r.astype(np.int32), 'pb': None}
+        if fh.seq_ptr[-1] == 0:
+            out['o'] = o.astype(np.int32)
+            return out
+        table = agg.glob_table.get_host(self.global_emb)
+        hb = G.build_batch(G.store_for(graph_dict), self.in_dim, self.num_rels, s, r, fh, sort=True,
+                           glob_index=table.index)
+        if hb.L > self.seq_len:
+            raise ValueError('history longer than seq_len (%d > %d)' % (hb.L, self.seq_len))
+        out['pb'] = G.PackedBatch(hb)
+        out['o'] = o[hb.perm].astype(np.int32)
+        return out
+
+    def prepare_from_host(self, hbatch):
+        """Device half of prepare(): one upload of the packed batch + the label vector."""
         dev = self.ent_embeds.device
         prep = PreparedBatch()
-        prep.subject, prep.b = bool(subject), len(s)
-        g = self.aggregator.build(hist, s, r, self.ent_embeds, graph_dict, self.global_emb, sort=True)
-        prep.g = g
-        if g is None:       # every history empty: the reference crashes here (SURVEY quirk 1); use h = 0
-            perm = np.arange(len(s))
-            prep.s_idx = torch.from_numpy(s.astype(np.int32)).to(dev)
-            prep.r_idx = torch.from_numpy(r.astype(np.int32)).to(dev)
-            prep.plan_s, prep.plan_r = _device_plan(s, dev), _device_plan(r, dev)
+        prep.subject, prep.b = hbatch['subject'], hbatch['b']
+        if hbatch['pb'] is None:    # every history empty: the reference crashes here (SURVEY quirk 1); use h = 0
+            prep.g = None
+            prep.perm = np.arange(prep.b)
+            prep.s_idx = torch.from_numpy(hbatch['s']).to(dev)
+            prep.r_idx = torch.from_numpy(hbatch['r']).to(dev)
+            prep.plan_s, prep.plan_r = _device_plan(hbatch['s'], dev), _device_plan(hbatch['r'], dev)
         else:
-            perm = g.host.perm
+            g = G.DeviceGraph(hbatch['pb'], dev)
+            g.glob = self.aggregator.glob_table.get(self.global_emb, self.h_dim, dev).mat
+            prep.g, prep.perm = g, g.host.perm
             prep.s_idx, prep.r_idx, prep.plan_s, prep.plan_r = g.s_sorted, g.r_sorted, g.plan_s, g.plan_r
             prep.batch_sizes = torch.from_numpy(g.host.batch_sizes)
             prep.step_off = ops.host_offsets(g.host.step_off)
-        prep.perm = perm
-        prep.o_idx = torch.from_numpy(o[perm].astype(np.int32)).to(dev)
+        prep.o_idx = torch.from_numpy(hbatch['o']).to(dev)
         return prep
+
+    def prepare(self, triplets, hist, graph_dict, subject=True):
+        """Host + upload half of one direction of a training step: batch graph, packed layout and plans,
+        uploaded once.  Everything `loss_prepared` needs is device-resident afterwards, so an input pipeline
+        can run this ahead of the step (bench.py does; pipeline.BatchPrefetcher runs the host part in worker
+        processes).  hist: (histories, timestamps) in the reference's nested-list layout, or a FlatHistory."""
+        return self.prepare_from_host(self.host_batch(triplets, hist, graph_dict, subject))
 
     def loss_prepared(self, prep):
         """Device half (model.py:82-103): RGCN x2 -> sequence assembly -> GRU x2 -> heads -> loss."""

@@ -1,0 +1,42 @@
+"""Input pipeline: the host half of every step (batch-graph construction, graph.build_batch -- the
+reference's dominant cost, utils.py:209-244) runs ahead of the device in worker PROCESSES, so the
+training loop only uploads one packed buffer per direction and launches kernels.
+
+Workers are forked (they inherit the graph store, the history index and the model's host-side tables
+copy-on-write) and never touch the GPU.  Results come back in step order.
+"""
+import multiprocessing as mp
+import os
+
+_job = {}
+
+
+def _run(step):
+    return _job['fn'](step)
+
+
+class BatchPrefetcher(object):
+    """for host_batches in BatchPrefetcher(fn, steps, workers): ...   where fn(step) is pure host work."""
+
+    def __init__(self, fn, steps, num_workers=None, chunksize=1):
+        self.fn, self.steps = fn, list(steps)
+        self.num_workers = num_workers or max(1, min(32, (os.cpu_count() or 2) // 2))
+        self.chunksize = chunksize
+        self.pool = None
+
+    def __iter__(self):
+        if self.num_workers <= 1:
+            for s in self.steps:
+                yield self.fn(s)
+            return
+        _job['fn'] = self.fn                       # visible to the forked children
+        ctx = mp.get_context('fork')
+        self.pool = ctx.Pool(self.num_workers)
+        try:
+            for item in self.pool.imap(_run, self.steps, self.chunksize):
+                yield item
+        finally:
+            self.pool.terminate()
+            self.pool.join()
+            self.pool = None
+            _job.pop('fn', None)

@@ -240,3 +240,27 @@ def test_preprocess_cli_writes_reference_layout(tmp_path):
     e0, e1 = gold['graph_edge_ptr'][k], gold['graph_edge_ptr'][k + 1]
     src, dst, et = gd[t].edges(False)
     assert np.array_equal(src, gold['graph_src'][e0:e1]) and np.array_equal(et, gold['graph_type_s'][e0:e1])
+
+
+def test_prefetcher_returns_packed_batches_in_order():
+    """pipeline.BatchPrefetcher (forked workers) == inline builder, same order; PackedBatch round trip."""
+    import pickle
+    import pipeline
+    import preprocess as P
+    import synth
+    quads, ne, nr, _ = synth.make_stream('ICEWS18', seed=1, num_t=20)
+    gd = P.build_graph_dict(quads, nr)
+    hs = P.HistoryIndex(quads, 's', 10)
+    perm = np.random.RandomState(0).permutation(len(quads))
+    store = G.store_for(gd)
+
+    def fn(step):
+        idx = perm[step * 128:(step + 1) * 128]
+        return G.PackedBatch(G.build_batch(store, ne, nr, quads[idx, 0], quads[idx, 1], hs.take(idx), sort=True))
+    inline = [fn(k) for k in range(5)]
+    piped = list(pipeline.BatchPrefetcher(fn, range(5), 3))
+    for x, y in zip(inline, piped):
+        assert np.array_equal(x.ints, y.ints) and np.array_equal(x.norm, y.norm) and x.scalars == y.scalars
+        assert x.names == y.names and x.offs == y.offs and np.array_equal(x.host_small['perm'], y.host_small['perm'])
+    z = pickle.loads(pickle.dumps(inline[0], protocol=5))
+    assert np.array_equal(z.ints, inline[0].ints) and all(o % 4 == 0 for o in z.offs)
