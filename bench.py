@@ -29,6 +29,7 @@ for p in (ROOT, PKG):
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA dense peak
+MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA dense peak (never the 2:1-sparse figure)
 
 
 def parse():
@@ -199,9 +200,16 @@ def main():
     if dom:
         st = stats[dom]
         if st['flops']:
+            # `achieved` counts the ALGORITHMIC fp32 flops (2MNK).  In bf16x6 mode every fp32 product is six
+            # bf16 MFMA products (fp32-class result), so the matrix-pipe ceiling for algorithmic flops is the
+            # dense bf16 peak / 6; in f32 mode it is the f32-input MFMA peak.
             ach = st['flops'] / (st['ms'] * 1e-3) / 1e12
-            roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TF,
-                        'unit': 'TFLOP/s', 'frac': ach / MFMA_F32_PEAK_TF, 'traffic': traffic_of(dom)}
+            peak = MFMA_BF16_PEAK_TF / 6.0 if K.GEMM_MODE == 'bf16x6' else MFMA_F32_PEAK_TF
+            roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': peak,
+                        'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic_of(dom),
+                        'gemm_mode': K.GEMM_MODE,
+                        'note': 'algorithmic fp32 TFLOP/s; peak = bf16 dense 2500/6 (six bf16 MFMA products per '
+                                'fp32 product)' if K.GEMM_MODE == 'bf16x6' else 'f32-input MFMA peak'}
         else:
             ach = st['bytes'] / (st['ms'] * 1e-3) / 1e9
             roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -224,7 +232,7 @@ def main():
         'metric': 'RGCN+GRU encoder triples/s at bs=1024 n_hidden=200 (full training step, both directions)',
         'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'gemm_mode': K.GEMM_MODE,
         'config': {'workload': '%s-shaped synthetic stream (seed 999), n_hidden=%d, seq_len=%d, batch=%d per GPU, '
                                'dropout=%.2f, fwd+bwd both directions + clip + Adam' %
                                (args.shape, args.hidden, args.seq_len, args.batch, args.dropout),

@@ -114,6 +114,13 @@ int renet_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, const float
                    const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                    int split_k, float* workspace, size_t workspace_bytes, void* stream);
 
+/* Same contract as renet_gemm_f32, computed on the bf16 matrix cores with every fp32 operand split into
+ * three bf16 terms and the six leading term products accumulated in fp32 ("bf16x6"): fp32-class accuracy
+ * (dropped terms <= 2^-23 relative) at 16/6 of the f32-input MFMA rate.  See csrc/gemm_split.hip. */
+int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
+                         const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
+                         int split_k, float* workspace, size_t workspace_bytes, void* stream);
+
 /* column sums: out[n] = sum_m X[m,n]  (bias gradients); two deterministic passes over row groups,
  * `workspace` = renet_colsum_workspace(M, N) bytes (0 for short matrices). */
 size_t renet_colsum_workspace(int M, int N);

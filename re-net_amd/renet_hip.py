@@ -35,6 +35,8 @@ _SIGNATURES = {
     'renet_gemm_workspace': (c_size_t, [c_int, c_int, c_int]),
     'renet_gemm_f32': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'renet_gemm_f32_split': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
+                                     c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'renet_colsum_workspace': (c_size_t, [c_int, c_int]),
     'renet_colsum': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_seq_assemble_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -234,7 +236,13 @@ def auto_split_k(m, n, k):
     return best
 
 
-def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, split_k=None):
+# 'f32'    : v_mfma_f32_32x32x2_f32, exact fp32 products (gemm.hip)
+# 'bf16x6' : fp32 operands split into 3 bf16 terms, 6 term products on v_mfma_f32_32x32x16_bf16 with fp32
+#            accumulation (gemm_split.hip): fp32-class accuracy at 2.67x the matrix-pipe rate
+GEMM_MODE = os.environ.get('RENET_GEMM', 'bf16x6')      # RENET_GEMM=f32 selects the exact-fp32 MFMA kernel
+
+
+def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, split_k=None, mode=None):
     """out = alpha * op(a) @ op(b) + bias + beta * out.  a/b may be row-strided views.
     split_k=None picks the deterministic split-K factor automatically."""
     if not (a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32):
@@ -255,9 +263,10 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, spl
         ws = torch.empty(ws_bytes // 4, device=a.device, dtype=torch.float32)
         ws_ptr = ws.data_ptr()
     t0 = _timer.begin() if _timer is not None else None
-    _check(lib().renet_gemm_f32(int(ta), int(tb), m, n, k, float(alpha), a.data_ptr(), _ld(a), b.data_ptr(),
-                                _ld(b), float(beta), out.data_ptr(), _ld(out), _f32(bias), split_k, ws_ptr,
-                                ws_bytes, _stream()), 'gemm_f32')
+    fn = lib().renet_gemm_f32_split if (mode or GEMM_MODE) == 'bf16x6' else lib().renet_gemm_f32
+    _check(fn(int(ta), int(tb), m, n, k, float(alpha), a.data_ptr(), _ld(a), b.data_ptr(),
+              _ld(b), float(beta), out.data_ptr(), _ld(out), _f32(bias), split_k, ws_ptr,
+              ws_bytes, _stream()), 'gemm_f32')
     if t0 is not None:
         _timer.end('gemm_f32', t0, flops=2.0 * m * n * k)
     return out

@@ -33,14 +33,15 @@ def _to(x, dev):
 @pytest.mark.parametrize('m,n,k', [(1, 1, 1), (7, 5, 3), (128, 128, 32), (200, 200, 200), (257, 130, 71),
                                    (1024, 777, 600), (64, 600, 200), (333, 200, 4)])
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_gemm_matches_fp64(dev, m, n, k, ta, tb):
+@pytest.mark.parametrize('mode', ['f32', 'bf16x6'])
+def test_gemm_matches_fp64(dev, m, n, k, ta, tb, mode):
     import renet_hip as K
     rng = np.random.RandomState(m * 131 + n * 17 + k + ta * 2 + tb)
     a = rng.uniform(-1, 1, (k, m) if ta else (m, k)).astype(np.float32)
     b = rng.uniform(-1, 1, (n, k) if tb else (k, n)).astype(np.float32)       # asymmetric operands
     bias = rng.uniform(-1, 1, n).astype(np.float32)
     ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64) + bias
-    out = K.gemm(_to(a, dev), _to(b, dev), ta=bool(ta), tb=bool(tb), bias=_to(bias, dev))
+    out = K.gemm(_to(a, dev), _to(b, dev), ta=bool(ta), tb=bool(tb), bias=_to(bias, dev), mode=mode)
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * max(1, k) ** 0.5)
 
 
@@ -53,9 +54,10 @@ def test_gemm_splitk_beta_and_strided_views(dev):
     c0 = rng.uniform(-1, 1, (96, 100)).astype(np.float32)
     ref = 0.5 * a.T.astype(np.float64) @ big[:, 400:].astype(np.float64) + 2.0 * c0
     for sk in (1, 4, 37):
-        out = _to(c0, dev).clone()
-        K.gemm(_to(a, dev), b_view, ta=True, out=out, alpha=0.5, beta=2.0, split_k=sk)
-        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=2e-4)
+        for mode in ('f32', 'bf16x6'):
+            out = _to(c0, dev).clone()
+            K.gemm(_to(a, dev), b_view, ta=True, out=out, alpha=0.5, beta=2.0, split_k=sk, mode=mode)
+            np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=2e-4)
     one = K.gemm(_to(a, dev), b_view, ta=True, split_k=8)
     two = K.gemm(_to(a, dev), b_view, ta=True, split_k=8)
     assert torch.equal(one, two), 'split-K must be deterministic'

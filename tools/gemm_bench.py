@@ -24,21 +24,22 @@ def main():
         a = torch.randn((k, m) if ta else (m, k), device=dev)
         b = torch.randn((n, k) if tb else (k, n), device=dev)
         out = torch.empty(m, n, device=dev)
-        for sk in (None,):
+        ref = (a.t() if ta else a).double() @ (b.t() if tb else b).double() if m * n * k < 3e10 else None
+        line = '%-16s M=%6d N=%6d K=%6d s=%-3d' % (name, m, n, k, K.auto_split_k(m, n, k))
+        for mode in ('f32', 'bf16x6'):
             for _ in range(3):
-                K.gemm(a, b, ta=bool(ta), tb=bool(tb), out=out, split_k=sk)
+                K.gemm(a, b, ta=bool(ta), tb=bool(tb), out=out, mode=mode)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             it = 20
             e0.record()
             for _ in range(it):
-                K.gemm(a, b, ta=bool(ta), tb=bool(tb), out=out, split_k=sk)
+                K.gemm(a, b, ta=bool(ta), tb=bool(tb), out=out, mode=mode)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / it
-            ref = (a.t() if ta else a).double() @ (b.t() if tb else b).double() if m * n * k < 3e10 else None
             err = float((out.double() - ref).abs().max() / ref.abs().max()) if ref is not None else float('nan')
-            print('%-18s M=%6d N=%6d K=%6d split=%-4s %9.1f us %7.2f TF  relerr %.1e' %
-                  (name, m, n, k, K.auto_split_k(m, n, k) if sk is None else sk, us, 2.0 * m * n * k / us / 1e6, err))
+            line += ' | %-6s %8.1f us %6.1f TF err %.1e' % (mode, us, 2.0 * m * n * k / us / 1e6, err)
+        print(line)
 
 
 if __name__ == '__main__':
