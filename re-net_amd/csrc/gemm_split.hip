@@ -208,19 +208,17 @@ __global__ __launch_bounds__(THREADS) void gemm_split_kernel(SplitArgs g) {
                     a[t][p] = *reinterpret_cast<const bf16x8*>(&sA[p * PLANE + arow + t * 32 * LDS_ROW + ko]);
                     b[t][p] = *reinterpret_cast<const bf16x8*>(&sB[p * PLANE + brow + t * 32 * LDS_ROW + ko]);
                 }
+            // six term pairs, smallest first; consecutive MFMAs go to DIFFERENT accumulators so that none
+            // waits on the previous one's result
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+            constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int q = 0; q < 6; ++q)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);   // smallest first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
         }
     }
 

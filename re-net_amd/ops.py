@@ -22,16 +22,46 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# When a parameter already owns a persistent .grad buffer (parallel.FlatGrads / zero_grad(set_to_none=False)),
+# the backward kernels accumulate STRAIGHT into it (GEMM beta=1, segmented scatter-add) and return None for
+# that input, instead of materialising a full-size gradient tensor that autograd then adds: for ent_embeds
+# (4 uses per direction, 18 MB each) and linear.weight (55 MB) that removes ~45 add/fill kernels per step.
+INPLACE_GRADS = True
+
+
+def grad_target(t):
+    """The slice of a leaf parameter's existing .grad that corresponds to tensor `t` (the parameter itself or
+    a contiguous row-slice view of it), or None if there is nothing to accumulate into."""
+    if not INPLACE_GRADS or t is None:
+        return None
+    base = t if t.is_leaf else getattr(t, '_base', None)
+    if base is None or not base.is_leaf or not base.requires_grad or base.grad is None:
+        return None
+    if not base.grad.is_contiguous() or base.grad.shape != base.shape:
+        return None
+    if t is base:
+        return base.grad
+    if t.dim() == 2 and base.dim() == 2 and t.is_contiguous() and t.shape[1] == base.shape[1]:
+        off = t.storage_offset() - base.storage_offset()
+        if off >= 0 and off % base.shape[1] == 0:
+            r0 = off // base.shape[1]
+            return base.grad[r0:r0 + t.shape[0]]
+    return None
+
+
 class GatherRowsFn(Function):
     """out = table[idx]  (utils.py:239 h0 = ent_embeds[id]); backward = deterministic segmented add."""
 
     @staticmethod
     def forward(ctx, table, idx, plan):
-        ctx.plan, ctx.shape = plan, table.shape
+        ctx.plan, ctx.shape, ctx.tgt = plan, table.shape, grad_target(table)
         return K.gather_rows(_c(table), idx)
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.tgt is not None:
+            K.segment_add(_c(g), ctx.plan, ctx.tgt)
+            return None, None, None
         d = torch.zeros(ctx.shape, device=g.device, dtype=torch.float32)
         K.segment_add(_c(g), ctx.plan, d)
         return d, None, None
@@ -54,6 +84,7 @@ class RGCNLayerFn(Function):
                       g.heavy_rows_out if pruned else g.heavy_rows, g.heavy_thresh,
                       n_edges=g.E_out if pruned else None)
         ctx.g, ctx.relu, ctx.drop_p, ctx.seed, ctx.shift, ctx.n_out = g, relu, drop_p, seed, shift, n_out
+        ctx.tgt_loop = grad_target(loop_weight)
         ctx.save_for_backward(h, weight, loop_weight, out)
         return out
 
@@ -69,7 +100,11 @@ class RGCNLayerFn(Function):
         K.rgcn_bwd_prep(g_out, out, g.norm, ctx.relu, ctx.drop_p, ctx.seed, gn, g_loop)
         dh = torch.empty(n, d, device=h.device, dtype=torch.float32)
         K.gemm(g_loop, loop_weight, tb=True, out=dh[:n_out])           # g_loop @ W_loop^T (rows < n_out)
-        d_loop = K.gemm(h[:n_out], g_loop, ta=True)                    # h^T @ g_loop (auto split-K)
+        if ctx.tgt_loop is not None:                                   # h^T @ g_loop (auto split-K), accumulated
+            K.gemm(h[:n_out], g_loop, ta=True, out=ctx.tgt_loop, beta=1.0)
+            d_loop = None
+        else:
+            d_loop = K.gemm(h[:n_out], g_loop, ta=True)
         # dh += sum over out-edges W[type]^T gn[dst]  == same CSR rows, the PAIRED edge's type; with a pruned
         # forward only destinations < n_out carry gradient: skip the other sources, no addend past n_out
         pair_shift = (ctx.shift + g.num_types // 2) % g.num_types
@@ -96,6 +131,7 @@ class SeqAssembleFn(Function):
                                    drop_p, seed_x, seed_xr)
         ctx.g, ctx.drop_p, ctx.seeds = g, drop_p, (seed_x, seed_xr)
         ctx.shapes = (h2.shape, ent.shape, rel.shape)
+        ctx.tgt_ent, ctx.tgt_rel = grad_target(ent), grad_target(rel)
         return x, xr
 
     @staticmethod
@@ -107,10 +143,17 @@ class SeqAssembleFn(Function):
         dev = dx.device
         d_h2 = torch.zeros(ctx.shapes[0], device=dev, dtype=torch.float32)
         K.segment_add(d_rows, g.plan_subj_row, d_h2)
-        d_ent = torch.zeros(ctx.shapes[1], device=dev, dtype=torch.float32)
-        K.segment_add(d_ent_seq, g.plan_s, d_ent)             # per-sequence sums, keyed by s[perm]
-        d_rel = torch.zeros(ctx.shapes[2], device=dev, dtype=torch.float32)
-        K.segment_add(d_rel_seq, g.plan_r, d_rel)
+        d_ent = d_rel = None
+        if ctx.tgt_ent is not None:
+            K.segment_add(d_ent_seq, g.plan_s, ctx.tgt_ent)       # per-sequence sums, keyed by s[perm]
+        else:
+            d_ent = torch.zeros(ctx.shapes[1], device=dev, dtype=torch.float32)
+            K.segment_add(d_ent_seq, g.plan_s, d_ent)
+        if ctx.tgt_rel is not None:
+            K.segment_add(d_rel_seq, g.plan_r, ctx.tgt_rel)
+        else:
+            d_rel = torch.zeros(ctx.shapes[2], device=dev, dtype=torch.float32)
+            K.segment_add(d_rel_seq, g.plan_r, d_rel)
         return d_h2, d_ent, d_rel, None, None, None, None, None
 
 
@@ -171,6 +214,7 @@ class DualGRUFn(Function):
                 t = full
             outs.append(t.unsqueeze(0))
         ctx.step_off, ctx.nnz, ctx.hdim = step_off, nnz, hdim
+        ctx.tgts = [grad_target(t) for t in (w_ih, w_hh, w_ih_r, w_hh_r)]
         ctx.save_for_backward(x, xr, w_ih, w_hh, w_ih_r, w_hh_r, sv, svr)
         return outs[0], outs[1]
 
@@ -181,9 +225,19 @@ class DualGRUFn(Function):
         (d_gi, d_gir), (d_gh, d_ghr) = K.gru_bwd_multi([_c(dh[0, :nnz]), _c(dq[0, :nnz])], ctx.step_off, hdim,
                                                        [w_hh, w_hh_r], [sv, svr])
         res = []
-        for xx, wi, dgi, dgh, s_ in ((x, w_ih, d_gi, d_gh, sv), (xr, w_ih_r, d_gir, d_ghr, svr)):
-            res.append((K.gemm(dgi, wi), K.gemm(dgi, xx, ta=True), K.gemm(dgh, s_[:, 4 * hdim:], ta=True),
-                        K.colsum(dgi), K.colsum(dgh)))
+        for k, (xx, wi, dgi, dgh, s_) in enumerate(((x, w_ih, d_gi, d_gh, sv), (xr, w_ih_r, d_gir, d_ghr, svr))):
+            t_ih, t_hh = ctx.tgts[2 * k], ctx.tgts[2 * k + 1]
+            if t_ih is not None:
+                K.gemm(dgi, xx, ta=True, out=t_ih, beta=1.0)
+                dwi_ = None
+            else:
+                dwi_ = K.gemm(dgi, xx, ta=True)
+            if t_hh is not None:
+                K.gemm(dgh, s_[:, 4 * hdim:], ta=True, out=t_hh, beta=1.0)
+                dwh_ = None
+            else:
+                dwh_ = K.gemm(dgh, s_[:, 4 * hdim:], ta=True)
+            res.append((K.gemm(dgi, wi), dwi_, dwh_, K.colsum(dgi), K.colsum(dgh)))
         (dx, dwi, dwh, dbi, dbh), (dxr, dwir, dwhr, dbir, dbhr) = res
         return dx, dxr, dwi, dwh, dbi, dbh, dwir, dwhr, dbir, dbhr, None, None
 
@@ -206,22 +260,34 @@ class HeadCEFn(Function):
                     c.shape if c is not None else None)
         if need_grad:
             ctx.save_for_backward(feat, logits, weight)
+            ctx.tgts = (grad_target(a), grad_target(c) if c is not None else None, grad_target(weight))
         return row_loss.mean()
 
     @staticmethod
     def backward(ctx, g):
         feat, dlogits, weight = ctx.saved_tensors
         d, parts, drop_p, seed, plan_a, plan_c, a_shape, c_shape = ctx.meta
+        t_a, t_c, t_w = ctx.tgts
         dfeat = K.gemm(dlogits, weight) * g                              # [B, parts*D]
-        d_w = K.gemm(dlogits, feat * g, ta=True)
+        if t_w is not None:
+            K.gemm(dlogits, feat * g, ta=True, out=t_w, beta=1.0)
+            d_w = None
+        else:
+            d_w = K.gemm(dlogits, feat * g, ta=True)
         d_b = K.colsum(dlogits) * g
         da_rows, dh, dc_rows = K.concat3_bwd(dfeat, d, parts, drop_p, seed)
-        d_a = torch.zeros(a_shape, device=g.device, dtype=torch.float32)
-        K.segment_add(da_rows, plan_a, d_a)
-        d_c = None
+        d_a = d_c = None
+        if t_a is not None:
+            K.segment_add(da_rows, plan_a, t_a)
+        else:
+            d_a = torch.zeros(a_shape, device=g.device, dtype=torch.float32)
+            K.segment_add(da_rows, plan_a, d_a)
         if parts == 3:
-            d_c = torch.zeros(c_shape, device=g.device, dtype=torch.float32)
-            K.segment_add(dc_rows, plan_c, d_c)
+            if t_c is not None:
+                K.segment_add(dc_rows, plan_c, t_c)
+            else:
+                d_c = torch.zeros(c_shape, device=g.device, dtype=torch.float32)
+                K.segment_add(dc_rows, plan_c, d_c)
         return d_a, None, dh, d_c, None, d_w, d_b, None, None, None, None, None
 
 

@@ -557,3 +557,32 @@ def test_fused_adam_matches_torch_adam_with_clipping(dev):
         assert float(opt.grads.flat.abs().max()) == 0.0 and opt.grads.check_views()
         for a, b in zip(ref.parameters(), mine.parameters()):
             torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-7)
+
+
+def test_inplace_gradient_accumulation_equals_autograd_accumulation(dev):
+    """With persistent .grad buffers (parallel.FlatGrads) the backward kernels accumulate straight into them;
+    the result must equal the ordinary autograd path (fresh .grad tensors), incl. a second accumulation."""
+    import ops
+    import parallel
+    c = train_case('small', 200)
+    batch = torch.from_numpy(c['batch']).to(dev)
+    grads = []
+    for inplace in (False, True):
+        net, gd = _build_model(c, dev)
+        net.eval()
+        ops.INPLACE_GRADS = inplace
+        flat = parallel.FlatGrads(net) if inplace else None
+        try:
+            for _ in range(2):                                   # accumulate two backward passes
+                loss = net(batch, c['hists']['s'], c['hists']['o'], gd, subject=True) + \
+                    net(batch, c['hists']['s'], c['hists']['o'], gd, subject=False)
+                loss.backward()
+        finally:
+            ops.INPLACE_GRADS = True
+        if inplace:
+            assert flat.check_views()
+        grads.append({k: p.grad.clone() for k, p in net.named_parameters()})
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        scale = max(float(a.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 1e-5 * scale, (k, float((a - b).abs().max()), scale)
