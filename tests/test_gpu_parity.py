@@ -586,3 +586,43 @@ def test_inplace_gradient_accumulation_equals_autograd_accumulation(dev):
         a, b = grads[0][k], grads[1][k]
         scale = max(float(a.abs().max()), 1e-6)
         assert float((a - b).abs().max()) <= 1e-5 * scale, (k, float((a - b).abs().max()), scale)
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases of the reference semantics: empty / single / ragged histories
+# ---------------------------------------------------------------------------------------------
+def test_edge_case_batches_match_oracle(dev):
+    c = train_case('small', 200)
+    cfg = c['cfg']
+    net, gd = _build_model(c, dev)
+    net.eval()
+    ogd = O.build_graph_dict(c['train'], cfg['num_rels'])
+    params = {k: torch.from_numpy(v) for k, v in c['params'].items()}
+    ge = {t: torch.from_numpy(v) for t, v in c['global_emb'].items()}
+    hs, hst = c['hists']['s']
+    lens = np.asarray([len(h) for h in hs])
+    empty = np.nonzero(lens == 0)[0]
+    full = np.nonzero(lens > 0)[0]
+    assert len(empty) >= 3 and len(full) >= 3
+    cases = {
+        'all_empty': empty[:3],                                  # reference: unbound variable crash (quirk 1); we use h = 0
+        'one_nonempty': np.concatenate((empty[:2], full[:1])),   # reference: squeeze() drops the batch dim (quirk 2)
+        'single_sequence': full[1:2],
+        'ragged': np.concatenate((full[:5], empty[:1], full[5:9])),
+    }
+    for name, sel in cases.items():
+        batch = c['batch'][sel]
+        h = ([hs[i] for i in sel], [hst[i] for i in sel])
+        with torch.no_grad():
+            mine = float(net(torch.from_numpy(batch).to(dev), h, h, gd, subject=True))
+        if name == 'all_empty':
+            # oracle formula with s_h = 0 (what the reference would compute had it not crashed)
+            s, r, o = batch[:, 0], batch[:, 1], batch[:, 2]
+            ent, rel = params['ent_embeds'], params['rel_embeds'][:cfg['num_rels']]
+            z = torch.zeros(len(s), c['d'])
+            lo = O.cross_entropy_mean(torch.cat((ent[s], z, rel[r]), 1) @ params['linear.weight'].t() + params['linear.bias'], o)
+            lr = O.cross_entropy_mean(torch.cat((ent[s], z), 1) @ params['linear_r.weight'].t() + params['linear_r.bias'], r)
+            ref = float(lo + 0.1 * lr)
+        else:
+            ref = float(O.renet_forward_loss(params, batch, h[0], h[1], ogd, ge, cfg['num_rels'], c['seq_len'], subject=True))
+        assert abs(mine - ref) < 2e-4 * max(1.0, abs(ref)), (name, mine, ref)
