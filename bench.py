@@ -152,15 +152,16 @@ def main():
         n_pipe = max(40, 8 * args.e2e_steps)
         e2e_workers = max(1, min(24, (os.cpu_count() or 2) // (2 * world)))
         pf = pipeline.BatchPrefetcher(host_step, range(n_total + 100, n_total + 100 + n_pipe), e2e_workers)
+        up = pipeline.Uploader(net)                              # H2D on a copy stream, off the compute queue
         it = iter(pf)
         first = [next(it) for _ in range(4)]                    # let the workers fill the pipe
         for hs_, ho_ in first:
-            train_step(net.prepare_from_host(hs_), net.prepare_from_host(ho_))
+            train_step(up(hs_), up(ho_))
         sync_all()
         t0 = time.perf_counter()
         done = 0
         for hs_, ho_ in it:
-            train_step(net.prepare_from_host(hs_), net.prepare_from_host(ho_))
+            train_step(up(hs_), up(ho_))
             done += 1
         sync_all()
         e2e = args.batch * world * done / (time.perf_counter() - t0)

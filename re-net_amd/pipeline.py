@@ -40,3 +40,28 @@ class BatchPrefetcher(object):
             self.pool.join()
             self.pool = None
             _job.pop('fn', None)
+
+
+class Uploader(object):
+    """Uploads packed host batches on a dedicated copy stream.  A pageable-memory H2D copy issued on the
+    compute stream would queue behind every kernel of the previous step and block the training thread until
+    they finish; on its own (idle) stream it completes immediately, the compute stream just waits for the
+    copy's event, and the training thread keeps running ahead of the GPU."""
+
+    def __init__(self, net):
+        import torch
+        self.torch = torch
+        self.net = net
+        self.stream = torch.cuda.Stream()
+
+    def __call__(self, hbatch):
+        torch = self.torch
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.stream):
+            prep = self.net.prepare_from_host(hbatch)
+        main.wait_stream(self.stream)
+        g = prep.g
+        for t in ([g._buf, g.norm] if g is not None else []) + [prep.o_idx, prep.s_idx, prep.r_idx]:
+            if t is not None and t.is_cuda:
+                t.record_stream(main)             # allocator: memory is in use on the compute stream
+        return prep
