@@ -138,6 +138,22 @@ def _lookup_table(n):
     return t
 
 
+def stable_argsort(keys, bound):
+    """Stable argsort of non-negative integer keys < bound.  numpy's stable sort is an O(n) radix sort only
+    for 16-bit keys (for int64 it is a mergesort ~6x slower at the sizes of a batch), so sort by 16-bit digits
+    least-significant first."""
+    keys = np.asarray(keys)
+    if bound <= (1 << 16):
+        return np.argsort(keys.astype(np.uint16), kind='stable')
+    order = np.argsort((keys & 0xFFFF).astype(np.uint16), kind='stable')
+    shift = 16
+    while (bound - 1) >> shift:
+        digit = ((keys[order] >> shift) & 0xFFFF).astype(np.uint16)
+        order = order[np.argsort(digit, kind='stable')]
+        shift += 16
+    return order
+
+
 def ragged_arange(starts, counts):
     """concat([arange(s, s + c) for s, c in zip(starts, counts)]) without a Python loop."""
     counts = np.asarray(counts, dtype=np.int64)
@@ -200,7 +216,7 @@ class SegPlan(object):
     def host(cls, idx):
         idx = np.asarray(idx, dtype=np.int64)
         p = cls()
-        p.order = np.argsort(idx, kind='stable').astype(np.int32)
+        p.order = stable_argsort(idx, int(idx.max()) + 1 if len(idx) else 1).astype(np.int32)
         srt = idx[p.order]
         if len(srt):
             first = np.concatenate(([True], srt[1:] != srt[:-1]))
@@ -231,14 +247,15 @@ class HostBatch(object):
         et = np.asarray(et, dtype=np.int64)
         E = len(src)
         self.N, self.E, self.num_types = int(n), E, int(num_types)
-        order = np.argsort(dst * np.int64(num_types) + et, kind='stable')     # by destination, then type
+        by_type = stable_argsort(et, num_types)
+        order = by_type[stable_argsort(dst[by_type], max(int(n), 1))]         # by destination, then type
         self.col = src[order].astype(np.int32)
         self.etype = et[order].astype(np.int32)
         deg = np.bincount(dst, minlength=n)
         self.row_ptr = np.concatenate(([0], np.cumsum(deg))).astype(np.int32)
         self.norm = (1.0 / np.maximum(deg, 1)).astype(np.float32)            # utils.py:89-93
         self.heavy_rows = np.nonzero(deg > HEAVY)[0].astype(np.int32)
-        order2 = np.argsort(et, kind='stable')
+        order2 = by_type
         self.e_src = src[order2].astype(np.int32)
         self.e_dst = dst[order2].astype(np.int32)
         T = int(num_types)

@@ -186,7 +186,9 @@ def rgcn_gather(x, row_ptr, col, etype, scale, weight, type_shift, transpose_w, 
         nn = out.shape[0]
         e = col.numel() if n_edges is None else int(n_edges)
         nbytes = e * (d * 4 + 8) + nn * (d * 4 + 8) + weight.numel() * 4 + (nn * d * 4 if addend is not None else 0)
-        _timer.end('rgcn_gather', t0, nbytes=float(nbytes))
+        # launches over the full batch graph (layer 1 and its backward) and the pruned ones (last layer:
+        # subject rows only, a few thousand short rows -- launch-latency bound) are different regimes
+        _timer.end('rgcn_gather' if n_edges is None else 'rgcn_gather_pruned', t0, nbytes=float(nbytes))
     return out
 
 
