@@ -222,7 +222,9 @@ def auto_split_k(m, n, k):
     """split-K factor when the output has too few 128x128 tiles to fill 256 CUs (weight-gradient and
     dX-of-the-head shapes): aim at ~2 workgroups per CU, keep >= 4 k-tiles per slice."""
     tiles = ((m + 127) // 128) * ((n + 127) // 128)
-    if tiles >= 512:
+    # the partial sums cost split * M * N * 8 bytes of traffic plus a reduce launch: only worth it while the
+    # un-split grid would leave more than half of the 256 CUs idle
+    if tiles >= 128:
         return 1
     ktiles = (k + 31) // 32
     # 2 workgroups are resident per CU (73.7 KB LDS each) => rounds of 512.  Swept on MI355X
