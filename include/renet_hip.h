@@ -215,6 +215,22 @@ int renet_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, 
                     float eps, float weight_decay, float max_norm, int step, int zero_grad, float* workspace,
                     size_t workspace_bytes, float* grad_norm_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * HOST-side batch-graph builder passes (no device work; pointers are HOST arrays): the native form of
+ * graph.build_batch's heavy middle, replacing the reference's per-batch DGL subgraph/batch calls
+ * (utils.py:115-131,158-170,236-241).  See csrc/host_builder.cpp for the contracts. */
+int64_t renet_host_filter_edges(const int64_t* trip_ptr, const int64_t* trip_s, const int64_t* trip_r,
+                                const int64_t* trip_o, const int64_t* ti, int64_t Tb, int64_t num_ent,
+                                const int64_t* keys, const int32_t* new_id, int64_t N, int32_t* table,
+                                int64_t* out_ls, int64_t* out_lo, int64_t* out_rr);
+void renet_host_edge_layouts(int64_t n, int64_t E, const int64_t* src, const int64_t* dst, const int64_t* et,
+                             int64_t T, int64_t chunk, int64_t heavy, int32_t* col, int32_t* etype,
+                             int32_t* row_ptr, float* norm, int32_t* heavy_rows, int64_t* n_heavy,
+                             int32_t* e_src, int32_t* e_dst, int32_t* type_chunk_ptr, int32_t* chunk_type,
+                             int32_t* chunk_ptr, int64_t* n_chunks);
+int64_t renet_host_segplan(const int64_t* idx, int64_t n, int64_t bound, int32_t* order, int32_t* seg_ptr,
+                           int32_t* target);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
 
 
 def sources():
-    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
 
 
 def stale():
@@ -34,8 +34,9 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     for src in sources():
-        obj = src[:-4] + '.o'
-        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+        obj = os.path.splitext(src)[0] + '.o'
+        flags = FLAGS if src.endswith('.hip') else ['-O3', '-std=c++17', '-fPIC', '-Wall']
+        cmd = [HIPCC] + flags + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

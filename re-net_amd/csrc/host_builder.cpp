@@ -1,0 +1,107 @@
+// Native HOST half of the batch-graph builder (no device code): the O(#facts of the batch's timestamps)
+// passes of graph.build_batch -- node-induced edge filtering, the two stable counting sorts that produce
+// the CSR-by-destination and the relation-bucketed edge list, chunking, hub rows, segmented-add plans.
+// Replaces the reference's per-batch DGL subgraph / batch calls (utils.py:115-131,158-170,236-241) and the
+// numpy versions in graph.py (kept as the executable specification: tests compare the two bit for bit).
+// Plain C ABI, caller-owned buffers, no allocation that outlives a call, thread-safe given distinct scratch.
+#include <stdint.h>
+#include <stddef.h>
+#include <vector>
+#include <algorithm>
+
+extern "C" {
+
+// Marks table[keys[i]] = new_id[i], scans every fact of the timestamps ti[0..Tb), keeps those whose two
+// endpoints are both marked, restores the table to -1.  `table` is a caller-owned int32 scratch of at least
+// Tb * num_ent entries, all -1 on entry.  Outputs (capacity = total facts of those timestamps): local source /
+// destination rows and relation of every kept fact, in (slot, fact) order.  Returns the number kept.
+int64_t renet_host_filter_edges(const int64_t* trip_ptr, const int64_t* trip_s, const int64_t* trip_r,
+                                const int64_t* trip_o, const int64_t* ti, int64_t Tb, int64_t num_ent,
+                                const int64_t* keys, const int32_t* new_id, int64_t N, int32_t* table,
+                                int64_t* out_ls, int64_t* out_lo, int64_t* out_rr) {
+    for (int64_t i = 0; i < N; ++i) table[keys[i]] = new_id[i];
+    int64_t m = 0;
+    for (int64_t slot = 0; slot < Tb; ++slot) {
+        const int32_t* tab = table + slot * num_ent;
+        const int64_t b = trip_ptr[ti[slot]], e = trip_ptr[ti[slot] + 1];
+        for (int64_t j = b; j < e; ++j) {
+            const int32_t ps = tab[trip_s[j]];
+            const int32_t po = tab[trip_o[j]];
+            if ((ps | po) >= 0) {                         // both non-negative
+                out_ls[m] = ps; out_lo[m] = po; out_rr[m] = trip_r[j];
+                ++m;
+            }
+        }
+    }
+    for (int64_t i = 0; i < N; ++i) table[keys[i]] = -1;
+    return m;
+}
+
+// Directed edges (src -> dst, type et in [0,T)) -> CSR by destination with relation-sorted rows, norm,
+// hub rows (in-degree > heavy), the relation-bucketed edge list and its <= chunk-edge single-type chunks.
+// Stable throughout (ties keep the input edge order) == graph.HostBatch.set_edges.
+void renet_host_edge_layouts(int64_t n, int64_t E, const int64_t* src, const int64_t* dst, const int64_t* et,
+                             int64_t T, int64_t chunk, int64_t heavy, int32_t* col, int32_t* etype,
+                             int32_t* row_ptr, float* norm, int32_t* heavy_rows, int64_t* n_heavy,
+                             int32_t* e_src, int32_t* e_dst, int32_t* type_chunk_ptr, int32_t* chunk_type,
+                             int32_t* chunk_ptr, int64_t* n_chunks) {
+    std::vector<int64_t> tstart(T + 1, 0), by_type(E);
+    for (int64_t e = 0; e < E; ++e) ++tstart[et[e] + 1];
+    for (int64_t t = 0; t < T; ++t) tstart[t + 1] += tstart[t];
+    {
+        std::vector<int64_t> cur(tstart.begin(), tstart.end() - 1);
+        for (int64_t e = 0; e < E; ++e) by_type[cur[et[e]]++] = e;
+    }
+    for (int64_t k = 0; k < E; ++k) { e_src[k] = (int32_t)src[by_type[k]]; e_dst[k] = (int32_t)dst[by_type[k]]; }
+    std::vector<int64_t> rstart(n + 1, 0);
+    for (int64_t e = 0; e < E; ++e) ++rstart[dst[e] + 1];
+    int64_t nh = 0;
+    for (int64_t v = 0; v < n; ++v) {
+        const int64_t d = rstart[v + 1];
+        norm[v] = 1.0f / (float)(d > 0 ? d : 1);
+        if (d > heavy) heavy_rows[nh++] = (int32_t)v;
+        rstart[v + 1] += rstart[v];
+    }
+    *n_heavy = nh;
+    for (int64_t v = 0; v <= n; ++v) row_ptr[v] = (int32_t)rstart[v];
+    {
+        std::vector<int64_t> cur(rstart.begin(), rstart.end() - 1);
+        for (int64_t k = 0; k < E; ++k) {                 // by_type order => rows end up sorted by type, stably
+            const int64_t e = by_type[k];
+            const int64_t p = cur[dst[e]]++;
+            col[p] = (int32_t)src[e];
+            etype[p] = (int32_t)et[e];
+        }
+    }
+    int64_t nc = 0;
+    for (int64_t t = 0; t < T; ++t) {
+        type_chunk_ptr[t] = (int32_t)nc;
+        for (int64_t b = tstart[t]; b < tstart[t + 1]; b += chunk) {
+            chunk_type[nc] = (int32_t)t;
+            chunk_ptr[nc] = (int32_t)b;
+            ++nc;
+        }
+    }
+    type_chunk_ptr[T] = (int32_t)nc;
+    chunk_ptr[nc] = (int32_t)E;
+    *n_chunks = nc;
+}
+
+// Sorted plan for renet_segment_add: order = stable argsort(idx); one segment per distinct value.
+// idx values in [0, bound).  Returns the number of segments.
+int64_t renet_host_segplan(const int64_t* idx, int64_t n, int64_t bound, int32_t* order, int32_t* seg_ptr,
+                           int32_t* target) {
+    std::vector<int64_t> start(bound + 1, 0);
+    for (int64_t i = 0; i < n; ++i) ++start[idx[i] + 1];
+    int64_t U = 0;
+    for (int64_t v = 0; v < bound; ++v) {
+        if (start[v + 1] > 0) { target[U] = (int32_t)v; seg_ptr[U] = (int32_t)start[v]; ++U; }
+        start[v + 1] += start[v];
+    }
+    seg_ptr[U] = (int32_t)n;
+    std::vector<int64_t> cur(start.begin(), start.end() - 1);
+    for (int64_t i = 0; i < n; ++i) order[cur[idx[i]]++] = (int32_t)i;
+    return U;
+}
+
+}  // extern "C"

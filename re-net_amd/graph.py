@@ -19,7 +19,23 @@ reference's is set-iteration order; results do not depend on it).
 import numpy as np
 import torch
 
+import ctypes
+
 CHUNK = 64          # edges per dW work item (one wave each)
+NATIVE = True       # use csrc/host_builder.cpp for the heavy passes (the numpy code below is their executable
+                    # specification; tests/test_host_cpu.py compares the two bit for bit)
+
+
+def _native():
+    """The C library's host-builder entry points, or None when disabled (no GPU is needed for them)."""
+    if not NATIVE:
+        return None
+    import renet_hip
+    return renet_hip.lib()
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
 HEAVY = 8           # in-degree above which a row is reduced by a whole workgroup (hub rows; swept in tools/gather_bench.py)
 
 
@@ -126,15 +142,17 @@ def store_for(graph_dict):
     return st
 
 
-_scratch = {}
+import threading
+
+_scratch = threading.local()
 
 
 def _lookup_table(n):
-    """Reusable int32 scratch table pre-filled with -1 (callers restore the entries they touch)."""
-    t = _scratch.get('table')
+    """Reusable per-thread int32 scratch table pre-filled with -1 (callers restore the entries they touch)."""
+    t = getattr(_scratch, 'table', None)
     if t is None or len(t) < n:
         t = np.full(max(n, 1 << 20), -1, dtype=np.int32)
-        _scratch['table'] = t
+        _scratch.table = t
     return t
 
 
@@ -214,8 +232,17 @@ class SegPlan(object):
 
     @classmethod
     def host(cls, idx):
-        idx = np.asarray(idx, dtype=np.int64)
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
         p = cls()
+        L = _native()
+        if L is not None and len(idx):
+            n, bound = len(idx), int(idx.max()) + 1
+            p.order = np.empty(n, np.int32)
+            seg = np.empty(min(n, bound) + 1, np.int32)
+            tgt = np.empty(min(n, bound), np.int32)
+            u = L.renet_host_segplan(_p(idx), n, bound, _p(p.order), _p(seg), _p(tgt))
+            p.seg_ptr, p.target, p.num_segments = seg[:u + 1].copy(), tgt[:u].copy(), int(u)
+            return p
         p.order = stable_argsort(idx, int(idx.max()) + 1 if len(idx) else 1).astype(np.int32)
         srt = idx[p.order]
         if len(srt):
@@ -242,11 +269,30 @@ class HostBatch(object):
         """Directed edges (src -> dst, type et = type_s) -> the two device layouts:
         CSR by destination with relation-sorted rows (gather-SpMM forward / backward-wrt-h) and the
         relation-bucketed edge list cut into <= CHUNK-edge work items (backward-wrt-W)."""
-        src = np.asarray(src, dtype=np.int64)
-        dst = np.asarray(dst, dtype=np.int64)
-        et = np.asarray(et, dtype=np.int64)
+        src = np.ascontiguousarray(src, dtype=np.int64)
+        dst = np.ascontiguousarray(dst, dtype=np.int64)
+        et = np.ascontiguousarray(et, dtype=np.int64)
         E = len(src)
         self.N, self.E, self.num_types = int(n), E, int(num_types)
+        L = _native()
+        if L is not None:
+            T = int(num_types)
+            self.col, self.etype = np.empty(E, np.int32), np.empty(E, np.int32)
+            self.row_ptr, self.norm = np.empty(int(n) + 1, np.int32), np.empty(int(n), np.float32)
+            heavy = np.empty(int(n), np.int32)
+            self.e_src, self.e_dst = np.empty(E, np.int32), np.empty(E, np.int32)
+            self.type_chunk_ptr = np.empty(T + 1, np.int32)
+            cap = E // CHUNK + T + 1
+            ctype, cptr = np.empty(cap, np.int32), np.empty(cap + 1, np.int32)
+            nh, nc = ctypes.c_int64(0), ctypes.c_int64(0)
+            L.renet_host_edge_layouts(int(n), E, _p(src), _p(dst), _p(et), T, CHUNK, HEAVY, _p(self.col),
+                                      _p(self.etype), _p(self.row_ptr), _p(self.norm), _p(heavy),
+                                      ctypes.byref(nh), _p(self.e_src), _p(self.e_dst), _p(self.type_chunk_ptr),
+                                      _p(ctype), _p(cptr), ctypes.byref(nc))
+            self.heavy_rows = heavy[:nh.value].copy()
+            self.n_chunks = int(nc.value)
+            self.chunk_type, self.chunk_ptr = ctype[:self.n_chunks].copy(), cptr[:self.n_chunks + 1].copy()
+            return self
         by_type = stable_argsort(et, num_types)
         order = by_type[stable_argsort(dst[by_type], max(int(n), 1))]         # by destination, then type
         self.col = src[order].astype(np.int32)
@@ -355,8 +401,19 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None):
 
     # node-induced edges of every member graph (utils.py:115-131)
     if Tb:
-        ti = store.index_of(uniq_t)
+        ti = np.ascontiguousarray(store.index_of(uniq_t), dtype=np.int64)
         tcnt = store.trip_ptr[ti + 1] - store.trip_ptr[ti]
+        L_ = _native()
+    if Tb and L_ is not None:
+        cap = int(tcnt.sum())
+        ls, lo, rr = np.empty(cap, np.int64), np.empty(cap, np.int64), np.empty(cap, np.int64)
+        table = _lookup_table(Tb * num_ent)
+        nid32 = np.ascontiguousarray(new_id, dtype=np.int32)
+        m = L_.renet_host_filter_edges(_p(store.trip_ptr), _p(store.trip_s), _p(store.trip_r), _p(store.trip_o),
+                                       _p(ti), Tb, num_ent, _p(keys), _p(nid32), N, _p(table), _p(ls), _p(lo),
+                                       _p(rr))
+        ls, lo, rr = ls[:m], lo[:m], rr[:m]
+    elif Tb:
         flat = ragged_arange(store.trip_ptr[ti], tcnt)
         eslot = np.repeat(np.arange(Tb, dtype=np.int64), tcnt)
         ks = eslot * num_ent + store.trip_s[flat]

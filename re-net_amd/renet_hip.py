@@ -63,6 +63,11 @@ _SIGNATURES = {
     'renet_adam_workspace': (c_size_t, [c_size_t]),
     'renet_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,
                                 c_float, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    'renet_host_filter_edges': (ctypes.c_int64, [c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p,
+                                                 ctypes.c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'renet_host_edge_layouts': (None, [ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p, c_void_p, ctypes.c_int64,
+                                       ctypes.c_int64, ctypes.c_int64] + [c_void_p] * 12),
+    'renet_host_segplan': (ctypes.c_int64, [c_void_p, ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p, c_void_p]),
     'renet_segment_pool_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'renet_segment_pool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),

@@ -264,3 +264,37 @@ def test_prefetcher_returns_packed_batches_in_order():
         assert x.names == y.names and x.offs == y.offs and np.array_equal(x.host_small['perm'], y.host_small['perm'])
     z = pickle.loads(pickle.dumps(inline[0], protocol=5))
     assert np.array_equal(z.ints, inline[0].ints) and all(o % 4 == 0 for o in z.offs)
+
+
+def test_native_host_builder_equals_numpy_builder():
+    """csrc/host_builder.cpp (edge filter, CSR / bucket layouts, plans) vs the numpy specification: every
+    array of the packed batch identical, for a training-shaped and a tiny batch."""
+    import preprocess as P
+    import synth
+    quads, ne, nr, _ = synth.make_stream('ICEWS18', seed=3, num_t=40)
+    gd = P.build_graph_dict(quads, nr)
+    hs = P.HistoryIndex(quads, 'o', 10)
+    perm = np.random.RandomState(2).permutation(len(quads))
+    store = G.store_for(gd)
+    for nb in (700, 5):
+        idx = perm[:nb]
+        packed = {}
+        for native in (False, True):
+            G.NATIVE = native
+            try:
+                hb = G.build_batch(store, ne, nr, quads[idx, 2], quads[idx, 1], hs.take(idx), sort=True)
+                packed[native] = (G.PackedBatch(hb), hb)
+            finally:
+                G.NATIVE = True
+        a, b = packed[False][0], packed[True][0]
+        assert a.names == b.names and a.sizes == b.sizes and a.scalars == b.scalars
+        assert np.array_equal(a.ints, b.ints) and np.array_equal(a.norm, b.norm)
+        assert np.array_equal(packed[False][1].heavy_rows, packed[True][1].heavy_rows)
+    # full-graph batches (global model) and explicit edge lists go through the same native pass
+    for native in (False, True):
+        G.NATIVE = native
+        try:
+            packed[native] = G.PackedBatch(G.build_full_graphs(gd, list(gd.keys())[:12]))
+        finally:
+            G.NATIVE = True
+    assert np.array_equal(packed[False].ints, packed[True].ints) and np.array_equal(packed[False].norm, packed[True].norm)
