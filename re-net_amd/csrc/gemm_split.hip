@@ -10,13 +10,17 @@
 //   v_mfma_f32_32x32x2_f32 kernel of gemm.hip) -- while the matrix pipe runs 16x faster per product:
 //   6 bf16 MFMAs replace 16/6 = 2.67x their time in f32-input MFMAs.
 //
-// 128x128x32 workgroup tile, 4 waves 2x2, each wave 2x2 MFMA tiles of 32x32.  Staging: every thread owns
+// Two k-loop structures share the tile (128x128x32, 4 waves 2x2, each wave 2x2 MFMA tiles of 32x32) and the
+// LDS image: gemm_split_kernel (two phases per k-tile, two workgroups per CU) and gemm_split_fused_kernel
+// (split interleaved with the MFMAs, one workgroup per CU); kernel_choice() picks by grid size.  Staging: every thread owns
 // (row, 4 consecutive k) items: one global_load_dwordx4 when k is contiguous in memory, four dword loads
 // (coalesced across lanes along the row index) otherwise; the split happens in registers on the way into
 // LDS; three bf16 planes per operand, image [row][k] with an 80-byte row stride (16-byte aligned, rows
 // spread over all banks); fragments are one ds_read_b128 per plane (8 consecutive k per lane).
 // Out-of-range elements are clamped at load time and zeroed at LDS-store time (never right behind the
 // load, see gemm.hip).
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -42,6 +46,25 @@ struct SplitArgs {
     int split_k;
     float* partial;
 };
+
+
+// Optional phase tracing (tools/gemm_trace.py builds a separate library with -DRENET_GEMM_TRACE; the shipped
+// library contains none of this): s_memtime stamps per wave and k-step for the first TRACE_BLOCKS workgroups.
+#ifdef RENET_GEMM_TRACE
+constexpr int TRACE_BLOCKS = 64, TRACE_STEPS = 320;
+__device__ unsigned long long* g_trace = nullptr;          // [TRACE_BLOCKS][8 waves][TRACE_STEPS][4]
+__device__ __forceinline__ void trace_put(int wave8, int step, int slot, unsigned long long v) {
+    const int flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    // workgroups 0-31 and 256-287: the second set usually lands on the same CUs as the first
+    if (g_trace && flat < 512 && (flat & 255) < 32 && step < TRACE_STEPS && (threadIdx.x & 63) == 0)
+        g_trace[(((size_t)((flat >> 8) * 32 + (flat & 255)) * 8 + wave8) * TRACE_STEPS + step) * 4 + slot] = v;
+}
+#define TRACE_T(wave8, step, slot) trace_put(wave8, step, slot, __builtin_amdgcn_s_memtime())
+#define TRACE_V(wave8, step, slot, v) trace_put(wave8, step, slot, (unsigned long long)(v))
+#else
+#define TRACE_T(wave8, step, slot)
+#define TRACE_V(wave8, step, slot, v)
+#endif
 
 // item i of this thread: CONTIG_K: row = f>>3, k = 4*(f&7);  else: row = f&127, k = 4*(f>>7)
 template <bool CONTIG_K>
@@ -73,28 +96,30 @@ struct ItemLoader {
     }
 
     __device__ __forceinline__ void load(int k0, float4 (&r)[4]) const {
-        const bool full = k0 + BK <= K;                     // workgroup-uniform
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = k0 + kk[i];
-            if constexpr (CONTIG_K) {
-                if (K >= 4) {
-                    r[i] = *reinterpret_cast<const float4*>(base[i] + (full ? k : min(k, K - 4)));
-                } else {
-                    const float* p = base[i];
-                    r[i] = make_float4(p[min(k, K - 1)], p[min(k + 1, K - 1)], p[min(k + 2, K - 1)], p[min(k + 3, K - 1)]);
-                }
+        for (int i = 0; i < 4; ++i) load_item(i, k0, r[i]);
+    }
+
+    __device__ __forceinline__ void load_item(int i, int k0, float4& r) const {
+        const bool full = k0 + BK <= K;                     // workgroup-uniform
+        const int k = k0 + kk[i];
+        if constexpr (CONTIG_K) {
+            if (K >= 4) {
+                r = *reinterpret_cast<const float4*>(base[i] + (full ? k : min(k, K - 4)));
             } else {
-                if (full) {
-                    const float* p = base[i] + (size_t)k * ld;
-                    r[i] = make_float4(p[0], p[ld], p[2 * ld], p[3 * ld]);
-                } else {
-                    const float* p = base[i];
-                    r[i].x = p[(size_t)min(k, K - 1) * ld];
-                    r[i].y = p[(size_t)min(k + 1, K - 1) * ld];
-                    r[i].z = p[(size_t)min(k + 2, K - 1) * ld];
-                    r[i].w = p[(size_t)min(k + 3, K - 1) * ld];
-                }
+                const float* p = base[i];
+                r = make_float4(p[min(k, K - 1)], p[min(k + 1, K - 1)], p[min(k + 2, K - 1)], p[min(k + 3, K - 1)]);
+            }
+        } else {
+            if (full) {
+                const float* p = base[i] + (size_t)k * ld;
+                r = make_float4(p[0], p[ld], p[2 * ld], p[3 * ld]);
+            } else {
+                const float* p = base[i];
+                r.x = p[(size_t)min(k, K - 1) * ld];
+                r.y = p[(size_t)min(k + 1, K - 1) * ld];
+                r.z = p[(size_t)min(k + 2, K - 1) * ld];
+                r.w = p[(size_t)min(k + 3, K - 1) * ld];
             }
         }
     }
@@ -105,6 +130,26 @@ __device__ __forceinline__ uint2 pack4(bf16x2 lo, bf16x2 hi) {
     u.x = __builtin_bit_cast(unsigned, lo);
     u.y = __builtin_bit_cast(unsigned, hi);
     return u;
+}
+
+// Out-of-range fix-up of one clamped item (see ItemLoader::load_item): (row, k) are the item's coordinates
+// inside the tile.
+template <bool CONTIG_K>
+__device__ __forceinline__ float4 fix_item(float4 v, int rows, int K, int row0, int k0, int row, int k) {
+    const int kg = k0 + k;
+    if constexpr (CONTIG_K) {
+        if (K >= 4 && kg > K - 4 && kg < K) {      // the float4 was loaded from K-4: shift it back
+            const int d = kg - (K - 4);
+            v = d == 1 ? make_float4(v.y, v.z, v.w, 0.f) : d == 2 ? make_float4(v.z, v.w, 0.f, 0.f)
+                                                                 : make_float4(v.w, 0.f, 0.f, 0.f);
+        }
+    }
+    const bool rok = row0 + row < rows;
+    if (!rok || kg >= K) v.x = 0.f;
+    if (!rok || kg + 1 >= K) v.y = 0.f;
+    if (!rok || kg + 2 >= K) v.z = 0.f;
+    if (!rok || kg + 3 >= K) v.w = 0.f;
+    return v;
 }
 
 // registers -> three bf16 planes in LDS.  EDGE (workgroup-uniform: the tile touches the end of the matrix
@@ -118,21 +163,7 @@ __device__ __forceinline__ void store_items(__bf16* __restrict__ S, int rows, in
         int row, k;
         item_pos<CONTIG_K>(tid + THREADS * i, row, k);
         float4 v = r[i];
-        if constexpr (EDGE) {
-            const int kg = k0 + k;
-            if constexpr (CONTIG_K) {
-                if (K >= 4 && kg > K - 4 && kg < K) {      // the float4 was loaded from K-4: shift it back
-                    const int d = kg - (K - 4);
-                    v = d == 1 ? make_float4(v.y, v.z, v.w, 0.f) : d == 2 ? make_float4(v.z, v.w, 0.f, 0.f)
-                                                                         : make_float4(v.w, 0.f, 0.f, 0.f);
-                }
-            }
-            const bool rok = row0 + row < rows;
-            if (!rok || kg >= K) v.x = 0.f;
-            if (!rok || kg + 1 >= K) v.y = 0.f;
-            if (!rok || kg + 2 >= K) v.z = 0.f;
-            if (!rok || kg + 3 >= K) v.w = 0.f;
-        }
+        if constexpr (EDGE) v = fix_item<CONTIG_K>(v, rows, K, row0, k0, row, k);
         f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
         __bf16* dst = S + row * LDS_ROW + k;
 #pragma unroll
@@ -146,6 +177,66 @@ __device__ __forceinline__ void store_items(__bf16* __restrict__ S, int rows, in
             }
         }
     }
+}
+
+
+// One 128x128x32 tile step of a wave: 24 fragment reads (ds_read_b128) and 48 MFMAs.
+__device__ __forceinline__ void mfma_tile(const __bf16* __restrict__ sA, const __bf16* __restrict__ sB, int arow,
+                                          int brow, int ksel, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int slab = 0; slab < 2; ++slab) {
+        const int ko = slab * 16 + ksel;
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[t][p] = *reinterpret_cast<const bf16x8*>(&sA[p * PLANE + arow + t * 32 * LDS_ROW + ko]);
+                b[t][p] = *reinterpret_cast<const bf16x8*>(&sB[p * PLANE + brow + t * 32 * LDS_ROW + ko]);
+            }
+        // six term pairs, smallest first; consecutive MFMAs go to DIFFERENT accumulators so that none
+        // waits on the previous one's result
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+        constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+    }
+}
+
+// accumulators -> C (or the split-K partial plane).  C/D layout of the 32x32 MFMA: col = lane & 31,
+// row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ void store_tile(const SplitArgs& g, int m0, int n0, int z, int wm, int wn, int lane,
+                                           const f32x16 (&acc)[2][2]) {
+    const bool split = g.split_k > 1;
+    float* Cout = split ? g.partial + (size_t)z * g.M * g.N : g.C;
+    const int ldo = split ? g.N : g.ldc;
+    const int half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= g.N) continue;
+            const float bv = (!split && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < g.M) {
+                    float* p = Cout + (size_t)row * ldo + col;
+                    if (split) *p = acc[i][j][r];
+                    else {
+                        float v = g.alpha * acc[i][j][r] + bv;
+                        if (g.beta != 0.f) v += g.beta * (*p);
+                        *p = v;
+                    }
+                }
+            }
+        }
 }
 
 template <bool TA, bool TB>
@@ -185,69 +276,307 @@ __global__ __launch_bounds__(THREADS) void gemm_split_kernel(SplitArgs g) {
     const int brow = (wn * 64 + (lane & 31)) * LDS_ROW;
     const int ksel = (lane >> 5) * 8;
 
+    TRACE_V(wave, TRACE_STEPS - 1, 0, __builtin_amdgcn_s_getreg((31 << 11) | 4));      // HW_ID
+    TRACE_V(wave, TRACE_STEPS - 1, 1, __builtin_amdgcn_s_getreg((31 << 11) | 20));     // XCC_ID
     for (int kt = kt0; kt < kt1; ++kt) {
         __syncthreads();                               // previous tile fully consumed
+        TRACE_T(wave, kt - kt0, 0);
         const bool k_edge = (kt + 1) * BK > g.K;
         if (a_edge || k_edge) store_items<A_CK, true>(sA, g.M, g.K, m0, kt * BK, tid, ra);
         else store_items<A_CK, false>(sA, g.M, g.K, m0, kt * BK, tid, ra);
         if (b_edge || k_edge) store_items<B_CK, true>(sB, g.N, g.K, n0, kt * BK, tid, rb);
         else store_items<B_CK, false>(sB, g.N, g.K, n0, kt * BK, tid, rb);
+        TRACE_T(wave, kt - kt0, 1);
         __syncthreads();
+        TRACE_T(wave, kt - kt0, 2);
         if (kt + 1 < kt1) {                            // next tile's global loads fly during the MFMAs
             la.load((kt + 1) * BK, ra);
             lb.load((kt + 1) * BK, rb);
         }
+        mfma_tile(sA, sB, arow, brow, ksel, acc);
+        TRACE_T(wave, kt - kt0, 3);
+    }
+
+    store_tile(g, m0, n0, z, wm, wn, lane, acc);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// FUSED variant: every wave runs its MFMAs and the split of the NEXT k-tile in ONE instruction stream.
+//
+// Measured on MI355X (tools/mfma_probe.hip, tools/fill_probe.hip; shader cycles per 128x128x32 k-tile):
+//   48 v_mfma_f32_32x32x16_bf16 of one wave                       1536   (32.0 each, any accumulator order)
+//   ... plus its 24 ds_read_b128                                  1697
+//   split of a k-tile (8 items/thread) + LDS stores, alone        1114
+//   the same split as a SECOND wave beside an MFMA wave           2657   (s_setprio changes nothing)
+//   free in a 32-cycle MFMA shadow of the same wave: ~4 plain VALU, 2 ds_read_b128; v_cvt_pk_bf16_f32 counts
+//   double, v_pk_add_f32 and ds_write_b64 do not overlap at all (the LDS store path moves ~85 B/clk/CU: the
+//   48 KB of planes of one k-tile cost ~650 cycles whichever wave issues them)
+// so neither two independent workgroups per CU (gemm_split_kernel: both drift into lockstep, 3300 cycles per
+// k-tile and CU) nor barrier-anti-phased halves (tried: 3650) hide the split behind the matrix pipe.  Here each
+// of the 48 MFMAs of a k-step is followed by one "micro-step" of the split (4 independent plain VALU, at times
+// one ds_write_b64 / ds_read_b128 / global load), the order pinned with sched_barrier: 2540 cycles per k-tile
+// (1623 without the split; the LDS stores are ~650 of the difference).
+//
+// LDS is double buffered (2 x 61 440 B, one 4-wave workgroup per CU) with ONE barrier per k-tile, and the
+// k-loop is rotated by half a tile so that no MFMA waits for LDS after the barrier:
+//     barrier(kt): tile kt visible in buf[kt&1]; every wave holds slab 1 of tile kt-1 in registers (F1)
+//       reads  F0 <- slab 0 of tile kt                   (first 4 up front, 8 in the first MFMA shadows)
+//       MFMAs   0..23 : slab 1 of tile kt-1 (F1)         | split micro-steps 0..23 of tile kt+1 -> buf[~kt&1]
+//       MFMAs  24..47 : slab 0 of tile kt   (F0)         | micro-steps 24..47, reads F1 <- slab 1 of tile kt
+//     (buf[~kt&1] held tile kt-1, whose last reads -- F1 -- completed before barrier(kt) in every wave)
+// The global loads of tile kt+2 are issued from the micro-steps that free their registers.
+// Loader of the fused kernel: every item's address is  UNIFORM tile base (SGPRs, advanced per k-tile by the
+// scalar unit) + a per-lane 32-bit element offset computed once (global_load saddr form: no VALU address math
+// in the k-loop).  Requires rows * ld < 2^31 elements and, for CONTIG_K, K >= 4 (checked on the host).
+template <bool CONTIG_K>
+struct TileLoader {
+    const float* P;
+    int off[4];                // CONTIG_K: row * ld + kk       else: row + kk * ld
+    int rowc[4], kk[4];        // clamped row / k offset inside a tile (for the partial last k-tile)
+    int ld, K;
+
+    __device__ __forceinline__ void init(const float* P_, int ld_, int rows, int K_, int row0, int tid) {
+        P = P_; ld = ld_; K = K_;
 #pragma unroll
-        for (int slab = 0; slab < 2; ++slab) {
-            const int ko = slab * 16 + ksel;
-            bf16x8 a[2][3], b[2][3];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    a[t][p] = *reinterpret_cast<const bf16x8*>(&sA[p * PLANE + arow + t * 32 * LDS_ROW + ko]);
-                    b[t][p] = *reinterpret_cast<const bf16x8*>(&sB[p * PLANE + brow + t * 32 * LDS_ROW + ko]);
-                }
-            // six term pairs, smallest first; consecutive MFMAs go to DIFFERENT accumulators so that none
-            // waits on the previous one's result
-            constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-            constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            int row, k;
+            item_pos<CONTIG_K>(tid + THREADS * i, row, k);
+            row = min(row0 + row, rows - 1);
+            rowc[i] = row;
+            kk[i] = k;
+            off[i] = CONTIG_K ? row * ld + k : row + k * ld;
         }
     }
 
-    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const bool split = g.split_k > 1;
-    float* Cout = split ? g.partial + (size_t)z * g.M * g.N : g.C;
-    const int ldo = split ? g.N : g.ldc;
-    const int half = lane >> 5;
+    template <bool FAST>
+    __device__ __forceinline__ void load_item(int i, int k0, float4& r) const {
+        if (FAST || k0 + BK <= K) {                         // workgroup-uniform: all but the last partial tile
+            if constexpr (CONTIG_K) {
+                r = *reinterpret_cast<const float4*>(P + k0 + off[i]);
+            } else {
+                const float* t0 = P + (size_t)k0 * ld;
+                r = make_float4(t0[off[i]], (t0 + ld)[off[i]], (t0 + 2 * (size_t)ld)[off[i]],
+                                (t0 + 3 * (size_t)ld)[off[i]]);
+            }
+        } else {
+            const int k = k0 + kk[i];
+            if constexpr (CONTIG_K) {
+                r = *reinterpret_cast<const float4*>(P + (size_t)rowc[i] * ld + min(k, K - 4));
+            } else {
+                const float* p = P + rowc[i];
+                r.x = p[(size_t)min(k, K - 1) * ld];
+                r.y = p[(size_t)min(k + 1, K - 1) * ld];
+                r.z = p[(size_t)min(k + 2, K - 1) * ld];
+                r.w = p[(size_t)min(k + 3, K - 1) * ld];
+            }
+        }
+    }
+
+    __device__ __forceinline__ void load(int k0, float4 (&r)[4]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_item<false>(i, k0, r[i]);
+    }
+};
+
+constexpr int BUF = 6 * PLANE;                              // bf16 per buffer: A planes, then B planes
+constexpr size_t FUSED_LDS = (size_t)2 * BUF * sizeof(__bf16);
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct SplitState {
+    float x[4];          // the item, then its residuals
+    bf16x2 blo, bhi;     // the bf16 terms just split off (pairs x[0..1], x[2..3])
+};
+
+__device__ __forceinline__ float bf16_lo_as_f32(bf16x2 b) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) << 16);
+}
+__device__ __forceinline__ float bf16_hi_as_f32(bf16x2 b) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xffff0000u);
+}
+__device__ __forceinline__ bf16x2 rne_pair(float lo, float hi) {          // v_cvt_pk_bf16_f32
+    return __builtin_convertvector(f32x2{lo, hi}, bf16x2);
+}
+
+// Micro-step ST (0..5) of one item: the SAME three round-to-nearest terms as store_items (both kernels feed
+// the matrix cores identical planes), cut into pieces that issue beside an MFMA (tools/fill_probe.hip: ~4 plain
+// VALU per 32-cycle shadow; v_cvt_pk_bf16_f32 counts double; v_pk_add_f32 does not overlap at all, hence the
+// scalar subtractions); dependent instructions sit in different steps.
+template <int ST>
+__device__ __forceinline__ void split_step(SplitState& t, __bf16* dst) {
+    if constexpr (ST == 0) {
+        t.blo = rne_pair(t.x[0], t.x[1]);
+        t.bhi = rne_pair(t.x[2], t.x[3]);
+        *reinterpret_cast<uint2*>(dst) = pack4(t.blo, t.bhi);
+    } else if constexpr (ST == 1) {
+        t.x[0] -= bf16_lo_as_f32(t.blo);
+        t.x[1] -= bf16_hi_as_f32(t.blo);
+    } else if constexpr (ST == 2) {
+        t.x[2] -= bf16_lo_as_f32(t.bhi);
+        t.x[3] -= bf16_hi_as_f32(t.bhi);
+    } else if constexpr (ST == 3) {
+        t.blo = rne_pair(t.x[0], t.x[1]);
+        t.bhi = rne_pair(t.x[2], t.x[3]);
+        *reinterpret_cast<uint2*>(dst + PLANE) = pack4(t.blo, t.bhi);
+    } else if constexpr (ST == 4) {
+        t.x[0] -= bf16_lo_as_f32(t.blo);
+        t.x[1] -= bf16_hi_as_f32(t.blo);
+        t.x[2] -= bf16_lo_as_f32(t.bhi);
+        t.x[3] -= bf16_hi_as_f32(t.bhi);
+    } else {
+        *reinterpret_cast<uint2*>(dst + 2 * PLANE) = pack4(rne_pair(t.x[0], t.x[1]), rne_pair(t.x[2], t.x[3]));
+    }
+}
+
+template <bool TA, bool TB>
+struct FusedCtx {
+    static constexpr bool A_CK = !TA, B_CK = TB;
+    TileLoader<A_CK> la;
+    TileLoader<B_CK> lb;
+    float4 ra[4], rb[4];                 // fp32 items of the tile being split next
+    bf16x8 F0[12], F1[12];               // fragments: index = operand + 2 * t + 4 * plane
+    SplitState st;
+    int M, N, K, m0, n0, tid;
+    int frag_a, frag_b;                  // element offsets of this lane's fragment rows inside a plane
+    bool a_edge, b_edge;
+
+    // item `it` (0..7): operand it&1 (0 = A), slot it>>1
+    // FAST: the tile being split needs no out-of-range fix-up and the tile being loaded is a full one
+    template <int IT, bool FAST>
+    __device__ __forceinline__ void item_begin(int k0_tile, int k0_next, __bf16* wbuf, __bf16*& dst) {
+        constexpr int i = IT >> 1;
+        int row, k;
+        float4 v;
+        if constexpr ((IT & 1) == 0) {
+            item_pos<A_CK>(tid + THREADS * i, row, k);
+            v = ra[i];
+            if (!FAST && (a_edge || k0_tile + BK > K)) v = fix_item<A_CK>(v, M, K, m0, k0_tile, row, k);
+            dst = wbuf + row * LDS_ROW + k;
+        } else {
+            item_pos<B_CK>(tid + THREADS * i, row, k);
+            v = rb[i];
+            if (!FAST && (b_edge || k0_tile + BK > K)) v = fix_item<B_CK>(v, N, K, n0, k0_tile, row, k);
+            dst = wbuf + 3 * PLANE + row * LDS_ROW + k;
+        }
+        st.x[0] = v.x; st.x[1] = v.y; st.x[2] = v.z; st.x[3] = v.w;
+        if constexpr ((IT & 1) == 0) la.template load_item<FAST>(i, k0_next, ra[i]);      // the register is free again
+        else lb.template load_item<FAST>(i, k0_next, rb[i]);
+    }
+
+    template <int FR>
+    __device__ __forceinline__ void read_frag(bf16x8 (&F)[12], const __bf16* rbuf, int slab) {
+        constexpr int op = FR & 1, t = (FR >> 1) & 1, p = FR >> 2;
+        const __bf16* base = rbuf + (op ? 3 * PLANE + frag_b : frag_a);
+        F[FR] = *reinterpret_cast<const bf16x8*>(base + p * PLANE + t * 32 * LDS_ROW + slab * 16);
+    }
+};
+
+template <int W>
+__device__ __forceinline__ void mfma_w(const bf16x8 (&F)[12], f32x16 (&acc)[2][2]) {
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    constexpr int q = W >> 2, i = (W >> 1) & 1, j = W & 1;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[2 * i + 4 * PA[q]], F[1 + 2 * j + 4 * PB[q]], acc[i][j], 0, 0, 0);
+}
+
+// one rotated k-step (see the header comment).  WITH_OLD: slab 1 of the previous tile is pending in F1;
+// WITH_CONV: there is a next tile to split.
+template <bool TA, bool TB, bool WITH_OLD, bool WITH_CONV, bool FAST>
+__device__ __forceinline__ void fused_step(FusedCtx<TA, TB>& c, f32x16 (&acc)[2][2], const __bf16* rbuf,
+                                           __bf16* wbuf, int k0_tile, int k0_next) {
+    static_for<0, 4>([&](auto fr) { c.template read_frag<fr.value>(c.F0, rbuf, 0); });
+    __bf16* dst = nullptr;
+    static_for<0, 48>([&](auto gc) {
+        constexpr int g = gc.value;
+        if constexpr (g < 24) {
+            if constexpr (WITH_OLD) mfma_w<g>(c.F1, acc);
+        } else {
+            mfma_w<g - 24>(c.F0, acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g < 8) c.template read_frag<4 + g>(c.F0, rbuf, 0);
+        if constexpr (g >= 24 && g < 36) c.template read_frag<g - 24>(c.F1, rbuf, 1);
+        if constexpr (WITH_CONV) {
+            constexpr int it = g / 6, stp = g % 6;
+            if constexpr (stp == 0) c.template item_begin<it, FAST>(k0_tile, k0_next, wbuf, dst);
+            split_step<stp>(c.st, dst);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(THREADS) void gemm_split_fused_kernel(SplitArgs g) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem[];           // [2][A planes | B planes]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+    const int kt0 = z * g.k_tiles_per_split;
+    const int kt_total = (g.K + BK - 1) / BK;
+    const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
+
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            if (col >= g.N) continue;
-            const float bv = (!split && g.bias) ? g.bias[col] : 0.f;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < g.M) {
-                    float* p = Cout + (size_t)row * ldo + col;
-                    if (split) *p = acc[i][j][r];
-                    else {
-                        float v = g.alpha * acc[i][j][r] + bv;
-                        if (g.beta != 0.f) v += g.beta * (*p);
-                        *p = v;
-                    }
-                }
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt0 < kt1) {
+        FusedCtx<TA, TB> c;
+        c.M = g.M; c.N = g.N; c.K = g.K; c.m0 = m0; c.n0 = n0; c.tid = tid;
+        c.a_edge = m0 + BM > g.M;
+        c.b_edge = n0 + BN > g.N;
+        c.frag_a = (wm * 64 + (lane & 31)) * LDS_ROW + (lane >> 5) * 8;
+        c.frag_b = (wn * 64 + (lane & 31)) * LDS_ROW + (lane >> 5) * 8;
+        c.la.init(g.A, g.lda, g.M, g.K, m0, tid);
+        c.lb.init(g.B, g.ldb, g.N, g.K, n0, tid);
+        c.la.load(kt0 * BK, c.ra);
+        c.lb.load(kt0 * BK, c.rb);
+        // prologue: split tile kt0 into buffer 0 (nothing to overlap it with), loads of tile kt0+1
+        {
+            const int k0_next = min(kt0 + 1, kt1 - 1) * BK;
+            __bf16* dst = nullptr;
+            static_for<0, 48>([&](auto gc) {
+                constexpr int it = gc.value / 6, stp = gc.value % 6;
+                if constexpr (stp == 0) c.template item_begin<it, false>(kt0 * BK, k0_next, smem, dst);
+                split_step<stp>(c.st, dst);
+            });
         }
+        __syncthreads();
+        // the loop is peeled so that its body is ONE straight-line variant (accumulators stay in place)
+        auto step = [&](int kt, auto with_old, auto with_conv, auto fast) {
+            const int cur = (kt - kt0) & 1;
+            const int k0_tile = (kt + 1) * BK;                        // the tile being split in this step
+            const int k0_next = min(kt + 2, kt1 - 1) * BK;            // the tile being loaded (clamped, harmless)
+            fused_step<TA, TB, with_old.value, with_conv.value, fast.value>(
+                c, acc, smem + cur * BUF, smem + (cur ^ 1) * BUF, k0_tile, k0_next);
+            __syncthreads();
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        if (kt0 + 1 < kt1) {
+            step(kt0, F{}, T{}, F{});
+            int kt = kt0 + 1;
+            if (!c.a_edge && !c.b_edge)          // interior tile: steady state without any edge handling
+                for (; kt < kt1 - 1 && (min(kt + 2, kt1 - 1) + 1) * BK <= g.K; ++kt) step(kt, T{}, T{}, T{});
+            for (; kt < kt1 - 1; ++kt) step(kt, T{}, T{}, F{});
+            step(kt1 - 1, T{}, F{}, F{});
+        } else {
+            step(kt0, F{}, F{}, F{});
+        }
+        static_for<0, 24>([&](auto w) { mfma_w<w.value>(c.F1, acc); });     // slab 1 of the last tile
+    }
+    store_tile(g, m0, n0, z, wm, wn, lane, acc);
 }
 
 __global__ __launch_bounds__(256) void split_reduce_kernel(const float* __restrict__ partial, int split_k,
@@ -267,9 +596,46 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(const float* __restri
     }
 }
 
+
+template <bool TA, bool TB>
+int launch_fused(const SplitArgs& g, dim3 grid, hipStream_t st) {
+    static bool attr_set = false;      // benign race: the attribute is idempotent
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_split_fused_kernel<TA, TB>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_split_fused_kernel<TA, TB>), grid, dim3(THREADS), FUSED_LDS, st, g);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+// Which k-loop: the fused kernel (one workgroup per CU, 122.9 KB LDS) when the whole grid fits in ONE round of
+// 256 workgroups -- there a lone workgroup finishes a k-tile in ~2500 cycles against ~3900 for the two-phase
+// kernel (MI355X: 51 vs 35 TFLOP/s on a 64-tile problem, 155 vs 126 on 256 tiles) -- and the two-phase kernel
+// with two co-resident workgroups per CU beyond that, where its second workgroup covers the prologue, the
+// C-store epilogue and the barrier waits of the first (short K loops: 133 vs 117 TFLOP/s on the 1440-tile
+// K=600 logits GEMM).  RENET_GEMM_KERNEL=fused|split forces one of them (tools/gemm_bench.py).
+int kernel_choice(int ntiles) {
+    static int forced = -2;
+    if (forced == -2) {
+        const char* e = getenv("RENET_GEMM_KERNEL");
+        forced = !e ? -1 : e[0] == 's' ? 1 : e[0] == 'f' ? 0 : -1;
+    }
+    if (forced >= 0) return forced;
+    return ntiles <= 256 ? 0 : 1;
+}
+
 }  // namespace
 
 extern "C" {
+
+#ifdef RENET_GEMM_TRACE
+int renet_gemm_trace_set(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf));
+}
+#endif
 
 int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
                          const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
@@ -287,11 +653,27 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
     g.k_tiles_per_split = max(1, (kt_total + split_k - 1) / split_k);
     g.partial = workspace;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, split_k);
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_split_kernel<false, false>), grid, dim3(THREADS), 0, st, g);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_split_kernel<false, true>), grid, dim3(THREADS), 0, st, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_split_kernel<true, false>), grid, dim3(THREADS), 0, st, g);
-    else hipLaunchKernelGGL((gemm_split_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
+    const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
+    const int ntiles = nbx * nby * split_k;
+    int choice = kernel_choice(ntiles);
+    // the fused kernel addresses with 32-bit element offsets and float4 loads along a contiguous K
+    if (choice == 0 && (K < 4 || (size_t)(ta ? K : M) * lda >= (1u << 31) || (size_t)(tb ? N : K) * ldb >= (1u << 31)))
+        choice = 1;
+    int e = RENET_OK;
+    if (choice == 0) {
+        dim3 grid(nbx, nby, split_k);
+        if (!ta && !tb) e = launch_fused<false, false>(g, grid, st);
+        else if (!ta && tb) e = launch_fused<false, true>(g, grid, st);
+        else if (ta && !tb) e = launch_fused<true, false>(g, grid, st);
+        else e = launch_fused<true, true>(g, grid, st);
+    } else {
+        dim3 grid(nbx, nby, split_k);
+        if (!ta && !tb) hipLaunchKernelGGL((gemm_split_kernel<false, false>), grid, dim3(THREADS), 0, st, g);
+        else if (!ta && tb) hipLaunchKernelGGL((gemm_split_kernel<false, true>), grid, dim3(THREADS), 0, st, g);
+        else if (ta && !tb) hipLaunchKernelGGL((gemm_split_kernel<true, false>), grid, dim3(THREADS), 0, st, g);
+        else hipLaunchKernelGGL((gemm_split_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
+    }
+    if (e != RENET_OK) return e;
     RENET_LAUNCH_CHECK();
     if (split_k > 1) {
         const size_t total = (size_t)M * N;

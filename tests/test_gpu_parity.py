@@ -4,6 +4,8 @@
   (c) size-independent properties at BASELINE.json's full sizes.
 Tolerances are fp32: the kernels sum in a different order than torch-CPU / the reference.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -43,6 +45,40 @@ def test_gemm_matches_fp64(dev, m, n, k, ta, tb, mode):
     ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64) + bias
     out = K.gemm(_to(a, dev), _to(b, dev), ta=bool(ta), tb=bool(tb), bias=_to(bias, dev), mode=mode)
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * max(1, k) ** 0.5)
+
+
+_GEMM_KERNEL_CHECK = r'''
+import sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import renet_hip as K
+dev = torch.device('cuda:0')
+rng = np.random.RandomState(11)
+# (m, n, k, ta, tb, split_k): ragged edges in every dimension, K < one tile, one k-tile, two, many; split-K
+for m, n, k, ta, tb, sk in [(1, 1, 4, 0, 1, 1), (130, 257, 31, 0, 1, 1), (130, 257, 33, 0, 0, 1), (300, 129, 64, 1, 0, 1),
+                            (257, 130, 71, 1, 1, 1), (64, 600, 200, 0, 1, 1), (1024, 777, 600, 0, 0, 1),
+                            (96, 100, 5000, 1, 0, 7), (2500, 2300, 96, 0, 1, 1), (200, 200, 4097, 1, 0, 3)]:
+    a = rng.uniform(-1, 1, (k, m) if ta else (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, k) if tb else (k, n)).astype(np.float32)
+    ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+    out = K.gemm(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), ta=bool(ta), tb=bool(tb), split_k=sk,
+                 mode='bf16x6')
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * max(1, k) ** 0.5)
+print('ok')
+'''
+
+
+@pytest.mark.parametrize('kernel', ['fused', 'split'])
+def test_gemm_both_k_loop_structures(dev, kernel):
+    """The bf16x6 GEMM has two k-loop structures (gemm_split.hip) picked by grid size; force each one over
+    shapes on both sides of that threshold."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RENET_GEMM_KERNEL=kernel)
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 're-net_amd')
+    r = subprocess.run([sys.executable, '-c', _GEMM_KERNEL_CHECK, pkg], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
 
 
 def test_gemm_splitk_beta_and_strided_views(dev):
