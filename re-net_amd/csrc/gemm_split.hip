@@ -66,19 +66,20 @@ __device__ __forceinline__ void trace_put(int wave8, int step, int slot, unsigne
 #define TRACE_V(wave8, step, slot, v)
 #endif
 
-// item i of this thread: CONTIG_K: row = f>>3, k = 4*(f&7);  else: row = f&127, k = 4*(f>>7)
-template <bool CONTIG_K>
+// item i of this thread (f = tid + threads * i) of a ROWS x 32 operand tile:
+//   CONTIG_K: row = f>>3, k = 4*(f&7);  else: row = f % ROWS, k = 4*(f / ROWS)
+template <bool CONTIG_K, int ROWS = 128>
 __device__ __forceinline__ void item_pos(int f, int& row, int& k) {
     if constexpr (CONTIG_K) { row = f >> 3; k = (f & 7) << 2; }
-    else { row = f & 127; k = (f >> 7) << 2; }
+    else { row = f & (ROWS - 1); k = (f / ROWS) << 2; }
 }
 
 // Per-thread load state: the row part of every item's address is computed ONCE (the per-tile work is an
 // add); integer multiplies inside the k loop cost more issue slots than the MFMAs they feed.
-template <bool CONTIG_K>
+template <bool CONTIG_K, int NT = 256, int ROWS = 128, int NI = 4>
 struct ItemLoader {
-    const float* base[4];      // CONTIG_K: P + row*ld          else: P + row
-    int kk[4];                 // k offset of the item inside a tile
+    const float* base[NI];     // CONTIG_K: P + row*ld          else: P + row
+    int kk[NI];                // k offset of the item inside a tile
     size_t ld;
     int K;
 
@@ -86,18 +87,18 @@ struct ItemLoader {
         ld = (size_t)ld_;
         K = K_;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             int row, k;
-            item_pos<CONTIG_K>(tid + THREADS * i, row, k);
+            item_pos<CONTIG_K, ROWS>(tid + NT * i, row, k);
             row = min(row0 + row, rows - 1);
             kk[i] = k;
             base[i] = CONTIG_K ? P + (size_t)row * ld : P + row;
         }
     }
 
-    __device__ __forceinline__ void load(int k0, float4 (&r)[4]) const {
+    __device__ __forceinline__ void load(int k0, float4 (&r)[NI]) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load_item(i, k0, r[i]);
+        for (int i = 0; i < NI; ++i) load_item(i, k0, r[i]);
     }
 
     __device__ __forceinline__ void load_item(int i, int k0, float4& r) const {
@@ -155,13 +156,14 @@ __device__ __forceinline__ float4 fix_item(float4 v, int rows, int K, int row0, 
 // registers -> three bf16 planes in LDS.  EDGE (workgroup-uniform: the tile touches the end of the matrix
 // in either dimension) enables the out-of-range fix-up of the clamped loads; interior tiles -- almost all of
 // them -- run the bare split: 6 v_cvt_pk_bf16_f32, 4 packed subtractions and 3 ds_write_b64 per item.
-template <bool CONTIG_K, bool EDGE>
+template <bool CONTIG_K, bool EDGE, int NT = 256, int ROWS = 128, int NI = 4>
 __device__ __forceinline__ void store_items(__bf16* __restrict__ S, int rows, int K, int row0, int k0, int tid,
-                                            const float4 (&r)[4]) {
+                                            const float4 (&r)[NI]) {
+    constexpr int PLANE = ROWS * LDS_ROW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         int row, k;
-        item_pos<CONTIG_K>(tid + THREADS * i, row, k);
+        item_pos<CONTIG_K, ROWS>(tid + NT * i, row, k);
         float4 v = r[i];
         if constexpr (EDGE) v = fix_item<CONTIG_K>(v, rows, K, row0, k0, row, k);
         f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
@@ -181,6 +183,7 @@ __device__ __forceinline__ void store_items(__bf16* __restrict__ S, int rows, in
 
 
 // One 128x128x32 tile step of a wave: 24 fragment reads (ds_read_b128) and 48 MFMAs.
+template <int PLANE_A = PLANE, int PLANE_B = PLANE>
 __device__ __forceinline__ void mfma_tile(const __bf16* __restrict__ sA, const __bf16* __restrict__ sB, int arow,
                                           int brow, int ksel, f32x16 (&acc)[2][2]) {
 #pragma unroll
@@ -191,8 +194,8 @@ __device__ __forceinline__ void mfma_tile(const __bf16* __restrict__ sA, const _
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                a[t][p] = *reinterpret_cast<const bf16x8*>(&sA[p * PLANE + arow + t * 32 * LDS_ROW + ko]);
-                b[t][p] = *reinterpret_cast<const bf16x8*>(&sB[p * PLANE + brow + t * 32 * LDS_ROW + ko]);
+                a[t][p] = *reinterpret_cast<const bf16x8*>(&sA[p * PLANE_A + arow + t * 32 * LDS_ROW + ko]);
+                b[t][p] = *reinterpret_cast<const bf16x8*>(&sB[p * PLANE_B + brow + t * 32 * LDS_ROW + ko]);
             }
         // six term pairs, smallest first; consecutive MFMAs go to DIFFERENT accumulators so that none
         // waits on the previous one's result
@@ -206,6 +209,48 @@ __device__ __forceinline__ void mfma_tile(const __bf16* __restrict__ sA, const _
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
     }
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// The MFMA phase of the two-phase kernels with the NEXT tile's global loads spread over it: issued in one
+// burst right after the barrier (8 x 1 KB per wave, every wave of the CU at once) they fill the vector-memory
+// queue -- the texture-address unit takes 64 B/clk, 16 cycles per dwordx4 wave-instruction -- and the waves
+// sit in the load issue for ~1000-1500 cycles before their first MFMA (tools/gemm_trace.py).  Order pinned with
+// sched_barrier: slab-0 fragments, then 48 MFMAs with the slab-1 fragment reads behind the first 12 and one
+// load piece behind every fifth.
+template <int PLANE_A, int PLANE_B, int NPIECES, class LoadFn>
+__device__ __forceinline__ void mfma_tile_ld(const __bf16* __restrict__ sA, const __bf16* __restrict__ sB, int arow,
+                                             int brow, int ksel, f32x16 (&acc)[2][2], LoadFn&& load_piece) {
+    bf16x8 F0[12], F1[12];                       // index = operand + 2 * t + 4 * plane
+    auto read = [&](auto frc, bf16x8 (&F)[12], int slab) {
+        constexpr int fr = frc.value, op = fr & 1, t = (fr >> 1) & 1, p = fr >> 2;
+        const __bf16* base = op ? sB + p * PLANE_B + brow : sA + p * PLANE_A + arow;
+        F[fr] = *reinterpret_cast<const bf16x8*>(base + t * 32 * LDS_ROW + slab * 16 + ksel);
+    };
+    // in the order the term pairs consume them (lgkmcnt retires LDS reads in order: the first MFMA waits for
+    // two fragments, not twelve)
+    constexpr int ORDER[12] = {8, 1, 3, 10, 4, 5, 7, 6, 0, 9, 11, 2};
+    static_for<0, 12>([&](auto n) { read(std::integral_constant<int, ORDER[n.value]>{}, F0, 0); });
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    static_for<0, 48>([&](auto gc) {
+        constexpr int g = gc.value, w = g % 24, q = w >> 2, i = (w >> 1) & 1, j = w & 1;
+        if constexpr (g < 24)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F0[2 * i + 4 * PA[q]], F0[1 + 2 * j + 4 * PB[q]], acc[i][j], 0, 0, 0);
+        else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F1[2 * i + 4 * PA[q]], F1[1 + 2 * j + 4 * PB[q]], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g < 12) read(std::integral_constant<int, ORDER[g]>{}, F1, 1);
+        if constexpr (g % 5 == 2 && g / 5 < NPIECES) load_piece(std::integral_constant<int, g / 5>{});
+        __builtin_amdgcn_sched_barrier(0);
+    });
 }
 
 // accumulators -> C (or the split-K partial plane).  C/D layout of the 32x32 MFMA: col = lane & 31,
@@ -289,11 +334,12 @@ __global__ __launch_bounds__(THREADS) void gemm_split_kernel(SplitArgs g) {
         TRACE_T(wave, kt - kt0, 1);
         __syncthreads();
         TRACE_T(wave, kt - kt0, 2);
-        if (kt + 1 < kt1) {                            // next tile's global loads fly during the MFMAs
-            la.load((kt + 1) * BK, ra);
-            lb.load((kt + 1) * BK, rb);
-        }
-        mfma_tile(sA, sB, arow, brow, ksel, acc);
+        const int k0n = min(kt + 1, kt1 - 1) * BK;     // next tile (the last step reloads its own: harmless)
+        mfma_tile_ld<PLANE, PLANE, 8>(sA, sB, arow, brow, ksel, acc, [&](auto ic) {
+            constexpr int i = ic.value;
+            if constexpr (i < 4) la.load_item(i, k0n, ra[i]);
+            else lb.load_item(i - 4, k0n, rb[i - 4]);
+        });
         TRACE_T(wave, kt - kt0, 3);
     }
 
@@ -380,14 +426,6 @@ struct TileLoader {
 
 constexpr int BUF = 6 * PLANE;                              // bf16 per buffer: A planes, then B planes
 constexpr size_t FUSED_LDS = (size_t)2 * BUF * sizeof(__bf16);
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 struct SplitState {
     float x[4];          // the item, then its residuals

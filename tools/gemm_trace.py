@@ -31,7 +31,8 @@ def run():
     import numpy as np
     import torch
     m, n, k, ta, tb = [int(x) for x in sys.argv[2:7]]
-    os.environ['RENET_GEMM_KERNEL'] = 'split'
+    os.environ['RENET_GEMM_KERNEL'] = sys.argv[7] if len(sys.argv) > 7 else 'split'
+    nw = 4
     lib = ctypes.CDLL(LIB)
     dev = torch.device('cuda:0')
     a = torch.randn((k, m) if ta else (m, k), device=dev)
@@ -67,7 +68,7 @@ def run():
         live = t[:, 0, 5, 0] != 0
         print('traced workgroups:', int(live.sum()))
         t = t[live]
-        st = t[:, :4, :nkt, :]
+        st = t[:, :nw, :nkt, :]
         s0, s1, s2, s3 = st[..., 0], st[..., 1], st[..., 2], st[..., 3]
         nxt = np.concatenate([s0[:, :, 1:], s0[:, :, -1:]], axis=2)
         sl = (slice(None), slice(None), slice(4, nkt - 4))
