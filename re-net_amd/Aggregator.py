@@ -86,7 +86,7 @@ class RGCNAggregator(nn.Module):
         self.last_batch = None
 
     # ------------------------------------------------------------------------------------------
-    def build(self, s_hist, s, r, ent_embeds, graph_dict, global_emb, sort):
+    def build(self, s_hist, s, r, ent_embeds, graph_dict, global_emb, sort, group=None):
         """Host side of utils.py:209-283: returns the device batch graph (or None if every history
         is empty)."""
         s_np, r_np = _host_ints(s), _host_ints(r)
@@ -95,7 +95,7 @@ class RGCNAggregator(nn.Module):
             return None
         table = self.glob_table.get(global_emb, self.h_dim, ent_embeds.device)
         hb = G.build_batch(G.store_for(graph_dict), self.num_nodes, self.num_rels, s_np, r_np, fh, sort=sort,
-                           glob_index=table.index)
+                           glob_index=table.index, group=group)
         if hb.L > self.seq_len:
             raise ValueError('history longer than seq_len (%d > %d)' % (hb.L, self.seq_len))
         g = G.DeviceGraph(hb, ent_embeds.device)
@@ -114,8 +114,8 @@ class RGCNAggregator(nn.Module):
         sx, sxr = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
         return ops.SeqAssembleFn.apply(h2, ent_embeds, rel_embeds, g.glob, g, p, sx, sxr)
 
-    def _run(self, s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse, sort):
-        g = self.build(s_hist, s, r, ent_embeds, graph_dict, global_emb, sort)
+    def _run(self, s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse, sort, group=None):
+        g = self.build(s_hist, s, r, ent_embeds, graph_dict, global_emb, sort, group)
         self.last_batch = g
         if g is None:
             return None, None
@@ -123,10 +123,12 @@ class RGCNAggregator(nn.Module):
         bs = torch.from_numpy(g.host.batch_sizes)
         return PackedSequence(x, bs), PackedSequence(xr, bs)
 
-    def forward(self, s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse):
+    def forward(self, s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse, group=None):
         """Aggregator.py:124-167.  Returns (PackedSequence[., 4h], PackedSequence[., 3h]) for the
-        length-sorted non-empty sequences, or (None, None) when every history is empty."""
-        return self._run(s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse, True)
+        length-sorted non-empty sequences, or (None, None) when every history is empty.
+        group (extension, see graph.build_batch): sequences of different groups get separate member graphs, i.e.
+        the batch equals one call per group -- used to batch the reference's per-quadruple inference."""
+        return self._run(s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse, True, group)
 
     def predict_batch(self, s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse):
         """Aggregator.py:169-214: same, sequences kept in the given order."""

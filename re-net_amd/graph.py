@@ -336,10 +336,61 @@ class HostBatch(object):
         return cls().set_edges(n, src, dst, type_s, 2 * num_rels)
 
 
-def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None):
+TABLE_ENTRIES = 1 << 24          # (slot, entity) lookup-table entries per chunk of _induced_edges
+
+
+def _induced_edges(store, ti, num_ent, keys, new_id):
+    """Node-induced edges of the member graphs (utils.py:115-131): slot c is the graph of store timestamp index
+    ti[c]; keys = sorted slot * num_ent + entity of the batch's nodes, new_id their row numbers.  Returns the
+    local (subject row, object row, relation) of every kept fact, slot-major in fact order.  Membership is a
+    direct lookup in a (slot, entity) table, processed in slot chunks that bound the table to 2^24 entries (one
+    chunk for a training batch's <= 240 timestamps, many for the per-sequence graphs of batched inference)."""
+    Tb = len(ti)
+    L_ = _native()
+    per = max(1, TABLE_ENTRIES // max(num_ent, 1))
+    out_s, out_o, out_r = [], [], []
+    nid32 = np.ascontiguousarray(new_id, dtype=np.int32)
+    for c0 in range(0, Tb, per):
+        c1 = min(Tb, c0 + per)
+        k0, k1 = np.searchsorted(keys, (c0 * num_ent, c1 * num_ent))
+        tic = np.ascontiguousarray(ti[c0:c1], dtype=np.int64)
+        tcnt = store.trip_ptr[tic + 1] - store.trip_ptr[tic]
+        kc = np.ascontiguousarray(keys[k0:k1] - c0 * num_ent, dtype=np.int64)
+        table = _lookup_table((c1 - c0) * num_ent)
+        if L_ is not None:
+            cap = int(tcnt.sum())
+            ls, lo, rr = np.empty(cap, np.int64), np.empty(cap, np.int64), np.empty(cap, np.int64)
+            nc = np.ascontiguousarray(nid32[k0:k1])
+            m = L_.renet_host_filter_edges(_p(store.trip_ptr), _p(store.trip_s), _p(store.trip_r), _p(store.trip_o),
+                                           _p(tic), c1 - c0, num_ent, _p(kc), _p(nc), k1 - k0, _p(table), _p(ls),
+                                           _p(lo), _p(rr))
+            out_s.append(ls[:m]); out_o.append(lo[:m]); out_r.append(rr[:m])
+        else:
+            flat = ragged_arange(store.trip_ptr[tic], tcnt)
+            eslot = np.repeat(np.arange(c1 - c0, dtype=np.int64), tcnt)
+            ks = eslot * num_ent + store.trip_s[flat]
+            ko = eslot * num_ent + store.trip_o[flat]
+            # two random gathers instead of two binary searches over the facts' endpoints
+            table[kc] = nid32[k0:k1]
+            ps, po = table[ks], table[ko]
+            table[kc] = -1                                        # leave the scratch table clean
+            keep = (ps >= 0) & (po >= 0)
+            out_s.append(ps[keep].astype(np.int64)); out_o.append(po[keep].astype(np.int64))
+            out_r.append(store.trip_r[flat][keep])
+    if not out_s:
+        z = np.zeros(0, np.int64)
+        return z, z, z
+    return np.concatenate(out_s), np.concatenate(out_o), np.concatenate(out_r)
+
+
+def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None, group=None):
     """Vectorised restatement of utils.py:209-283 (+115-131,149-181).
 
     store: GraphStore;  s, r: int arrays [B];  fh: FlatHistory of the B sequences;
+    group: None = the reference's TRAINING semantics -- one node set per timestamp, the union over every sequence
+      of the batch; an int array [B] = sequences with different group ids get SEPARATE member
+      graphs per timestamp, i.e. the result of calling the reference once per group (what its inference does,
+      model.py:329-352, one call per test quadruple) in one batch;
     Edge types are stored as type_s; the object-side pass (reverse, model.py:78) uses
     type_o = (type_s + R) mod 2R, which the kernels apply as `type_shift`;
     glob_index: callable mapping an int64 array of timestamps to rows of the global-embedding matrix.
@@ -375,6 +426,10 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None):
     step_j = np.arange(S, dtype=np.int64) - np.repeat(np.cumsum(ln) - ln, ln)
     t_k = fh.step_t[step_idx]
     uniq_t, slot_k = np.unique(t_k, return_inverse=True)
+    if group is not None:
+        g_k = np.asarray(group, dtype=np.int64).reshape(-1)[perm][step_seq]
+        pair, slot_k = np.unique(g_k * max(len(uniq_t), 1) + slot_k, return_inverse=True)
+        uniq_t = uniq_t[pair % max(len(uniq_t), 1)]               # the timestamp of every (group, t) slot
     Tb = len(uniq_t)
     hb.graph_t = uniq_t
 
@@ -401,31 +456,7 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None):
 
     # node-induced edges of every member graph (utils.py:115-131)
     if Tb:
-        ti = np.ascontiguousarray(store.index_of(uniq_t), dtype=np.int64)
-        tcnt = store.trip_ptr[ti + 1] - store.trip_ptr[ti]
-        L_ = _native()
-    if Tb and L_ is not None:
-        cap = int(tcnt.sum())
-        ls, lo, rr = np.empty(cap, np.int64), np.empty(cap, np.int64), np.empty(cap, np.int64)
-        table = _lookup_table(Tb * num_ent)
-        nid32 = np.ascontiguousarray(new_id, dtype=np.int32)
-        m = L_.renet_host_filter_edges(_p(store.trip_ptr), _p(store.trip_s), _p(store.trip_r), _p(store.trip_o),
-                                       _p(ti), Tb, num_ent, _p(keys), _p(nid32), N, _p(table), _p(ls), _p(lo),
-                                       _p(rr))
-        ls, lo, rr = ls[:m], lo[:m], rr[:m]
-    elif Tb:
-        flat = ragged_arange(store.trip_ptr[ti], tcnt)
-        eslot = np.repeat(np.arange(Tb, dtype=np.int64), tcnt)
-        ks = eslot * num_ent + store.trip_s[flat]
-        ko = eslot * num_ent + store.trip_o[flat]
-        # membership by direct lookup ((slot, entity) -> new row id, -1 = not in the batch's node set): two
-        # random gathers instead of two binary searches over ~370k endpoints
-        table = _lookup_table(Tb * num_ent)
-        table[keys] = new_id.astype(np.int32)
-        ps, po = table[ks], table[ko]
-        table[keys] = -1                                          # leave the scratch table clean
-        keep = (ps >= 0) & (po >= 0)
-        ls, lo, rr = ps[keep].astype(np.int64), po[keep].astype(np.int64), store.trip_r[flat][keep]
+        ls, lo, rr = _induced_edges(store, store.index_of(uniq_t), num_ent, keys, new_id)
     else:
         ls = lo = rr = np.zeros(0, np.int64)
     src = np.concatenate((ls, lo))

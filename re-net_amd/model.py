@@ -422,6 +422,116 @@ def _evaluate_filter(self, triplet, s_hist, o_hist, global_model, all_triplets):
     return np.array([rank_sub, rank_ob]), loss
 
 
+def _host_quads(triplets):
+    tr = triplets.detach().cpu().numpy() if isinstance(triplets, torch.Tensor) else np.asarray(triplets)
+    return tr.astype(np.int64).reshape(-1, 4)
+
+
+def _predict_batch(self, triplets, s_hist, o_hist, global_model):
+    """predict() for n test quadruples that share ONE timestamp, in one batch: row i of the result equals
+    predict(triplets[i], (s_hist[0][i], s_hist[1][i]), (o_hist[0][i], o_hist[1][i]), global_model).
+    The reference (and predict) build the batch graph of every quadruple separately, so the member graphs are kept
+    separate per entity here (build_batch group=entity: same entity => same rolling history => same graphs)
+    instead of being merged per timestamp as in training.  s_hist / o_hist: (list of the n given histories,
+    list of their timestamp lists), i.e. slices of test.py's s_history_test / s_history_test_t.
+    Returns (loss[n], sub_pred[n, in_dim], ob_pred[n, in_dim])."""
+    tr = _host_quads(triplets)
+    n = len(tr)
+    if n == 0 or np.any(tr[:, 3] != tr[0, 3]):
+        raise ValueError('predict_batch takes the quadruples of ONE timestamp')
+    if _as_int(self.latest_time) != int(tr[0, 3]):
+        self._advance_time(torch.tensor(int(tr[0, 3])), global_model)
+    R, dev = self.num_rels, self.ent_embeds.device
+
+    def encode(ents, rels, given, hist, hist_t, rel_embeds, reverse):
+        h = torch.zeros(n, self.h_dim, device=dev)
+        act = np.asarray([i for i in range(n) if len(given[i]) != 0 and len(hist[ents[i]]) != 0], dtype=np.int64)
+        if len(act):                                                              # model.py:332,342
+            e = ents[act]
+            px, _ = self.aggregator.forward(([hist[k] for k in e], [hist_t[k] for k in e]), e, rels[act],
+                                            self.ent_embeds, rel_embeds, self.graph_dict, self.global_emb,
+                                            reverse=reverse, group=e)
+            _, hh = self.encoder(px, total_rows=len(act))
+            perm = self.aggregator.last_batch.host.perm                          # sorted position -> sequence
+            h[torch.from_numpy(act[perm]).to(dev)] = hh[0]
+        return h
+
+    with torch.no_grad():
+        s, r, o = tr[:, 0], tr[:, 1], tr[:, 2]
+        s_h = encode(s, r, s_hist[0], self.s_hist_test, self.s_hist_test_t, self.rel_embeds[:R], False)
+        o_h = encode(o, r, o_hist[0], self.o_hist_test, self.o_hist_test_t, self.rel_embeds[R:], True)
+        si, ri, oi = (torch.from_numpy(x).to(dev) for x in (s, r, o))
+        ob_pred = _linear_eval(self.linear, torch.cat((self.ent_embeds[si], s_h, self.rel_embeds[ri]), dim=1))
+        sub_pred = _linear_eval(self.linear, torch.cat((self.ent_embeds[oi], o_h, self.rel_embeds[R + ri]), dim=1))
+        loss = K.softmax_ce(ob_pred, oi.int(), 1.0, False) + K.softmax_ce(sub_pred, si.int(), 1.0, False)
+    return loss, sub_pred, ob_pred
+
+
+def _rank_rows(scores, label, filt_rows=None, filt_cols=None):
+    """_rank for every row of scores[n, C] at once (label[n]); filt_rows/filt_cols list the (row, column) pairs
+    of the other known-true completions (filtered setting).  Returns float64 ranks [n] (ties averaged)."""
+    rows = torch.arange(scores.shape[0], device=scores.device)
+    if filt_rows is not None:
+        scores = torch.sigmoid(scores)
+        ground = scores[rows, label].clone()
+        scores[filt_rows, filt_cols] = 0
+        scores[rows, label] = ground
+    else:
+        ground = scores[rows, label]
+    greater = (scores > ground[:, None]).sum(dim=1).double()
+    equal = (scores == ground[:, None]).sum(dim=1).double()
+    return (greater + (equal - 1.0) / 2 + 1).cpu().numpy()
+
+
+def _known_pairs(at, key_cols, val_col, keys):
+    """For every row i of keys[n, 2]: the values all_triplets[:, val_col] of the facts whose key_cols equal
+    keys[i] -> (row index, value) pair lists (the time-agnostic filter sets of model.py:392-401)."""
+    at = np.asarray(at.cpu() if isinstance(at, torch.Tensor) else at, dtype=np.int64)
+    span = int(at[:, list(key_cols) + [val_col]].max()) + 2
+    code = at[:, key_cols[0]] * span + at[:, key_cols[1]]
+    order = np.argsort(code, kind='stable')
+    code_sorted = code[order]
+    want = keys[:, 0] * span + keys[:, 1]
+    lo, hi = np.searchsorted(code_sorted, want, 'left'), np.searchsorted(code_sorted, want, 'right')
+    cnt = hi - lo
+    rows = np.repeat(np.arange(len(keys)), cnt)
+    vals = at[order[G.ragged_arange(lo, cnt)], val_col]
+    return rows, vals
+
+
+def _evaluate_filter_batch(self, triplets, s_hist, o_hist, global_model, all_triplets):
+    """evaluate_filter() for the n quadruples of ONE timestamp (extension of the reference API): returns
+    (ranks[n, 2] = (rank_sub, rank_ob) per row, loss[n]), row i equal to
+    evaluate_filter(triplets[i], (s_hist[0][i], s_hist[1][i]), (o_hist[0][i], o_hist[1][i]), ...)."""
+    tr = _host_quads(triplets)
+    loss, sub_pred, ob_pred = self.predict_batch(tr, s_hist, o_hist, global_model)
+    dev = ob_pred.device
+    s, r, o = tr[:, 0], tr[:, 1], tr[:, 2]
+    ro, co = _known_pairs(all_triplets, (0, 1), 2, np.stack((s, r), axis=1))       # objects known for (s, r)
+    rs, cs = _known_pairs(all_triplets, (2, 1), 0, np.stack((o, r), axis=1))       # subjects known for (o, r)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    rank_ob = _rank_rows(ob_pred, t(o), t(ro), t(co))
+    rank_sub = _rank_rows(sub_pred, t(s), t(rs), t(cs))
+    return np.stack((rank_sub, rank_ob), axis=1), loss
+
+
+def _evaluate_filter_stream(self, total_data, s_history, o_history, global_model, all_triplets, max_batch=4096):
+    """test.py:104-139 for a whole time-ordered test stream: groups consecutive quadruples by timestamp and
+    evaluates each group with evaluate_filter_batch (the per-timestamp state update of predict() runs once per
+    group, exactly as in the sequential loop).  s_history / o_history: (histories, timestamps) per quadruple,
+    as loaded by test.py.  Returns (ranks[len, 2], loss[len])."""
+    tr = _host_quads(total_data)
+    ranks, losses = np.zeros((len(tr), 2)), np.zeros(len(tr), dtype=np.float32)
+    cut = np.concatenate(([0], np.nonzero(np.diff(tr[:, 3]))[0] + 1, [len(tr)]))
+    for a, b in zip(cut[:-1], cut[1:]):
+        for c in range(a, b, max_batch):
+            d = min(b, c + max_batch)
+            rk, ls = self.evaluate_filter_batch(tr[c:d], (s_history[0][c:d], s_history[1][c:d]),
+                                                (o_history[0][c:d], o_history[1][c:d]), global_model, all_triplets)
+            ranks[c:d], losses[c:d] = rk, ls.cpu().numpy()
+    return ranks, losses
+
+
 RENet.init_history = _init_history
 RENet.update_cache = _update_cache
 RENet.pred_r_rank2 = _pred_r_rank2
@@ -432,3 +542,6 @@ RENet._advance_time = _advance_time
 RENet.predict = _predict
 RENet.evaluate = _evaluate
 RENet.evaluate_filter = _evaluate_filter
+RENet.predict_batch = _predict_batch
+RENet.evaluate_filter_batch = _evaluate_filter_batch
+RENet.evaluate_filter_stream = _evaluate_filter_stream

@@ -427,14 +427,14 @@ def test_full_size_dw_matches_fp64_sampled(dev):
 # ---------------------------------------------------------------------------------------------
 # multi-step inference (model.py:216-419): evaluate_filter trajectory vs the reference (golden)
 # ---------------------------------------------------------------------------------------------
-def test_evaluate_filter_matches_reference_golden(dev):
+def _eval_setup(dev, gold):
+    """Model, global model, histories and graph dict in the state test.py has before its evaluation loop."""
     import global_model as GM
     import model as M
     import preprocess as P
     import utils as U
-    gold = load_golden('eval_small_100.npz')
     cfg, tr, va, te = fixtures.split_dataset('small')
-    d, seq_len, num_k, n_eval = int(gold['d']), int(gold['seq_len']), int(gold['num_k']), int(gold['n_eval'])
+    d, seq_len, num_k = int(gold['d']), int(gold['seq_len']), int(gold['num_k'])
     net = M.RENet(cfg['num_ent'], d, cfg['num_rels'], dropout=0.0, seq_len=seq_len, num_k=num_k)
     gnet = GM.RENet_global(cfg['num_ent'], d, cfg['num_rels'], dropout=0.0, seq_len=seq_len, num_k=num_k, maxpool=1)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in
@@ -449,7 +449,6 @@ def test_evaluate_filter_matches_reference_golden(dev):
            'test': np.arange(len(tr) + len(va), len(allq))}
     H = {k: (hs.to_lists(v), ho.to_lists(v)) for k, v in rng.items()}
     gd = U.build_graph_dict(tr, cfg['num_rels'])
-    n_graphs0 = len(gd)
     samples = [torch.from_numpy(x).to(dev) for x in gold['samples']]
     net.sample_entities = lambda prob: samples.pop(0)          # drive the reference's random trajectory
     total = torch.from_numpy(allq).to(dev)
@@ -460,6 +459,49 @@ def test_evaluate_filter_matches_reference_golden(dev):
         net.init_history(tr, H['train'][0], H['train'][1], valid, H['valid'][0], H['valid'][1], te,
                          H['test'][0], H['test'][1])
         net.latest_time = valid[0][3]
+    return net, gnet, H, gd, samples, total, valid, va
+
+
+def test_evaluate_filter_stream_equals_sequential_calls(dev):
+    """evaluate_filter_stream / evaluate_filter_batch / predict_batch (all quadruples of a timestamp in one batch,
+    member graphs kept separate per entity) vs one evaluate_filter call per quadruple on an identical model."""
+    gold = load_golden('eval_small_100.npz')
+    n_eval = int(gold['n_eval'])
+    net, gnet, H, gd, samples, total, valid, va = _eval_setup(dev, gold)
+    (vs, vst), (vo, vot) = H['valid']
+    with torch.no_grad():
+        seq = [net.evaluate_filter(valid[i], (vs[i], vst[i]), (vo[i], vot[i]), gnet, total) for i in range(n_eval)]
+    ranks_seq = np.asarray([r for r, _ in seq])
+    loss_seq = np.asarray([float(l) for _, l in seq])
+    net2, gnet2, H2, gd2, samples2, total2, valid2, _ = _eval_setup(dev, gold)
+    ranks, loss = net2.evaluate_filter_stream(valid2[:n_eval], (vs[:n_eval], vst[:n_eval]), (vo[:n_eval], vot[:n_eval]),
+                                              gnet2, total2)
+    assert len(samples) == len(samples2) == 0
+    assert list(gd.keys()) == list(gd2.keys())
+    for t in gd.keys():
+        a, b = gd[t].global_triples(), gd2[t].global_triples()
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    np.testing.assert_allclose(loss, loss_seq, rtol=1e-5, atol=1e-5)
+    assert float(np.mean(ranks == ranks_seq)) >= 0.99 and np.abs(ranks - ranks_seq).max() <= 1
+    # the quadruples of the timestamp the state is at, in a different order and with a repeated row
+    t0 = int(va[n_eval - 1, 3])
+    m = np.nonzero(va[:n_eval, 3] == t0)[0][::-1]
+    m = np.concatenate((m, m[:1]))
+    rk, ls = net2.evaluate_filter_batch(va[m], ([vs[i] for i in m], [vst[i] for i in m]),
+                                        ([vo[i] for i in m], [vot[i] for i in m]), gnet2, total2)
+    assert rk.shape == (len(m), 2) and np.array_equal(rk[0], rk[-1]) and float(ls[0]) == float(ls[-1])
+    np.testing.assert_allclose(ls.cpu().numpy()[:-1], loss_seq[m[:-1]], rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        net2.predict_batch(va[:n_eval], (vs[:n_eval], vst[:n_eval]), (vo[:n_eval], vot[:n_eval]), gnet2)
+
+
+def test_evaluate_filter_matches_reference_golden(dev):
+    gold = load_golden('eval_small_100.npz')
+    cfg, tr, va, te = fixtures.split_dataset('small')
+    n_eval = int(gold['n_eval'])
+    net, gnet, H, gd, samples, total, valid, va = _eval_setup(dev, gold)
+    n_graphs0 = len(gd) - 0
+    with torch.no_grad():
         ranks, losses = [], []
         for i in range(n_eval):
             (vs, vst), (vo, vot) = H['valid']

@@ -298,3 +298,51 @@ def test_native_host_builder_equals_numpy_builder():
         finally:
             G.NATIVE = True
     assert np.array_equal(packed[False].ints, packed[True].ints) and np.array_equal(packed[False].norm, packed[True].norm)
+
+
+def _subject_row_signature(hb):
+    """For every packed step row: (sequence in the caller's order, step) -> (norm of the subject row, sorted
+    multiset of its in-edges as (source entity, relation type))."""
+    sig = {}
+    step_of_row = np.arange(hb.S) - hb.step_off[np.searchsorted(hb.step_off, np.arange(hb.S), side='right') - 1]
+    j_of_row = np.searchsorted(hb.step_off, np.arange(hb.S), side='right') - 1
+    del step_of_row
+    for p in range(hb.S):
+        row = int(hb.subj_row[p])
+        lo, hi = int(hb.row_ptr[row]), int(hb.row_ptr[row + 1])
+        edges = sorted(zip(hb.node_ent[hb.col[lo:hi]].tolist(), hb.etype[lo:hi].tolist()))
+        sig[(int(hb.perm[hb.row_seq[p]]), int(j_of_row[p]))] = (float(hb.norm[row]), edges)
+    return sig
+
+
+def test_grouped_batch_equals_one_call_per_group():
+    """build_batch(group=...) = the member graphs of calling the builder once per group (the reference's
+    inference calls get_s_r_embed_rgcn per test quadruple, model.py:329-352), for both builder back ends, with
+    more (group, timestamp) slots than one lookup-table chunk holds."""
+    import preprocess as P
+    import synth
+    quads, ne, nr, _ = synth.make_stream('ICEWS18', seed=5, num_t=30)
+    gd = P.build_graph_dict(quads, nr)
+    hs = P.HistoryIndex(quads, 's', 10)
+    idx = np.random.RandomState(4).permutation(len(quads))[:120]
+    store = G.store_for(gd)
+    s, r, fh = quads[idx, 0], quads[idx, 1], hs.take(idx)
+    group = np.arange(len(idx)) // 2                     # pairs of sequences share their member graphs
+    sigs = []
+    for native, entries in ((False, 1 << 24), (True, 1 << 24), (True, 37 * ne), (False, 37 * ne)):
+        G.NATIVE, G.TABLE_ENTRIES = native, entries      # 37 slots per chunk: many chunks
+        try:
+            sigs.append(_subject_row_signature(G.build_batch(store, ne, nr, s, r, fh, sort=True, group=group)))
+        finally:
+            G.NATIVE, G.TABLE_ENTRIES = True, 1 << 24
+    assert sigs[0] == sigs[1] == sigs[2] == sigs[3]
+    want = {}
+    for g in np.unique(group):
+        m = np.nonzero(group == g)[0]
+        hb = G.build_batch(store, ne, nr, s[m], r[m], fh.take(m), sort=True)
+        for (i, j), v in _subject_row_signature(hb).items():
+            want[(int(m[i]), j)] = v
+    assert sigs[1] == want
+    # the default (training) semantics differ: node sets are unions over the whole batch
+    union = _subject_row_signature(G.build_batch(store, ne, nr, s, r, fh, sort=True))
+    assert union.keys() == want.keys() and union != want
