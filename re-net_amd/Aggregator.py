@@ -123,11 +123,15 @@ class RGCNAggregator(nn.Module):
         bs = torch.from_numpy(g.host.batch_sizes)
         return PackedSequence(x, bs), PackedSequence(xr, bs)
 
-    def forward(self, s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse, group=None):
+    def forward(self, s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse):
         """Aggregator.py:124-167.  Returns (PackedSequence[., 4h], PackedSequence[., 3h]) for the
-        length-sorted non-empty sequences, or (None, None) when every history is empty.
-        group (extension, see graph.build_batch): sequences of different groups get separate member graphs, i.e.
-        the batch equals one call per group -- used to batch the reference's per-quadruple inference."""
+        length-sorted non-empty sequences, or (None, None) when every history is empty."""
+        return self._run(s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse, True)
+
+    def forward_grouped(self, s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse, group):
+        """Extension (not in the reference): forward() with SEPARATE member graphs for sequences of different
+        `group` ids (graph.build_batch), i.e. the batch equals one reference call per group -- used to batch the
+        reference's per-quadruple inference."""
         return self._run(s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse, True, group)
 
     def predict_batch(self, s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse):

@@ -448,9 +448,9 @@ def _predict_batch(self, triplets, s_hist, o_hist, global_model):
         act = np.asarray([i for i in range(n) if len(given[i]) != 0 and len(hist[ents[i]]) != 0], dtype=np.int64)
         if len(act):                                                              # model.py:332,342
             e = ents[act]
-            px, _ = self.aggregator.forward(([hist[k] for k in e], [hist_t[k] for k in e]), e, rels[act],
-                                            self.ent_embeds, rel_embeds, self.graph_dict, self.global_emb,
-                                            reverse=reverse, group=e)
+            px, _ = self.aggregator.forward_grouped(([hist[k] for k in e], [hist_t[k] for k in e]), e, rels[act],
+                                                    self.ent_embeds, rel_embeds, self.graph_dict, self.global_emb,
+                                                    reverse, e)
             _, hh = self.encoder(px, total_rows=len(act))
             perm = self.aggregator.last_batch.host.perm                          # sorted position -> sequence
             h[torch.from_numpy(act[perm]).to(dev)] = hh[0]
