@@ -96,8 +96,8 @@ int renet_rgcn_bwd_prep(const float* g_out, const float* out, const float* norm,
 size_t renet_rgcn_bwd_w_workspace(int n_chunks, int D);
 int renet_rgcn_bwd_w(const float* x, const float* gn, const int32_t* e_src, const int32_t* e_dst,
                      const int32_t* chunk_ptr, const int32_t* chunk_type, int n_chunks,
-                     const int32_t* type_chunk_ptr, int T, int type_shift, int D, float* dW,
-                     float* workspace, size_t workspace_bytes, void* stream);
+                     const int32_t* type_chunk_ptr, int T, int type_shift, int D, float* dW, float beta,
+                     float* workspace, size_t workspace_bytes, void* stream);   /* dW = beta * dW + ... */
 
 /* ------------------------------------------------------------------------------------------------
  * fp32 GEMM on the f32-input MFMA (exact fp32, v_mfma_f32_32x32x2_f32):
@@ -121,11 +121,16 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
                          const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                          int split_k, float* workspace, size_t workspace_bytes, void* stream);
 
-/* column sums: out[n] = sum_m X[m,n]  (bias gradients); two deterministic passes over row groups,
- * `workspace` = renet_colsum_workspace(M, N) bytes (0 for short matrices). */
+/* column sums: out[n] = beta * out[n] + sum_m X[m,n]  (bias gradients; beta = 1 accumulates straight into
+ * an existing .grad); two deterministic passes over row groups, `workspace` = renet_colsum_workspace(M, N)
+ * bytes (0 for short matrices). */
 size_t renet_colsum_workspace(int M, int N);
-int renet_colsum(const float* X, int M, int N, int ldx, float* out, float* workspace,
+int renet_colsum(const float* X, int M, int N, int ldx, float* out, float beta, float* workspace,
                  size_t workspace_bytes, void* stream);
+
+/* x[0..n) *= *scale, with the factor read from DEVICE memory (an upstream autograd gradient: no host sync);
+ * a factor of exactly 1 returns without touching x. */
+int renet_scale_by_device_scalar(float* x, size_t n, const float* scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sequence assembly (Aggregator.py:142-165): builds the GRU inputs directly in PACKED time-major
@@ -157,14 +162,16 @@ int renet_seq_assemble_bwd(const float* dX, const float* dXr, const int32_t* ste
  *                    length-sorted batch is row off[j]+i; batch_sizes non-increasing)
  *   step_off[L+1]    HOST array of row offsets (off[0] = 0, off[L] = S)
  *   Whh [3H,H], bhh[3H]
- *   h_last  [B,H]    state of every sequence after its own last step (h_n of nn.GRU), B = off[1]
+ *   h_last  [out_rows,H] state of every sequence after its own last step (h_n of nn.GRU), B = off[1];
+ *                    rows [B, out_rows) are written as zeros (the reference pads h_n for the empty
+ *                    histories, model.py:88): out_rows >= B
  *   saved   [S, 5H]  per packed row: r, z, n, (W_hn h + b_hn), h_prev   (consumed by backward)
  * Backward: given dh_last[B,H] produces dGi[S,3H], dGh[S,3H] (caller forms dW_ih, dW_hh, biases,
  * dX with renet_gemm_f32 / renet_colsum) ; `dh_work`[B,H] is scratch.
  * ---------------------------------------------------------------------------------------------- */
 size_t renet_gru_workspace(int B, int H);
 int renet_gru_fwd(const float* Gi, const int32_t* step_off, int L, int H, const float* Whh,
-                  const float* bhh, float* h_last, float* saved, float* workspace,
+                  const float* bhh, float* h_last, int out_rows, float* saved, float* workspace,
                   size_t workspace_bytes, void* stream);
 int renet_gru_bwd(const float* dh_last, const int32_t* step_off, int L, int H, const float* Whh,
                   const float* saved, float* dGi, float* dGh, float* workspace,
@@ -173,7 +180,7 @@ int renet_gru_bwd(const float* dh_last, const int32_t* step_off, int L, int H, c
  * `encoder_r`, model.py:86,94): every pointer argument is a HOST array of n device pointers;
  * the backward workspace is n * renet_gru_workspace bytes. */
 int renet_gru_fwd_multi(int n, const float* const* Gi, const int32_t* step_off, int L, int H,
-                        const float* const* Whh, const float* const* bhh, float* const* h_last,
+                        const float* const* Whh, const float* const* bhh, float* const* h_last, int out_rows,
                         float* const* saved, void* stream);
 int renet_gru_bwd_multi(int n, const float* const* dh_last, const int32_t* step_off, int L, int H,
                         const float* const* Whh, const float* const* saved, float* const* dGi,

@@ -16,6 +16,7 @@
 // Used for: the RGCN self-loop h @ W_loop (RGCN.py:35), the GRU input projections (inside nn.GRU,
 // model.py:86,94), the score heads (model.py:89-90,98-99) and all their backward GEMMs
 // (dX = dY W, dW = dY^T X with deterministic split-K).
+#include <cstdint>
 #include "common.h"
 
 namespace {
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // combine => deterministic.  Two launches (row groups, then the groups) keep every CU busy on the
 // tall-skinny bias-gradient shapes ([7.6k, 600], [1024, 23033]).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ldx,
-                                                     int rows_per_group, float* __restrict__ out) {
+                                                     int rows_per_group, float beta, float* __restrict__ out) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
@@ -299,8 +300,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     }
     red[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (wave == 0 && n < N)
-        out[(size_t)g * N + n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wave == 0 && n < N) {
+        float r = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        float* o = out + (size_t)g * N + n;
+        if (beta != 0.f) r += beta * (*o);
+        *o = r;
+    }
+}
+
+// x *= *scale with the factor in device memory (an upstream autograd gradient); exactly 1 => nothing to do.
+__global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, size_t n,
+                                                        const float* __restrict__ scale) {
+    const float f = *scale;
+    if (f == 1.f) return;
+    const size_t n4 = n >> 2;
+    float4* x4 = reinterpret_cast<float4*>(x);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = x4[i];
+        x4[i] = make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) x[(n4 << 2) + threadIdx.x] *= f;
 }
 
 inline int colsum_groups(int M) { return max(1, min(64, (M + 127) / 128)); }
@@ -351,21 +370,30 @@ size_t renet_colsum_workspace(int M, int N) {
     return G > 1 ? (size_t)G * (size_t)N * sizeof(float) : 0;
 }
 
-int renet_colsum(const float* X, int M, int N, int ldx, float* out, float* workspace,
+int renet_scale_by_device_scalar(float* x, size_t n, const float* scale, void* stream) {
+    if (!x || !scale || (reinterpret_cast<uintptr_t>(x) & 15)) return RENET_ERR_BADARG;
+    if (n == 0) return RENET_OK;
+    const int blocks = (int)min((size_t)2048, (n / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, scale);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_colsum(const float* X, int M, int N, int ldx, float* out, float beta, float* workspace,
                  size_t workspace_bytes, void* stream) {
     if (M < 0 || N <= 0 || ldx < N) return RENET_ERR_BADARG;
     const int G = colsum_groups(M);
     hipStream_t st = (hipStream_t)stream;
     if (G == 1) {
-        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, st, X, M, N, ldx, max(M, 1), out);
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, st, X, M, N, ldx, max(M, 1), beta, out);
         RENET_LAUNCH_CHECK();
         return RENET_OK;
     }
     if (workspace_bytes < renet_colsum_workspace(M, N)) return RENET_ERR_WORKSPACE;
     const int rpg = (M + G - 1) / G;
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, G), dim3(256), 0, st, X, M, N, ldx, rpg, workspace);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, G), dim3(256), 0, st, X, M, N, ldx, rpg, 0.f, workspace);
     RENET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, st, workspace, G, N, N, G, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, st, workspace, G, N, N, G, beta, out);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }

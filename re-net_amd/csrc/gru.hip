@@ -52,7 +52,7 @@ struct BwdProb { const float* dh_last; const float* WhhT; const float* saved; fl
 struct BwdProbs { BwdProb p[MAXP]; };
 
 template <int H>
-__global__ __launch_bounds__(NT) void gru_fwd_kernel(FwdProbs ps, StepOff so, int L) {
+__global__ __launch_bounds__(NT) void gru_fwd_kernel(FwdProbs ps, StepOff so, int L, int out_rows) {
     using C = Cfg<H>;
     const float* __restrict__ Gi = ps.p[blockIdx.y].Gi;
     const float* __restrict__ Whh = ps.p[blockIdx.y].Whh;
@@ -142,9 +142,10 @@ __global__ __launch_bounds__(NT) void gru_fwd_kernel(FwdProbs ps, StepOff so, in
         }
         __syncthreads();
     }
-    for (int t = tid; t < MT * H; t += NT) {
+    (void)B;
+    for (int t = tid; t < MT * H; t += NT) {                  // rows >= B were never touched: still h0 = 0
         const int i = t / H, u = t - i * H;
-        if (i0 + i < B) h_last[(size_t)(i0 + i) * H + u] = Hs[i * C::LDH + u];
+        if (i0 + i < out_rows) h_last[(size_t)(i0 + i) * H + u] = Hs[i * C::LDH + u];
     }
 }
 
@@ -249,8 +250,9 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }
 
 template <int H>
-int launch_fwd(const FwdProbs& ps, int np, const StepOff& so, int L, int B, hipStream_t st) {
-    hipLaunchKernelGGL((gru_fwd_kernel<H>), dim3((B + MT - 1) / MT, np), dim3(NT), 0, st, ps, so, L);
+int launch_fwd(const FwdProbs& ps, int np, const StepOff& so, int L, int out_rows, hipStream_t st) {
+    hipLaunchKernelGGL((gru_fwd_kernel<H>), dim3((out_rows + MT - 1) / MT, np), dim3(NT), 0, st, ps, so, L,
+                       out_rows);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -291,14 +293,19 @@ size_t renet_gru_workspace(int B, int H) {
 }
 
 int renet_gru_fwd_multi(int n, const float* const* Gi, const int32_t* step_off, int L, int H,
-                        const float* const* Whh, const float* const* bhh, float* const* h_last,
+                        const float* const* Whh, const float* const* bhh, float* const* h_last, int out_rows,
                         float* const* saved, void* stream) {
     if (n < 1 || n > MAXP) return RENET_ERR_BADARG;
-    if (L == 0) return RENET_OK;
     StepOff so;
-    int B;
-    if (!fill_offsets(step_off, L, so, B)) return RENET_ERR_BADARG;
-    if (B == 0) return RENET_OK;
+    int B = 0;
+    if (L == 0) {                                   // no steps at all: every row is h0
+        for (int j = 0; j <= MAXL; ++j) so.off[j] = 0;
+        L = 0;
+    } else if (!fill_offsets(step_off, L, so, B)) {
+        return RENET_ERR_BADARG;
+    }
+    if (out_rows < B) return RENET_ERR_BADARG;
+    if (out_rows == 0) return RENET_OK;
     FwdProbs ps;
     for (int i = 0; i < MAXP; ++i) {
         const int k = i < n ? i : 0;
@@ -307,18 +314,18 @@ int renet_gru_fwd_multi(int n, const float* const* Gi, const int32_t* step_off, 
     }
     hipStream_t st = (hipStream_t)stream;
     switch (H) {
-        case 100: return launch_fwd<100>(ps, n, so, L, B, st);
-        case 200: return launch_fwd<200>(ps, n, so, L, B, st);
-        case 400: return launch_fwd<400>(ps, n, so, L, B, st);
+        case 100: return launch_fwd<100>(ps, n, so, L, out_rows, st);
+        case 200: return launch_fwd<200>(ps, n, so, L, out_rows, st);
+        case 400: return launch_fwd<400>(ps, n, so, L, out_rows, st);
         default: return RENET_ERR_UNSUPPORTED;
     }
 }
 
 int renet_gru_fwd(const float* Gi, const int32_t* step_off, int L, int H, const float* Whh,
-                  const float* bhh, float* h_last, float* saved, float* workspace,
+                  const float* bhh, float* h_last, int out_rows, float* saved, float* workspace,
                   size_t workspace_bytes, void* stream) {
     (void)workspace; (void)workspace_bytes;
-    return renet_gru_fwd_multi(1, &Gi, step_off, L, H, &Whh, &bhh, &h_last, &saved, stream);
+    return renet_gru_fwd_multi(1, &Gi, step_off, L, H, &Whh, &bhh, &h_last, out_rows, &saved, stream);
 }
 
 int renet_gru_bwd_multi(int n, const float* const* dh_last, const int32_t* step_off, int L, int H,

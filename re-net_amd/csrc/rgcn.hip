@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kThreads) void rgcn_bwd_w_partial_kernel(
 // 4 waves split the chunk range, then an LDS tree over the 4 partial sums.
 __global__ __launch_bounds__(kThreads) void rgcn_bwd_w_reduce_kernel(
     const float4* __restrict__ partial, const int32_t* __restrict__ type_chunk_ptr, int WROW4,
-    int T, int shift, float4* __restrict__ dW) {
+    int T, int shift, float beta, float4* __restrict__ dW) {
     __shared__ float4 red[kWaves][64];
     const int t = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -422,7 +422,12 @@ __global__ __launch_bounds__(kThreads) void rgcn_bwd_w_reduce_kernel(
         float4 r = f4_add(f4_add(red[0][lane], red[1][lane]), f4_add(red[2][lane], red[3][lane]));
         int to = t + shift;
         if (to >= T) to -= T;
-        dW[(size_t)to * WROW4 + colq] = r;
+        float4* o = dW + (size_t)to * WROW4 + colq;
+        if (beta != 0.f) {
+            const float4 p = *o;
+            r = make_float4(r.x + beta * p.x, r.y + beta * p.y, r.z + beta * p.z, r.w + beta * p.w);
+        }
+        *o = r;
     }
 }
 
@@ -556,7 +561,7 @@ size_t renet_rgcn_bwd_w_workspace(int n_chunks, int D) {
 
 int renet_rgcn_bwd_w(const float* x, const float* gn, const int32_t* e_src, const int32_t* e_dst,
                      const int32_t* chunk_ptr, const int32_t* chunk_type, int n_chunks,
-                     const int32_t* type_chunk_ptr, int T, int type_shift, int D, float* dW,
+                     const int32_t* type_chunk_ptr, int T, int type_shift, int D, float* dW, float beta,
                      float* workspace, size_t workspace_bytes, void* stream) {
     (void)chunk_type;
     if (!renet_dim_ok(D)) return RENET_ERR_UNSUPPORTED;
@@ -587,7 +592,7 @@ int renet_rgcn_bwd_w(const float* x, const float* gn, const int32_t* e_src, cons
         RENET_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(rgcn_bwd_w_reduce_kernel, dim3(T, (WROW4 + 63) / 64), dim3(kThreads), 0, st,
-                       (const float4*)workspace, type_chunk_ptr, WROW4, T, type_shift, (float4*)dW);
+                       (const float4*)workspace, type_chunk_ptr, WROW4, T, type_shift, beta, (float4*)dW);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }

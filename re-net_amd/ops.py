@@ -85,6 +85,7 @@ class RGCNLayerFn(Function):
                       n_edges=g.E_out if pruned else None)
         ctx.g, ctx.relu, ctx.drop_p, ctx.seed, ctx.shift, ctx.n_out = g, relu, drop_p, seed, shift, n_out
         ctx.tgt_loop = grad_target(loop_weight)
+        ctx.tgt_w = grad_target(weight)
         ctx.save_for_backward(h, weight, loop_weight, out)
         return out
 
@@ -111,14 +112,15 @@ class RGCNLayerFn(Function):
         K.rgcn_gather(gn, g.row_ptr, g.col, g.etype, None, weight, pair_shift, True, dh, 0.0, 0, False, dh,
                       g.heavy_rows, g.heavy_thresh, n_out if pruned else 0, n_out if pruned else 0,
                       n_edges=g.E_out if pruned else None)
-        d_w = torch.empty_like(weight)
+        acc = ctx.tgt_w is not None                                    # straight into weight.grad (beta = 1)
+        d_w = ctx.tgt_w if acc else torch.empty_like(weight)
         if pruned:
             K.rgcn_bwd_w(h, gn, g.e_src2, g.e_dst2, g.chunk_ptr2, g.chunk_type2, g.n_chunks2, g.type_chunk_ptr2,
-                         g.num_types, ctx.shift, d_w)
+                         g.num_types, ctx.shift, d_w, beta=1.0 if acc else 0.0)
         else:
             K.rgcn_bwd_w(h, gn, g.e_src, g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr,
-                         g.num_types, ctx.shift, d_w)
-        return dh, d_w, d_loop, None, None, None, None, None, None
+                         g.num_types, ctx.shift, d_w, beta=1.0 if acc else 0.0)
+        return dh, None if acc else d_w, d_loop, None, None, None, None, None, None
 
 
 class SeqAssembleFn(Function):
@@ -166,13 +168,8 @@ class GRUFn(Function):
         x, w_ih, w_hh, b_ih, b_hh = _c(x), _c(w_ih), _c(w_hh), _c(b_ih), _c(b_hh)
         hdim = w_hh.shape[1]
         gi = K.gemm(x, w_ih, tb=True, bias=b_ih)                         # [S, 3H]
-        h_last, saved = K.gru_fwd(gi, step_off, hdim, w_hh, b_hh)
-        nnz = h_last.shape[0]
-        if total_rows > nnz:
-            full = torch.zeros(total_rows, hdim, device=x.device, dtype=torch.float32)
-            full[:nnz] = h_last
-        else:
-            full = h_last
+        full, saved = K.gru_fwd(gi, step_off, hdim, w_hh, b_hh, out_rows=total_rows)     # zero rows past nnz
+        nnz = int(step_off[1] - step_off[0]) if len(step_off) > 1 else 0
         ctx.step_off, ctx.nnz, ctx.hdim = step_off, nnz, hdim
         ctx.save_for_backward(x, w_ih, w_hh, saved)
         return full.unsqueeze(0)                 # h_n layout of nn.GRU: [1, B, H]
@@ -204,17 +201,13 @@ class DualGRUFn(Function):
         hdim = w_hh.shape[1]
         gi = K.gemm(x, w_ih, tb=True, bias=b_ih)
         gir = K.gemm(xr, w_ih_r, tb=True, bias=b_ih_r)
-        (h, q), (sv, svr) = K.gru_fwd_multi([gi, gir], step_off, hdim, [w_hh, w_hh_r], [b_hh, b_hh_r])
-        nnz = h.shape[0]
-        outs = []
-        for t in (h, q):
-            if total_rows > nnz:
-                full = torch.zeros(total_rows, hdim, device=x.device, dtype=torch.float32)
-                full[:nnz] = t
-                t = full
-            outs.append(t.unsqueeze(0))
+        (h, q), (sv, svr) = K.gru_fwd_multi([gi, gir], step_off, hdim, [w_hh, w_hh_r], [b_hh, b_hh_r],
+                                            out_rows=total_rows)                 # rows past nnz are zero
+        nnz = int(step_off[1] - step_off[0]) if len(step_off) > 1 else 0
+        outs = [h.unsqueeze(0), q.unsqueeze(0)]
         ctx.step_off, ctx.nnz, ctx.hdim = step_off, nnz, hdim
         ctx.tgts = [grad_target(t) for t in (w_ih, w_hh, w_ih_r, w_hh_r)]
+        ctx.btgts = [grad_target(t) for t in (b_ih, b_hh, b_ih_r, b_hh_r)]
         ctx.save_for_backward(x, xr, w_ih, w_hh, w_ih_r, w_hh_r, sv, svr)
         return outs[0], outs[1]
 
@@ -237,7 +230,17 @@ class DualGRUFn(Function):
                 dwh_ = None
             else:
                 dwh_ = K.gemm(dgh, s_[:, 4 * hdim:], ta=True)
-            res.append((K.gemm(dgi, wi), dwi_, dwh_, K.colsum(dgi), K.colsum(dgh)))
+            t_bi, t_bh = ctx.btgts[2 * k], ctx.btgts[2 * k + 1]
+            dbi_ = dbh_ = None
+            if t_bi is not None:
+                K.colsum(dgi, out=t_bi, beta=1.0)
+            else:
+                dbi_ = K.colsum(dgi)
+            if t_bh is not None:
+                K.colsum(dgh, out=t_bh, beta=1.0)
+            else:
+                dbh_ = K.colsum(dgh)
+            res.append((K.gemm(dgi, wi), dwi_, dwh_, dbi_, dbh_))
         (dx, dwi, dwh, dbi, dbh), (dxr, dwir, dwhr, dbir, dbhr) = res
         return dx, dxr, dwi, dwh, dbi, dbh, dwir, dwhr, dbir, dbhr, None, None
 
@@ -260,21 +263,34 @@ class HeadCEFn(Function):
                     c.shape if c is not None else None)
         if need_grad:
             ctx.save_for_backward(feat, logits, weight)
-            ctx.tgts = (grad_target(a), grad_target(c) if c is not None else None, grad_target(weight))
+            ctx.tgts = (grad_target(a), grad_target(c) if c is not None else None, grad_target(weight),
+                        grad_target(bias))
+            ctx.consumed = False
         return row_loss.mean()
 
     @staticmethod
     def backward(ctx, g):
         feat, dlogits, weight = ctx.saved_tensors
         d, parts, drop_p, seed, plan_a, plan_c, a_shape, c_shape = ctx.meta
-        t_a, t_c, t_w = ctx.tgts
-        dfeat = K.gemm(dlogits, weight) * g                              # [B, parts*D]
+        t_a, t_c, t_w, t_b = ctx.tgts
+        if ctx.consumed:
+            raise RuntimeError('HeadCEFn: the saved (softmax - onehot) buffer was scaled in place by the first '
+                               'backward pass; a second pass over the same graph is not supported')
+        ctx.consumed = True
+        # every gradient below is linear in dlogits: fold the upstream scalar (1 for `loss_s + loss_o`, 0.1 for
+        # the relation head) into it ONCE, from device memory, instead of scaling three results
+        K.scale_by_device_scalar(dlogits, g)
+        dfeat = K.gemm(dlogits, weight)                                  # [B, parts*D]
         if t_w is not None:
-            K.gemm(dlogits, feat * g, ta=True, out=t_w, beta=1.0)
+            K.gemm(dlogits, feat, ta=True, out=t_w, beta=1.0)
             d_w = None
         else:
-            d_w = K.gemm(dlogits, feat * g, ta=True)
-        d_b = K.colsum(dlogits) * g
+            d_w = K.gemm(dlogits, feat, ta=True)
+        if t_b is not None:
+            K.colsum(dlogits, out=t_b, beta=1.0)
+            d_b = None
+        else:
+            d_b = K.colsum(dlogits)
         da_rows, dh, dc_rows = K.concat3_bwd(dfeat, d, parts, drop_p, seed)
         d_a = d_c = None
         if t_a is not None:

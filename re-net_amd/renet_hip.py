@@ -31,26 +31,27 @@ _SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p]),
     'renet_rgcn_bwd_w_workspace': (c_size_t, [c_int, c_int]),
     'renet_rgcn_bwd_w': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                 c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                 c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     'renet_gemm_workspace': (c_size_t, [c_int, c_int, c_int]),
     'renet_gemm_f32': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'renet_gemm_f32_split': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                      c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'renet_colsum_workspace': (c_size_t, [c_int, c_int]),
-    'renet_colsum': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'renet_colsum': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    'renet_scale_by_device_scalar': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     'renet_seq_assemble_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_void_p,
                                        c_void_p]),
     'renet_seq_assemble_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                        c_u64, c_u64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'renet_gru_workspace': (c_size_t, [c_int, c_int]),
-    'renet_gru_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+    'renet_gru_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                               c_void_p, c_size_t, c_void_p]),
     'renet_gru_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_size_t, c_void_p]),
     'renet_gru_fwd_multi': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_void_p]),
+                                    c_int, c_void_p, c_void_p]),
     'renet_gru_bwd_multi': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_concat3_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
@@ -204,14 +205,14 @@ def rgcn_bwd_prep(g_out, out, norm, relu, drop_p, seed, gn, g_loop):
 
 
 def rgcn_bwd_w(x, gn, e_src, e_dst, chunk_ptr, chunk_type, n_chunks, type_chunk_ptr, num_types, type_shift,
-               dW):
+               dW, beta=0.0):
     d = x.shape[1]
     nbytes = lib().renet_rgcn_bwd_w_workspace(n_chunks, d)
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
     t0 = _timer.begin() if _timer is not None else None
     _check(lib().renet_rgcn_bwd_w(_f32(x), _f32(gn), _i32(e_src), _i32(e_dst), _i32(chunk_ptr),
                                   _i32(chunk_type), n_chunks, _i32(type_chunk_ptr), num_types, type_shift, d,
-                                  _f32(dW), ws.data_ptr(), nbytes, _stream()), 'rgcn_bwd_w')
+                                  _f32(dW), float(beta), ws.data_ptr(), nbytes, _stream()), 'rgcn_bwd_w')
     if t0 is not None:      # SURVEY 8d backward-W: E * 2 rows + indices, dW written once
         _timer.end('rgcn_bwd_w', t0, nbytes=float(e_src.numel() * (2 * d * 4 + 8) + dW.numel() * 4))
     return dW
@@ -281,15 +282,26 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, spl
     return out
 
 
-def colsum(x, out=None):
+def colsum(x, out=None, beta=0.0):
+    """out = beta * out + column sums of x."""
     m, n = x.shape
     if out is None:
+        if beta != 0.0:
+            raise RenetHipError('beta != 0 needs an output tensor')
         out = torch.empty(n, device=x.device, dtype=torch.float32)
     nbytes = lib().renet_colsum_workspace(m, n)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32) if nbytes else None
-    _check(lib().renet_colsum(x.data_ptr(), m, n, _ld(x), _f32(out), ws.data_ptr() if nbytes else None, nbytes,
-                              _stream()), 'colsum')
+    _check(lib().renet_colsum(x.data_ptr(), m, n, _ld(x), _f32(out), float(beta), ws.data_ptr() if nbytes else None,
+                              nbytes, _stream()), 'colsum')
     return out
+
+
+def scale_by_device_scalar(x, g):
+    """x *= g in place, g a 0-dim / 1-element DEVICE tensor (no host sync; g == 1 leaves x untouched)."""
+    if not x.is_contiguous():
+        raise RenetHipError('scale_by_device_scalar needs a contiguous tensor')
+    _check(lib().renet_scale_by_device_scalar(_f32(x), x.numel(), _f32(g), _stream()), 'scale_by_device_scalar')
+    return x
 
 
 def seq_assemble_fwd(h2, ent, rel, glob, subj_row, row_ent, row_rel, glob_row, drop_p, seed_x, seed_xr):
@@ -315,17 +327,19 @@ def seq_assemble_bwd(dx, dxr, step_off, num_steps, num_seq, d, drop_p, seed_x, s
     return d_rows, d_ent, d_rel
 
 
-def gru_fwd(gi, step_off_host, hdim, w_hh, b_hh):
-    """gi [S,3H] packed; step_off_host: ctypes int32 array (L+1).  Returns (h_last[B,H], saved[S,5H])."""
+def gru_fwd(gi, step_off_host, hdim, w_hh, b_hh, out_rows=0):
+    """gi [S,3H] packed; step_off_host: ctypes int32 array (L+1).  Returns (h_last[max(B, out_rows), H] with
+    rows >= B zero, saved[S,5H])."""
     L = len(step_off_host) - 1
     s = gi.shape[0]
     b = step_off_host[1] - step_off_host[0] if L > 0 else 0
-    h_last = torch.empty(b, hdim, device=gi.device, dtype=torch.float32)
+    out_rows = max(int(out_rows), b)
+    h_last = torch.empty(out_rows, hdim, device=gi.device, dtype=torch.float32)
     saved = torch.empty(s, 5 * hdim, device=gi.device, dtype=torch.float32)
     nbytes = lib().renet_gru_workspace(b, hdim)
     ws = torch.empty(max(nbytes // 4, 1), device=gi.device, dtype=torch.float32)
     _check(lib().renet_gru_fwd(_f32(gi), ctypes.cast(step_off_host, c_void_p), L, hdim, _f32(w_hh), _f32(b_hh),
-                               _f32(h_last), _f32(saved), ws.data_ptr(), nbytes, _stream()), 'gru_fwd')
+                               _f32(h_last), out_rows, _f32(saved), ws.data_ptr(), nbytes, _stream()), 'gru_fwd')
     return h_last, saved
 
 
@@ -346,17 +360,19 @@ def _ptrs(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def gru_fwd_multi(gis, step_off_host, hdim, w_hhs, b_hhs):
-    """n GRUs over the same packed layout in one launch -> ([h_last...], [saved...])."""
+def gru_fwd_multi(gis, step_off_host, hdim, w_hhs, b_hhs, out_rows=0):
+    """n GRUs over the same packed layout in one launch -> ([h_last...], [saved...]); h_last has
+    max(B, out_rows) rows, the ones past B zero."""
     L = len(step_off_host) - 1
     b = step_off_host[1] - step_off_host[0] if L > 0 else 0
+    out_rows = max(int(out_rows), b)
     dev = gis[0].device
-    hs = [torch.empty(b, hdim, device=dev, dtype=torch.float32) for _ in gis]
+    hs = [torch.empty(out_rows, hdim, device=dev, dtype=torch.float32) for _ in gis]
     svs = [torch.empty(g.shape[0], 5 * hdim, device=dev, dtype=torch.float32) for g in gis]
     for t in list(gis) + list(w_hhs) + list(b_hhs):
         _f32(t)
     _check(lib().renet_gru_fwd_multi(len(gis), _ptrs(gis), ctypes.cast(step_off_host, c_void_p), L, hdim,
-                                     _ptrs(w_hhs), _ptrs(b_hhs), _ptrs(hs), _ptrs(svs), _stream()),
+                                     _ptrs(w_hhs), _ptrs(b_hhs), _ptrs(hs), out_rows, _ptrs(svs), _stream()),
            'gru_fwd_multi')
     return hs, svs
 

@@ -99,6 +99,15 @@ def test_gemm_splitk_beta_and_strided_views(dev):
     assert torch.equal(one, two), 'split-K must be deterministic'
     cs = K.colsum(_to(big, dev)[:, 100:333])
     np.testing.assert_allclose(cs.cpu().numpy(), big[:, 100:333].astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
+    K.colsum(_to(big, dev)[:, 100:333], out=cs, beta=1.0)                   # accumulate into an existing buffer
+    np.testing.assert_allclose(cs.cpu().numpy(), 2 * big[:, 100:333].astype(np.float64).sum(0), rtol=1e-5, atol=2e-3)
+    x = _to(big, dev).clone()
+    for f in (1.0, 0.1):
+        K.scale_by_device_scalar(x, torch.tensor(f, device=dev))
+    np.testing.assert_allclose(x.cpu().numpy(), big * np.float32(0.1), rtol=1e-6)
+    odd = _to(big.reshape(-1)[:1003].copy(), dev)                           # n % 4 != 0
+    K.scale_by_device_scalar(odd, torch.tensor(3.0, device=dev))
+    np.testing.assert_allclose(odd.cpu().numpy(), big.reshape(-1)[:1003] * np.float32(3.0), rtol=1e-6)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -414,6 +423,10 @@ def test_full_size_dw_matches_fp64_sampled(dev):
     K.rgcn_bwd_w(x, gn, g.e_src, g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr, 2 * R, 0, dw)
     dw2 = torch.empty_like(dw)
     K.rgcn_bwd_w(x, gn, g.e_src, g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr, 2 * R, 0, dw2)
+    acc = dw.clone()                                      # beta = 1: accumulate into an existing gradient
+    K.rgcn_bwd_w(x, gn, g.e_src, g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr, 2 * R, 0, acc,
+                 beta=1.0)
+    assert torch.equal(acc, dw + dw)
     assert torch.equal(dw, dw2)
     xc, gc = x.cpu().double().numpy(), gn.cpu().double().numpy()
     got = dw.cpu().numpy()
