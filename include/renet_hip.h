@@ -167,7 +167,10 @@ int renet_seq_assemble_bwd(const float* dX, const float* dXr, const int32_t* ste
  *                    histories, model.py:88): out_rows >= B
  *   saved   [S, 5H]  per packed row: r, z, n, (W_hn h + b_hn), h_prev   (consumed by backward)
  * Backward: given dh_last[B,H] produces dGi[S,3H], dGh[S,3H] (caller forms dW_ih, dW_hh, biases,
- * dX with renet_gemm_f32 / renet_colsum) ; `dh_work`[B,H] is scratch.
+ * dX with renet_gemm_f32 / renet_colsum).
+ * `workspace` = renet_gru_workspace(B, H) bytes per GRU, for both directions: the bf16 planes of W_hh
+ * (forward) / W_hh^T and its planes (backward) -- the recurrent products run as "bf16x6" like
+ * renet_gemm_f32_split unless RENET_GEMM=f32 selects the exact-fp32 MFMA kernels.
  * ---------------------------------------------------------------------------------------------- */
 size_t renet_gru_workspace(int B, int H);
 int renet_gru_fwd(const float* Gi, const int32_t* step_off, int L, int H, const float* Whh,
@@ -178,10 +181,10 @@ int renet_gru_bwd(const float* dh_last, const int32_t* step_off, int L, int H, c
                   size_t workspace_bytes, void* stream);
 /* n (1 or 2) independent GRUs over the SAME packed layout in one launch (RE-Net's `encoder` and
  * `encoder_r`, model.py:86,94): every pointer argument is a HOST array of n device pointers;
- * the backward workspace is n * renet_gru_workspace bytes. */
+ * the workspace is n * renet_gru_workspace bytes. */
 int renet_gru_fwd_multi(int n, const float* const* Gi, const int32_t* step_off, int L, int H,
                         const float* const* Whh, const float* const* bhh, float* const* h_last, int out_rows,
-                        float* const* saved, void* stream);
+                        float* const* saved, float* workspace, size_t workspace_bytes, void* stream);
 int renet_gru_bwd_multi(int n, const float* const* dh_last, const int32_t* step_off, int L, int H,
                         const float* const* Whh, const float* const* saved, float* const* dGi,
                         float* const* dGh, float* workspace, size_t workspace_bytes, void* stream);

@@ -51,7 +51,7 @@ _SIGNATURES = {
     'renet_gru_bwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_size_t, c_void_p]),
     'renet_gru_fwd_multi': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                    c_int, c_void_p, c_void_p]),
+                                    c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_gru_bwd_multi': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_concat3_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
@@ -371,9 +371,11 @@ def gru_fwd_multi(gis, step_off_host, hdim, w_hhs, b_hhs, out_rows=0):
     svs = [torch.empty(g.shape[0], 5 * hdim, device=dev, dtype=torch.float32) for g in gis]
     for t in list(gis) + list(w_hhs) + list(b_hhs):
         _f32(t)
+    nbytes = len(gis) * lib().renet_gru_workspace(b, hdim)
+    ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
     _check(lib().renet_gru_fwd_multi(len(gis), _ptrs(gis), ctypes.cast(step_off_host, c_void_p), L, hdim,
-                                     _ptrs(w_hhs), _ptrs(b_hhs), _ptrs(hs), out_rows, _ptrs(svs), _stream()),
-           'gru_fwd_multi')
+                                     _ptrs(w_hhs), _ptrs(b_hhs), _ptrs(hs), out_rows, _ptrs(svs), ws.data_ptr(),
+                                     nbytes, _stream()), 'gru_fwd_multi')
     return hs, svs
 
 
