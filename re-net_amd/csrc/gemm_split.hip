@@ -634,6 +634,38 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(const float* __restri
     }
 }
 
+// The same reduction for SMALL outputs with many slices (dW of the 200x200 / 600x200 weights: 40k-120k elements,
+// 39-128 slices): one thread per element leaves most of the chip idle and walks the slices serially, so the 4
+// waves of a workgroup split the slices (wave w takes z = w, w+4, ...: every load a coalesced 256-byte row
+// segment) and combine through LDS in a fixed order.
+__global__ __launch_bounds__(256) void split_reduce4_kernel(const float* __restrict__ partial, int split_k,
+                                                            int M, int N, float alpha, float beta,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ C, int ldc) {
+    __shared__ float red[4][64];
+    const size_t total = (size_t)M * N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < total) {
+        int zz = wave;
+        for (; zz + 4 < split_k; zz += 8) {
+            s0 += partial[(size_t)zz * total + i];
+            s1 += partial[(size_t)(zz + 4) * total + i];
+        }
+        if (zz < split_k) s0 += partial[(size_t)zz * total + i];
+    }
+    red[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && i < total) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        float v = alpha * s + (bias ? bias[n] : 0.f);
+        float* p = C + (size_t)m * ldc + n;
+        if (beta != 0.f) v += beta * (*p);
+        *p = v;
+    }
+}
 
 template <bool TA, bool TB>
 int launch_fused(const SplitArgs& g, dim3 grid, hipStream_t st) {
@@ -715,9 +747,14 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
     RENET_LAUNCH_CHECK();
     if (split_k > 1) {
         const size_t total = (size_t)M * N;
-        int blocks = (int)min((size_t)2048, (total + 255) / 256);
-        hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, split_k, M, N, alpha,
-                           beta, bias, C, ldc);
+        if (total <= (size_t)256 * 1024 && split_k >= 8) {
+            hipLaunchKernelGGL(split_reduce4_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, workspace,
+                               split_k, M, N, alpha, beta, bias, C, ldc);
+        } else {
+            int blocks = (int)min((size_t)2048, (total + 255) / 256);
+            hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, split_k, M, N, alpha,
+                               beta, bias, C, ldc);
+        }
         RENET_LAUNCH_CHECK();
     }
     return RENET_OK;

@@ -414,7 +414,19 @@ __global__ __launch_bounds__(kThreads) void rgcn_bwd_w_reduce_kernel(
     const int c0 = type_chunk_ptr[t], c1 = type_chunk_ptr[t + 1];
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (colq < WROW4) {
-        for (int c = c0 + wave; c < c1; c += kWaves) s = f4_add(s, partial[(size_t)c * WROW4 + colq]);
+        // relation frequencies are Zipf-like: the hottest type owns hundreds of chunks.  Four independent
+        // partial-sum loads in flight per wave (fixed association order => still deterministic)
+        float4 s1 = s, s2 = s, s3 = s;
+        int c = c0 + wave;
+        for (; c + 3 * kWaves < c1; c += 4 * kWaves) {
+            const float4 v0 = partial[(size_t)c * WROW4 + colq];
+            const float4 v1 = partial[(size_t)(c + kWaves) * WROW4 + colq];
+            const float4 v2 = partial[(size_t)(c + 2 * kWaves) * WROW4 + colq];
+            const float4 v3 = partial[(size_t)(c + 3 * kWaves) * WROW4 + colq];
+            s = f4_add(s, v0); s1 = f4_add(s1, v1); s2 = f4_add(s2, v2); s3 = f4_add(s3, v3);
+        }
+        for (; c < c1; c += kWaves) s = f4_add(s, partial[(size_t)c * WROW4 + colq]);
+        s = f4_add(f4_add(s, s1), f4_add(s2, s3));
     }
     red[wave][lane] = s;
     __syncthreads();
