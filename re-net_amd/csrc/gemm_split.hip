@@ -45,6 +45,7 @@ struct SplitArgs {
     int k_tiles_per_split;
     int split_k;
     float* partial;
+    int xcd_order;          // 1: XCD-aware virtual tile order (tile_of_block)
 };
 
 
@@ -65,6 +66,22 @@ __device__ __forceinline__ void trace_put(int wave8, int step, int slot, unsigne
 #define TRACE_T(wave8, step, slot)
 #define TRACE_V(wave8, step, slot, v)
 #endif
+
+// Tile of this workgroup.  The dispatcher deals workgroups to the 8 XCDs round-robin (block b -> XCD b % 8, each
+// XCD with its own 4 MB L2), so the plain (blockIdx.x, blockIdx.y) order makes every XCD sweep the WHOLE of the
+// long operand once per tile row of the short one (PMC: 215 MB of fabric traffic per GEMM launch of the step
+// against ~60 MB of operands + output).  Virtual order instead: XCD x owns one contiguous 1/8 of the tile
+// sequence, and in that sequence the SHORT grid dimension runs fastest, so the tiles that share a slab of the
+// long operand are consecutive on one XCD and the slab is fetched once.  RENET_GEMM_TILE_ORDER=0 in the
+// environment restores the plain order (tools/gemm_bench.py).
+__device__ __forceinline__ void tile_of_block(int nbx, int nby, bool xcd_order, int& bx, int& by) {
+    if (!xcd_order) { bx = blockIdx.x; by = blockIdx.y; return; }
+    const int nb = nbx * nby, per = nb >> 3;
+    const int L = blockIdx.x + nbx * blockIdx.y;
+    const int t = L < 8 * per ? (L & 7) * per + (L >> 3) : L;
+    if (nby <= nbx) { bx = t / nby; by = t - bx * nby; }
+    else { by = t / nbx; bx = t - by * nbx; }
+}
 
 // item i of this thread (f = tid + threads * i) of a ROWS x 32 operand tile:
 //   CONTIG_K: row = f>>3, k = 4*(f&7);  else: row = f % ROWS, k = 4*(f / ROWS)
@@ -291,7 +308,9 @@ __global__ __launch_bounds__(THREADS) void gemm_split_kernel(SplitArgs g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int bx, by;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    const int m0 = by * BM, n0 = bx * BN;
     const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;
     const int kt_total = (g.K + BK - 1) / BK;
@@ -555,7 +574,9 @@ __global__ __launch_bounds__(THREADS) void gemm_split_fused_kernel(SplitArgs g) 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int bx, by;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    const int m0 = by * BM, n0 = bx * BN;
     const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;
     const int kt_total = (g.K + BK - 1) / BK;
@@ -667,6 +688,15 @@ __global__ __launch_bounds__(256) void split_reduce4_kernel(const float* __restr
     }
 }
 
+int tile_order() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RENET_GEMM_TILE_ORDER");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+
 template <bool TA, bool TB>
 int launch_fused(const SplitArgs& g, dim3 grid, hipStream_t st) {
     static bool attr_set = false;      // benign race: the attribute is idempotent
@@ -722,6 +752,7 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
     g.split_k = split_k;
     g.k_tiles_per_split = max(1, (kt_total + split_k - 1) / split_k);
     g.partial = workspace;
+    g.xcd_order = tile_order();
     hipStream_t st = (hipStream_t)stream;
     const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
     const int ntiles = nbx * nby * split_k;
