@@ -70,17 +70,24 @@ __device__ __forceinline__ void trace_put(int wave8, int step, int slot, unsigne
 // Tile of this workgroup.  The dispatcher deals workgroups to the 8 XCDs round-robin (block b -> XCD b % 8, each
 // XCD with its own 4 MB L2), so the plain (blockIdx.x, blockIdx.y) order makes every XCD sweep the WHOLE of the
 // long operand once per tile row of the short one (PMC: 215 MB of fabric traffic per GEMM launch of the step
-// against ~60 MB of operands + output).  Virtual order instead: XCD x owns one contiguous 1/8 of the tile
-// sequence, and in that sequence the SHORT grid dimension runs fastest, so the tiles that share a slab of the
-// long operand are consecutive on one XCD and the slab is fetched once.  RENET_GEMM_TILE_ORDER=0 in the
-// environment restores the plain order (tools/gemm_bench.py).
+// against ~60 MB of operands + output; 127 MB with this order).  Virtual order instead: XCD x owns one contiguous
+// 1/8 of the tile sequence, and in that sequence the SHORT grid dimension runs fastest, so the tiles that share
+// a slab of the long operand are consecutive on one XCD and the slab is fetched once.  RENET_GEMM_TILE_ORDER=0
+// in the environment restores the plain order (tools/gemm_bench.py).
 __device__ __forceinline__ void tile_of_block(int nbx, int nby, bool xcd_order, int& bx, int& by) {
     if (!xcd_order) { bx = blockIdx.x; by = blockIdx.y; return; }
     const int nb = nbx * nby, per = nb >> 3;
     const int L = blockIdx.x + nbx * blockIdx.y;
     const int t = L < 8 * per ? (L & 7) * per + (L >> 3) : L;
-    if (nby <= nbx) { bx = t / nby; by = t - bx * nby; }
-    else { by = t / nbx; bx = t - by * nbx; }
+    // sequence: panels of <= 8 tiles across the SHORT dimension, the long dimension sweeping each panel
+    // (a square problem becomes 8 x 8 blocks of concurrently resident tiles per XCD instead of 2 x 32)
+    const int ns = min(nbx, nby), nl = max(nbx, nby);
+    const int w = min(ns, 8);
+    const int p = t / (w * nl), r = t - p * (w * nl);
+    const int wp = min(w, ns - p * w);                       // width of this (possibly last, narrower) panel
+    const int l = r / wp, sh = p * w + (r - l * wp);
+    if (nby <= nbx) { bx = l; by = sh; }
+    else { by = l; bx = sh; }
 }
 
 // item i of this thread (f = tid + threads * i) of a ROWS x 32 operand tile:
