@@ -225,24 +225,25 @@ def _ld(t):
 
 
 def auto_split_k(m, n, k):
-    """split-K factor when the output has too few 128x128 tiles to fill 256 CUs (weight-gradient and
-    dX-of-the-head shapes): aim at ~2 workgroups per CU, keep >= 4 k-tiles per slice."""
+    """Deterministic split-K factor for outputs with too few 128x128 tiles to fill the chip (weight-gradient and
+    dX-of-the-head shapes), from a small cost model in units of one k-tile step of a workgroup (~1.5 us):
+        T(s) = rounds(tiles * s / 512 slots) * (ktiles / s + 6 [prologue + C store]) + s * M*N * 2.7e-6 [partial
+        sums written and re-read by the reduce kernel]
+    It reproduces the factors swept on MI355X (tools/gemm_sweep.py: dfeat 40 tiles -> 12 slices, dW_ih 35 -> 14,
+    dW_loop 4 -> 128) and, unlike a pure fill heuristic, still splits a single-tile output (n_hidden = 100:
+    100x100xK=46k would otherwise run 1440 k-tiles in ONE workgroup)."""
     tiles = ((m + 127) // 128) * ((n + 127) // 128)
-    # the partial sums cost split * M * N * 8 bytes of traffic plus a reduce launch: only worth it while the
-    # un-split grid would leave more than half of the 256 CUs idle
-    if tiles >= 128:
-        return 1
     ktiles = (k + 31) // 32
-    # 2 workgroups are resident per CU (73.7 KB LDS each) => rounds of 512.  Swept on MI355X
-    # (tools/gemm_sweep.py): the best split fills one or two rounds almost exactly (40 tiles -> 12 slices =
-    # 480 workgroups; 35 -> 14; 300 -> 3) and more slices only add partial-sum traffic.
-    smax = int(max(1, min(128, ktiles // 6, max(1024 // tiles, 1))))
-    best, best_score = 1, -1.0
+    if tiles >= 256 or ktiles < 8:
+        return 1
+    smax = int(max(1, min(128, ktiles // 4)))
+    per_slice = m * n * 2.7e-6
+    best, best_t = 1, None
     for s in range(1, smax + 1):
-        wgs = tiles * s
-        score = wgs / float(((wgs + 511) // 512) * 512) - 0.004 * s
-        if score > best_score + 1e-12:
-            best, best_score = s, score
+        rounds = (tiles * s + 511) // 512
+        t = rounds * (ktiles / float(s) + 6.0) + (per_slice * s if s > 1 else 0.0)
+        if best_t is None or t < best_t - 1e-9:
+            best, best_t = s, t
     return best
 
 

@@ -437,6 +437,21 @@ def test_full_size_dw_matches_fp64_sampled(dev):
         np.testing.assert_allclose(got[t], ref, rtol=1e-4, atol=1e-4 * max(1.0, len(e)) ** 0.5)
 
 
+def test_exact_fp32_mode_in_a_subprocess(dev):
+    """RENET_GEMM=f32 selects the exact-fp32 MFMA kernels (gemm.hip, gru_fwd/bwd_kernel) for the whole library;
+    the switch is read once per process, so the GRU / training-step parity tests are re-run in a child process."""
+    import subprocess
+    import sys
+    if os.environ.get('RENET_GEMM') == 'f32':
+        pytest.skip('already running in f32 mode')
+    env = dict(os.environ, RENET_GEMM='f32')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-x', '-k',
+                        'gru_matches_torch_cpu or training_step or global_model'], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'no tests ran' not in r.stdout
+
+
 # ---------------------------------------------------------------------------------------------
 # multi-step inference (model.py:216-419): evaluate_filter trajectory vs the reference (golden)
 # ---------------------------------------------------------------------------------------------
