@@ -4,6 +4,16 @@
 #include <stdint.h>
 #include "../../include/renet_hip.h"
 
+// hipGetLastError() reports the last error of ANY earlier runtime call on this thread -- including calls made
+// by the host framework that are expected to fail and are never cleared (PyTorch probing a host pointer with
+// hipPointerGetAttributes leaves hipErrorInvalidValue behind).  Every launch therefore clears the slot first,
+// so that RENET_LAUNCH_CHECK() sees the status of OUR launch only.
+#define RENET_LAUNCH(...)                         \
+    do {                                          \
+        (void)hipGetLastError();                  \
+        hipLaunchKernelGGL(__VA_ARGS__);          \
+    } while (0)
+
 #define RENET_LAUNCH_CHECK()                      \
     do {                                          \
         hipError_t e__ = hipGetLastError();       \

@@ -350,15 +350,15 @@ int renet_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, const float
     g.partial = workspace;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, split_k);
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(THREADS), 0, st, g);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(THREADS), 0, st, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(THREADS), 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
+    if (!ta && !tb) RENET_LAUNCH((gemm_f32_kernel<false, false>), grid, dim3(THREADS), 0, st, g);
+    else if (!ta && tb) RENET_LAUNCH((gemm_f32_kernel<false, true>), grid, dim3(THREADS), 0, st, g);
+    else if (ta && !tb) RENET_LAUNCH((gemm_f32_kernel<true, false>), grid, dim3(THREADS), 0, st, g);
+    else RENET_LAUNCH((gemm_f32_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
     RENET_LAUNCH_CHECK();
     if (split_k > 1) {
         const size_t total = (size_t)M * N;
         int blocks = (int)min((size_t)2048, (total + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, split_k, M, N,
+        RENET_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, split_k, M, N,
                            alpha, beta, bias, C, ldc);
         RENET_LAUNCH_CHECK();
     }
@@ -374,7 +374,7 @@ int renet_scale_by_device_scalar(float* x, size_t n, const float* scale, void* s
     if (!x || !scale || (reinterpret_cast<uintptr_t>(x) & 15)) return RENET_ERR_BADARG;
     if (n == 0) return RENET_OK;
     const int blocks = (int)min((size_t)2048, (n / 4 + 255) / 256 + 1);
-    hipLaunchKernelGGL(scale_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, scale);
+    RENET_LAUNCH(scale_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, scale);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -385,15 +385,15 @@ int renet_colsum(const float* X, int M, int N, int ldx, float* out, float beta, 
     const int G = colsum_groups(M);
     hipStream_t st = (hipStream_t)stream;
     if (G == 1) {
-        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, st, X, M, N, ldx, max(M, 1), beta, out);
+        RENET_LAUNCH(colsum_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, st, X, M, N, ldx, max(M, 1), beta, out);
         RENET_LAUNCH_CHECK();
         return RENET_OK;
     }
     if (workspace_bytes < renet_colsum_workspace(M, N)) return RENET_ERR_WORKSPACE;
     const int rpg = (M + G - 1) / G;
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, G), dim3(256), 0, st, X, M, N, ldx, rpg, 0.f, workspace);
+    RENET_LAUNCH(colsum_kernel, dim3((N + 63) / 64, G), dim3(256), 0, st, X, M, N, ldx, rpg, 0.f, workspace);
     RENET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, st, workspace, G, N, N, G, beta, out);
+    RENET_LAUNCH(colsum_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, st, workspace, G, N, N, G, beta, out);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }

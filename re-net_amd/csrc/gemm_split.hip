@@ -713,7 +713,7 @@ int launch_fused(const SplitArgs& g, dim3 grid, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_split_fused_kernel<TA, TB>), grid, dim3(THREADS), FUSED_LDS, st, g);
+    RENET_LAUNCH((gemm_split_fused_kernel<TA, TB>), grid, dim3(THREADS), FUSED_LDS, st, g);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -776,21 +776,21 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
         else e = launch_fused<true, true>(g, grid, st);
     } else {
         dim3 grid(nbx, nby, split_k);
-        if (!ta && !tb) hipLaunchKernelGGL((gemm_split_kernel<false, false>), grid, dim3(THREADS), 0, st, g);
-        else if (!ta && tb) hipLaunchKernelGGL((gemm_split_kernel<false, true>), grid, dim3(THREADS), 0, st, g);
-        else if (ta && !tb) hipLaunchKernelGGL((gemm_split_kernel<true, false>), grid, dim3(THREADS), 0, st, g);
-        else hipLaunchKernelGGL((gemm_split_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
+        if (!ta && !tb) RENET_LAUNCH((gemm_split_kernel<false, false>), grid, dim3(THREADS), 0, st, g);
+        else if (!ta && tb) RENET_LAUNCH((gemm_split_kernel<false, true>), grid, dim3(THREADS), 0, st, g);
+        else if (ta && !tb) RENET_LAUNCH((gemm_split_kernel<true, false>), grid, dim3(THREADS), 0, st, g);
+        else RENET_LAUNCH((gemm_split_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
     }
     if (e != RENET_OK) return e;
     RENET_LAUNCH_CHECK();
     if (split_k > 1) {
         const size_t total = (size_t)M * N;
         if (total <= (size_t)256 * 1024 && split_k >= 8) {
-            hipLaunchKernelGGL(split_reduce4_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, workspace,
+            RENET_LAUNCH(split_reduce4_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, workspace,
                                split_k, M, N, alpha, beta, bias, C, ldc);
         } else {
             int blocks = (int)min((size_t)2048, (total + 255) / 256);
-            hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, split_k, M, N, alpha,
+            RENET_LAUNCH(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, split_k, M, N, alpha,
                                beta, bias, C, ldc);
         }
         RENET_LAUNCH_CHECK();

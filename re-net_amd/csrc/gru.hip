@@ -534,7 +534,7 @@ int set_lds(KernelT kernel, size_t lds, bool& done) {
 
 template <int H>
 int launch_fwd(const FwdProbs& ps, int np, const StepOff& so, int L, int out_rows, hipStream_t st) {
-    hipLaunchKernelGGL((gru_fwd_kernel<H>), dim3((out_rows + MT - 1) / MT, np), dim3(NT), 0, st, ps, so, L,
+    RENET_LAUNCH((gru_fwd_kernel<H>), dim3((out_rows + MT - 1) / MT, np), dim3(NT), 0, st, ps, so, L,
                        out_rows);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
@@ -547,7 +547,7 @@ int launch_fwd_bf(const FwdProbsB& ps, int np, const StepOff& so, int L, int out
     static bool attr_set = false;
     const int e = set_lds(gru_fwd_bf_kernel<H>, lds, attr_set);
     if (e != RENET_OK) return e;
-    hipLaunchKernelGGL((gru_fwd_bf_kernel<H>), dim3((out_rows + MT - 1) / MT, np), dim3(NT), lds, st, ps, so, L,
+    RENET_LAUNCH((gru_fwd_bf_kernel<H>), dim3((out_rows + MT - 1) / MT, np), dim3(NT), lds, st, ps, so, L,
                        out_rows);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
@@ -560,7 +560,7 @@ int launch_bwd(const BwdProbs& ps, int np, const StepOff& so, int L, int B, hipS
     static bool attr_set = false;
     const int e = set_lds(gru_bwd_kernel<H>, lds, attr_set);
     if (e != RENET_OK) return e;
-    hipLaunchKernelGGL((gru_bwd_kernel<H>), dim3((B + MT - 1) / MT, np), dim3(NT), lds, st, ps, so, L);
+    RENET_LAUNCH((gru_bwd_kernel<H>), dim3((B + MT - 1) / MT, np), dim3(NT), lds, st, ps, so, L);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -572,7 +572,7 @@ int launch_bwd_bf(const BwdProbsB& ps, int np, const StepOff& so, int L, int B, 
     static bool attr_set = false;
     const int e = set_lds(gru_bwd_bf_kernel<H>, lds, attr_set);
     if (e != RENET_OK) return e;
-    hipLaunchKernelGGL((gru_bwd_bf_kernel<H>), dim3((B + MT - 1) / MT, np), dim3(NT), lds, st, ps, so, L);
+    RENET_LAUNCH((gru_bwd_bf_kernel<H>), dim3((B + MT - 1) / MT, np), dim3(NT), lds, st, ps, so, L);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -596,7 +596,7 @@ inline size_t bwd_plane_bytes(int H) { return (size_t)nub(H) * ((3 * H + 31) / 3
 int split_frag(const float* in, int U, int K, int G, size_t sg, size_t su, size_t sk, bf16x8* out, hipStream_t st) {
     const int NUBk = (U + 15) / 16, KGk = (K + 31) / 32;
     const int total = NUBk * KGk * G * 64;
-    hipLaunchKernelGGL(split_frag_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, U, K, G, sg, su, sk, NUBk,
+    RENET_LAUNCH(split_frag_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, U, K, G, sg, su, sk, NUBk,
                        KGk, out);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
@@ -694,7 +694,7 @@ int renet_gru_bwd_multi(int n, const float* const* dh_last, const int32_t* step_
         bf16x8* planes = reinterpret_cast<bf16x8*>(base);
         if (i < n) {
             if (f32) {
-                hipLaunchKernelGGL(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, st, Whh[k],
+                RENET_LAUNCH(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, st, Whh[k],
                                    3 * H, H, WhhT);
                 RENET_LAUNCH_CHECK();
             } else {                                // W_hh^T: unit u = hidden unit, k = gate column c: W_hh[c][u]

@@ -107,7 +107,7 @@ int renet_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, 
     hipStream_t st = (hipStream_t)stream;
     const size_t n4 = n / 4;
     const int blocks = (int)max((size_t)1, min((size_t)kBlocks, (n4 + 255) / 256));
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)g, n4, g + n4 * 4,
+    RENET_LAUNCH(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)g, n4, g + n4 * 4,
                        (int)(n & 3), workspace);
     RENET_LAUNCH_CHECK();
     AdamCfg c;
@@ -115,7 +115,7 @@ int renet_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, 
     c.bc1 = 1.f - powf(beta1, (float)step);
     c.bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     c.zero_grad = zero_grad;
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, workspace, blocks, c,
+    RENET_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, workspace, blocks, c,
                        grad_norm_out);
     RENET_LAUNCH_CHECK();
     return RENET_OK;

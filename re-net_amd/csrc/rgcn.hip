@@ -283,8 +283,8 @@ int launch_gather(const GatherArgs& a, bool tr, hipStream_t st) {
     blocks = max(8, min(blocks, 256 * 8));
     blocks = (blocks + 7) & ~7;
     const int grid = blocks + a.n_heavy;         // hub rows first, then the row groups, in ONE launch
-    if (tr) hipLaunchKernelGGL((rgcn_gather_kernel<SI, NCH, UNR, true>), dim3(grid), dim3(kThreads), 0, st, a);
-    else hipLaunchKernelGGL((rgcn_gather_kernel<SI, NCH, UNR, false>), dim3(grid), dim3(kThreads), 0, st, a);
+    if (tr) RENET_LAUNCH((rgcn_gather_kernel<SI, NCH, UNR, true>), dim3(grid), dim3(kThreads), 0, st, a);
+    else RENET_LAUNCH((rgcn_gather_kernel<SI, NCH, UNR, false>), dim3(grid), dim3(kThreads), 0, st, a);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -509,7 +509,7 @@ int renet_gather_rows(const float* table, const int32_t* idx, int n, int D, floa
     const int CH = D / 4;
     const size_t total = (size_t)n * CH;
     int blocks = (int)min((size_t)2048, (total + 255) / 256);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+    RENET_LAUNCH(gather_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)table, idx, n, CH, (float4*)out);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
@@ -520,7 +520,7 @@ int renet_segment_add(const float* src, const int32_t* order, const int32_t* seg
     if (U < 0 || D <= 0 || (D & 3)) return RENET_ERR_BADARG;
     if (U == 0) return RENET_OK;
     if (D > 512) return RENET_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(segment_add_kernel, dim3(U), dim3(kThreads), 0,
+    RENET_LAUNCH(segment_add_kernel, dim3(U), dim3(kThreads), 0,
                        (hipStream_t)stream, (const float4*)src, order, seg_ptr, seg_target, U, D / 4,
                        (float4*)dst);
     RENET_LAUNCH_CHECK();
@@ -560,7 +560,7 @@ int renet_rgcn_bwd_prep(const float* g_out, const float* out, const float* norm,
     if (N == 0) return RENET_OK;
     const size_t total = (size_t)N * (D / 4);
     int blocks = (int)min((size_t)2048, (total + 255) / 256);
-    hipLaunchKernelGGL(rgcn_bwd_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+    RENET_LAUNCH(rgcn_bwd_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)g_out, (const float4*)out, norm, relu, make_drop(drop_p, seed), N,
                        D / 4, (float4*)gn, (float4*)g_loop);
     RENET_LAUNCH_CHECK();
@@ -589,21 +589,21 @@ int renet_rgcn_bwd_w(const float* x, const float* gn, const int32_t* e_src, cons
         float4* p4 = (float4*)workspace;
         switch (D) {
             case 100:
-                hipLaunchKernelGGL((rgcn_bwd_w_partial_kernel<1, 1>), grid, dim3(kThreads), 0, st, x4, g4,
+                RENET_LAUNCH((rgcn_bwd_w_partial_kernel<1, 1>), grid, dim3(kThreads), 0, st, x4, g4,
                                    e_src, e_dst, chunk_ptr, n_chunks, p4);
                 break;
             case 200:
-                hipLaunchKernelGGL((rgcn_bwd_w_partial_kernel<2, 1>), grid, dim3(kThreads), 0, st, x4, g4,
+                RENET_LAUNCH((rgcn_bwd_w_partial_kernel<2, 1>), grid, dim3(kThreads), 0, st, x4, g4,
                                    e_src, e_dst, chunk_ptr, n_chunks, p4);
                 break;
             default:
-                hipLaunchKernelGGL((rgcn_bwd_w_partial_kernel<4, 2>), grid, dim3(kThreads), 0, st, x4, g4,
+                RENET_LAUNCH((rgcn_bwd_w_partial_kernel<4, 2>), grid, dim3(kThreads), 0, st, x4, g4,
                                    e_src, e_dst, chunk_ptr, n_chunks, p4);
                 break;
         }
         RENET_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(rgcn_bwd_w_reduce_kernel, dim3(T, (WROW4 + 63) / 64), dim3(kThreads), 0, st,
+    RENET_LAUNCH(rgcn_bwd_w_reduce_kernel, dim3(T, (WROW4 + 63) / 64), dim3(kThreads), 0, st,
                        (const float4*)workspace, type_chunk_ptr, WROW4, T, type_shift, beta, (float4*)dW);
     RENET_LAUNCH_CHECK();
     return RENET_OK;

@@ -235,7 +235,7 @@ int renet_seq_assemble_fwd(const float* h2, const float* ent, const float* rel, 
     if (S < 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f) return RENET_ERR_BADARG;
     if (S == 0) return RENET_OK;
     const int CH = D / 4;
-    hipLaunchKernelGGL(seq_assemble_fwd_kernel, dim3(grid_for((size_t)S * 4 * CH)), dim3(256), 0,
+    RENET_LAUNCH(seq_assemble_fwd_kernel, dim3(grid_for((size_t)S * 4 * CH)), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)h2, (const float4*)ent, (const float4*)rel,
                        (const float4*)glob, subj_row, row_ent, row_rel, glob_row, S, CH,
                        make_drop(drop_p, seed_x), make_drop(drop_p, seed_xr), (float4*)X, (float4*)Xr);
@@ -250,13 +250,13 @@ int renet_seq_assemble_bwd(const float* dX, const float* dXr, const int32_t* ste
     const int CH = D / 4;
     const DropCfg dx = make_drop(drop_p, seed_x), dxr = make_drop(drop_p, seed_xr);
     if (S > 0) {
-        hipLaunchKernelGGL(seq_assemble_bwd_rows_kernel, dim3(grid_for((size_t)S * CH)), dim3(256), 0,
+        RENET_LAUNCH(seq_assemble_bwd_rows_kernel, dim3(grid_for((size_t)S * CH)), dim3(256), 0,
                            (hipStream_t)stream, (const float4*)dX, (const float4*)dXr, S, CH, dx, dxr,
                            (float4*)dRows);
         RENET_LAUNCH_CHECK();
     }
     if (B > 0) {
-        hipLaunchKernelGGL(seq_assemble_bwd_seq_kernel, dim3(grid_for((size_t)B * CH)), dim3(256), 0,
+        RENET_LAUNCH(seq_assemble_bwd_seq_kernel, dim3(grid_for((size_t)B * CH)), dim3(256), 0,
                            (hipStream_t)stream, (const float4*)dX, (const float4*)dXr, step_off, L, B, CH, dx,
                            dxr, (float4*)dEntSeq, (float4*)dRelSeq);
         RENET_LAUNCH_CHECK();
@@ -270,7 +270,7 @@ int renet_concat3_fwd(const float* a, const int32_t* ia, const float* hmid, cons
     if (B < 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f) return RENET_ERR_BADARG;
     if (B == 0) return RENET_OK;
     const int CH = D / 4, parts = c ? 3 : 2;
-    hipLaunchKernelGGL(concat3_fwd_kernel, dim3(grid_for((size_t)B * parts * CH)), dim3(256), 0,
+    RENET_LAUNCH(concat3_fwd_kernel, dim3(grid_for((size_t)B * parts * CH)), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)a, ia, (const float4*)hmid, (const float4*)c, ic,
                        B, CH, parts, make_drop(drop_p, seed), (float4*)feat);
     RENET_LAUNCH_CHECK();
@@ -283,7 +283,7 @@ int renet_concat3_bwd(const float* dfeat, int B, int D, int parts, float drop_p,
         return RENET_ERR_BADARG;
     if (B == 0) return RENET_OK;
     const int CH = D / 4;
-    hipLaunchKernelGGL(concat3_bwd_kernel, dim3(grid_for((size_t)B * parts * CH)), dim3(256), 0,
+    RENET_LAUNCH(concat3_bwd_kernel, dim3(grid_for((size_t)B * parts * CH)), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)dfeat, B, CH, parts, make_drop(drop_p, seed),
                        (float4*)da_rows, (float4*)dhmid, (float4*)dc_rows);
     RENET_LAUNCH_CHECK();
@@ -293,7 +293,7 @@ int renet_concat3_bwd(const float* dfeat, int B, int D, int parts, float drop_p,
 int renet_dropout(const float* x, size_t n, float drop_p, uint64_t seed, float* y, void* stream) {
     if ((n & 3) || drop_p < 0.f || drop_p >= 1.f) return RENET_ERR_BADARG;
     if (n == 0) return RENET_OK;
-    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
+    RENET_LAUNCH(dropout_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)x, n / 4, make_drop(drop_p, seed), (float4*)y);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
@@ -303,7 +303,7 @@ int renet_softmax_ce(const float* logits, const int32_t* target, int B, int C, i
                      float grad_scale, float* row_loss, float* dlogits, void* stream) {
     if (B < 0 || C <= 0 || ld < C) return RENET_ERR_BADARG;
     if (B == 0) return RENET_OK;
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, target, C, ld,
+    RENET_LAUNCH(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, target, C, ld,
                        grad_scale, row_loss, dlogits);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
@@ -313,7 +313,7 @@ int renet_segment_pool_fwd(const float* h, const int32_t* seg_ptr, int G, int D,
                            float* out, int32_t* argmax, void* stream) {
     if (G < 0 || D <= 0) return RENET_ERR_BADARG;
     if (G == 0) return RENET_OK;
-    hipLaunchKernelGGL(segment_pool_fwd_kernel, dim3(G, (D + 63) / 64), dim3(256), 0, (hipStream_t)stream, h,
+    RENET_LAUNCH(segment_pool_fwd_kernel, dim3(G, (D + 63) / 64), dim3(256), 0, (hipStream_t)stream, h,
                        seg_ptr, D, is_max, out, argmax);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
@@ -324,7 +324,7 @@ int renet_segment_pool_bwd(const float* dout, const int32_t* seg_ptr, const int3
     (void)N;
     if (G < 0 || D <= 0) return RENET_ERR_BADARG;
     if (G == 0) return RENET_OK;
-    hipLaunchKernelGGL(segment_pool_bwd_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, dout, seg_ptr,
+    RENET_LAUNCH(segment_pool_bwd_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, dout, seg_ptr,
                        argmax, D, is_max, dh);
     RENET_LAUNCH_CHECK();
     return RENET_OK;

@@ -303,17 +303,62 @@ def _sample(self, prob):
     return torch.distributions.categorical.Categorical(prob).sample(torch.Size([self.num_k]))
 
 
+def _joint_topk_many(self, ents, prob, subject=True):
+    """pred_r_rank2 + the per-entity top-k of model.py:229-258 for SEVERAL entities in one batch:
+    one batch graph with separate member graphs per entity (build_batch group=entity: identical to one call per
+    entity), one GRU launch, one [n*R, 3h] x [3h, N_ent] GEMM.  Returns {entity: (values[num_k], flat indices
+    into [R, N_ent])} -- the same numbers as num_k separate pred_r_rank2 calls."""
+    R, dev, H = self.num_rels, self.ent_embeds.device, self.h_dim
+    if subject:
+        hist_all, hist_t_all, rel_embeds, reverse = self.s_hist_test, self.s_hist_test_t, self.rel_embeds[:R], False
+    else:
+        hist_all, hist_t_all, rel_embeds, reverse = self.o_hist_test, self.o_hist_test_t, self.rel_embeds[R:], True
+    out = {}
+    chunk = max(1, (1 << 26) // max(R * self.in_dim, 1))               # bound the [n*R, N_ent] score block
+    ents = [int(e) for e in ents]
+    for c0 in range(0, len(ents), chunk):
+        es = ents[c0:c0 + chunk]
+        n = len(es)
+        s_h = torch.zeros(n * R, H, device=dev)
+        s_q = torch.zeros(n, H, device=dev)
+        have = [i for i, e in enumerate(es) if len(hist_all[e]) != 0]
+        if have:
+            seq_ent = np.repeat(np.asarray([es[i] for i in have], dtype=np.int64), R)
+            seq_rel = np.tile(np.arange(R, dtype=np.int64), len(have))
+            hists = [hist_all[e] for e in seq_ent]
+            hts = [hist_t_all[e] for e in seq_ent]
+            px, pxr = self.aggregator.forward_grouped((hists, hts), seq_ent, seq_rel, self.ent_embeds, rel_embeds,
+                                                      self.graph_dict, self.global_emb, reverse, seq_ent)
+            m = len(seq_ent)
+            _, hh = self.encoder(px, total_rows=m)
+            _, qq = self.encoder_r(pxr, total_rows=m)
+            perm = torch.from_numpy(self.aggregator.last_batch.host.perm).to(dev)   # sorted position -> sequence
+            rows = torch.as_tensor(have, device=dev).repeat_interleave(R) * R + \
+                torch.arange(R, device=dev).repeat(len(have))
+            h_seq = torch.empty(m, H, device=dev)
+            q_seq = torch.empty(m, H, device=dev)
+            h_seq[perm] = hh[0]
+            q_seq[perm] = qq[0]
+            s_h[rows] = h_seq
+            s_q[torch.as_tensor(have, device=dev)] = q_seq[::R]                      # the R copies are identical
+        ent_rows = self.ent_embeds[torch.as_tensor(es, device=dev)]                   # [n, H]
+        feat = torch.cat((ent_rows.repeat_interleave(R, dim=0), s_h, rel_embeds.repeat(n, 1)), dim=1)
+        p_o = torch.softmax(_linear_eval(self.linear, feat), dim=1)                  # [n*R, N_ent]
+        p_r = torch.softmax(_linear_eval(self.linear_r, torch.cat((ent_rows, s_q), dim=1)), dim=1)   # [n, R]
+        joint = (p_o * p_r.reshape(n * R, 1)).view(n, R * self.in_dim)
+        joint = joint * prob[torch.as_tensor(es, device=dev)].view(n, 1)
+        vals, idx = torch.topk(joint, self.num_k, dim=1, sorted=False)
+        for i, e in enumerate(es):
+            out[e] = (vals[i], idx[i])
+    return out
+
+
 def _advance_side(self, picks, prob, subject):
     """model.py:229-258 (subjects) / 266-297 (objects): rank (r, o) continuations of every sampled entity,
     keep the globally best num_k and write them into the prediction caches."""
     picks_np = picks.detach().cpu().numpy().astype(np.int64)
-    uniq, first = np.unique(picks_np, return_index=True)
-    per_ent = {}
-    for e in uniq:                      # identical entities give identical results: compute once
-        joint = self.pred_r_rank2(torch.full((self.num_rels,), int(e), dtype=torch.long),
-                                  torch.arange(self.num_rels), subject=subject)
-        vals, idx = torch.topk((prob[int(e)] * joint).view(-1), self.num_k, sorted=False)
-        per_ent[int(e)] = (vals, idx)
+    uniq = np.unique(picks_np)                           # identical entities give identical results: compute once
+    per_ent = self._joint_topk_many(uniq, prob, subject=subject)
     all_vals = torch.cat([per_ent[int(e)][0] for e in picks_np])          # sample order, duplicates included
     _, best = torch.topk(all_vals, self.num_k, sorted=False)
     cache, cache_t = (self.s_his_cache, self.s_his_cache_t) if subject else (self.o_his_cache, self.o_his_cache_t)
@@ -536,6 +581,7 @@ RENet.init_history = _init_history
 RENet.update_cache = _update_cache
 RENet.pred_r_rank2 = _pred_r_rank2
 RENet.sample_entities = _sample
+RENet._joint_topk_many = _joint_topk_many
 RENet._advance_side = _advance_side
 RENet._roll_histories = _roll_histories
 RENet._advance_time = _advance_time

@@ -26,7 +26,7 @@ _SIGNATURES = {
     'renet_segment_add': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'renet_rgcn_gather': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_int, c_int, c_void_p, c_float, c_u64, c_int, c_void_p, c_int, c_void_p,
-                                  c_int, c_int, c_void_p]),
+                                  c_int, c_int, c_int, c_int, c_void_p]),
     'renet_rgcn_bwd_prep': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_u64, c_int, c_int,
                                     c_void_p, c_void_p, c_void_p]),
     'renet_rgcn_bwd_w_workspace': (c_size_t, [c_int, c_int]),

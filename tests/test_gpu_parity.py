@@ -437,6 +437,22 @@ def test_full_size_dw_matches_fp64_sampled(dev):
         np.testing.assert_allclose(got[t], ref, rtol=1e-4, atol=1e-4 * max(1.0, len(e)) ** 0.5)
 
 
+def test_stale_hip_error_of_another_caller_does_not_fail_our_launches(dev):
+    """hipGetLastError() is per-thread state shared with every other HIP user in the process: an expected-to-fail
+    call of the host framework (here: hipMalloc of an absurd size) must not be reported as OUR launch failure."""
+    import ctypes
+    import renet_hip as K
+    hip = ctypes.CDLL('libamdhip64.so')
+    table = torch.arange(40, device=dev, dtype=torch.float32).view(10, 4)
+    idx = torch.tensor([3, 1], device=dev, dtype=torch.int32)
+    torch.cuda.synchronize()
+    ptr = ctypes.c_void_p()
+    rc = hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(1 << 60))
+    assert rc != 0                                   # failed, and left its error code in the thread's slot
+    out = K.gather_rows(table, idx)                  # our launch clears the slot and reports only its own status
+    assert out.tolist() == [[12.0, 13.0, 14.0, 15.0], [4.0, 5.0, 6.0, 7.0]]
+
+
 def test_exact_fp32_mode_in_a_subprocess(dev):
     """RENET_GEMM=f32 selects the exact-fp32 MFMA kernels (gemm.hip, gru_fwd/bwd_kernel) for the whole library;
     the switch is read once per process, so the GRU / training-step parity tests are re-run in a child process."""

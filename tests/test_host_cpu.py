@@ -346,3 +346,28 @@ def test_grouped_batch_equals_one_call_per_group():
     # the default (training) semantics differ: node sets are unions over the whole batch
     union = _subject_row_signature(G.build_batch(store, ne, nr, s, r, fh, sort=True))
     assert union.keys() == want.keys() and union != want
+
+
+def test_ctypes_signatures_match_the_header():
+    """Every prototype of include/renet_hip.h against the argtypes / restype renet_hip.py binds it with: same
+    arity, same class per argument.  (ctypes accepts EXTRA positional arguments and converts them as 32-bit ints:
+    a binding two entries short once passed the stream handle that way, leaving the upper half of the pointer to
+    whatever was on the stack.)"""
+    import renet_hip as K
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'renet_hip.h')).read(), flags=re.S)
+    protos = re.findall(r'\b(int|size_t|void|int64_t)\s+(renet_\w+)\s*\(([^)]*)\)\s*;', hdr)
+    assert len(protos) >= 30
+    kinds = {'int': 'i32', 'int32_t': 'i32', 'float': 'f32', 'uint64_t': 'u64', 'size_t': 'size', 'int64_t': 'i64'}
+    ckind = {ctypes.c_int: 'i32', ctypes.c_int32: 'i32', ctypes.c_float: 'f32', ctypes.c_uint64: 'u64',
+             ctypes.c_size_t: 'size', ctypes.c_int64: 'i64', ctypes.c_void_p: 'ptr', ctypes.c_ulong: 'u64',
+             ctypes.c_long: 'i64'}
+    for ret, name, params in protos:
+        want = []
+        for prm in [x.strip() for x in params.split(',') if x.strip() and x.strip() != 'void']:
+            want.append('ptr' if '*' in prm else kinds[prm.rsplit(' ', 1)[0].replace('const', '').strip()])
+        assert name in K._SIGNATURES, 'no binding for ' + name
+        restype, argtypes = K._SIGNATURES[name]
+        got = [ckind[a] for a in argtypes]
+        got = ['size' if (g == 'u64' and w == 'size') else g for g, w in zip(got, want)] + got[len(want):]
+        assert got == want, (name, got, want)
+        assert (restype is None) == (ret == 'void') and (ret == 'void' or ckind[restype] in (kinds[ret], 'u64'))
