@@ -233,6 +233,14 @@ int64_t renet_host_filter_edges(const int64_t* trip_ptr, const int64_t* trip_s, 
                                 const int64_t* trip_o, const int64_t* ti, int64_t Tb, int64_t num_ent,
                                 const int64_t* keys, const int32_t* new_id, int64_t N, int32_t* table,
                                 int64_t* out_ls, int64_t* out_lo, int64_t* out_rr);
+/* The same result for MANY small member graphs (batched inference: one slot per (entity, timestamp)): walks only
+ * the facts whose subject is in the slot's node set through a per-timestamp subject index -- by_subj = fact
+ * indices sorted stably by (timestamp, subject), subj_sorted = their subjects; `table`: num_ent entries, -1. */
+int64_t renet_host_filter_edges_sparse(const int64_t* trip_ptr, const int64_t* trip_s, const int64_t* trip_r,
+                                       const int64_t* trip_o, const int64_t* by_subj,
+                                       const int64_t* subj_sorted, const int64_t* ti, int64_t Tb,
+                                       int64_t num_ent, const int64_t* keys, const int32_t* new_id, int64_t N,
+                                       int32_t* table, int64_t* out_ls, int64_t* out_lo, int64_t* out_rr);
 void renet_host_edge_layouts(int64_t n, int64_t E, const int64_t* src, const int64_t* dst, const int64_t* et,
                              int64_t T, int64_t chunk, int64_t heavy, int32_t* col, int32_t* etype,
                              int32_t* row_ptr, float* norm, int32_t* heavy_rows, int64_t* n_heavy,

@@ -37,6 +37,44 @@ int64_t renet_host_filter_edges(const int64_t* trip_ptr, const int64_t* trip_s, 
     return m;
 }
 
+// The same filter for MANY small member graphs (batched inference: one slot per (entity, timestamp), node sets
+// of a few dozen entities): instead of scanning all facts of every slot's timestamp, walk only the facts whose
+// SUBJECT is in the slot's node set, through a per-timestamp subject index (by_subj: fact indices sorted by
+// (timestamp, subject), stable; subj_sorted: their subjects).  `table` is an int32 scratch of num_ent entries,
+// all -1 on entry and on return.  Output order = (slot, fact), identical to renet_host_filter_edges.
+int64_t renet_host_filter_edges_sparse(const int64_t* trip_ptr, const int64_t* trip_s, const int64_t* trip_r,
+                                       const int64_t* trip_o, const int64_t* by_subj,
+                                       const int64_t* subj_sorted, const int64_t* ti, int64_t Tb,
+                                       int64_t num_ent, const int64_t* keys, const int32_t* new_id, int64_t N,
+                                       int32_t* table, int64_t* out_ls, int64_t* out_lo, int64_t* out_rr) {
+    int64_t m = 0, k0 = 0;
+    std::vector<int64_t> facts;
+    for (int64_t slot = 0; slot < Tb; ++slot) {
+        int64_t k1 = k0;
+        while (k1 < N && keys[k1] < (slot + 1) * num_ent) ++k1;          // keys are sorted: this slot's nodes
+        const int64_t base = slot * num_ent;
+        for (int64_t i = k0; i < k1; ++i) table[keys[i] - base] = new_id[i];
+        const int64_t b = trip_ptr[ti[slot]], e = trip_ptr[ti[slot] + 1];
+        facts.clear();
+        for (int64_t i = k0; i < k1; ++i) {
+            const int64_t u = keys[i] - base;
+            const int64_t* q = std::lower_bound(subj_sorted + b, subj_sorted + e, u);
+            for (; q < subj_sorted + e && *q == u; ++q) {
+                const int64_t j = by_subj[q - subj_sorted];
+                if (table[trip_o[j]] >= 0) facts.push_back(j);
+            }
+        }
+        std::sort(facts.begin(), facts.end());                           // back to fact order
+        for (int64_t j : facts) {
+            out_ls[m] = table[trip_s[j]]; out_lo[m] = table[trip_o[j]]; out_rr[m] = trip_r[j];
+            ++m;
+        }
+        for (int64_t i = k0; i < k1; ++i) table[keys[i] - base] = -1;
+        k0 = k1;
+    }
+    return m;
+}
+
 // Directed edges (src -> dst, type et in [0,T)) -> CSR by destination with relation-sorted rows, norm,
 // hub rows (in-degree > heavy), the relation-bucketed edge list and its <= chunk-edge single-type chunks.
 // Stable throughout (ties keep the input edge order) == graph.HostBatch.set_edges.

@@ -115,6 +115,15 @@ class GraphStore(object):
         self._sorted_times = self.times[order]
         self._sorted_pos = order
 
+    def subject_index(self):
+        """(by_subj, subj_sorted): fact indices sorted stably by (timestamp, subject) and their subjects -- built
+        on first use (batched inference walks only the facts of a member graph's own nodes)."""
+        if getattr(self, '_by_subj', None) is None:
+            t_of = np.repeat(np.arange(len(self.trip_ptr) - 1, dtype=np.int64), np.diff(self.trip_ptr))
+            self._by_subj = np.ascontiguousarray(np.lexsort((self.trip_s, t_of)), dtype=np.int64)
+            self._subj_sorted = np.ascontiguousarray(self.trip_s[self._by_subj], dtype=np.int64)
+        return self._by_subj, self._subj_sorted
+
     @staticmethod
     def signature(graph_dict):
         return (id(graph_dict), len(graph_dict), tuple(id(g) for g in graph_dict.values()))
@@ -337,9 +346,10 @@ class HostBatch(object):
 
 
 TABLE_ENTRIES = 1 << 24          # (slot, entity) lookup-table entries per chunk of _induced_edges
+SPARSE_FACTS = 1 << 23           # facts of the member graphs' timestamps per call of the sparse filter
 
 
-def _induced_edges(store, ti, num_ent, keys, new_id):
+def _induced_edges(store, ti, num_ent, keys, new_id, sparse=False):
     """Node-induced edges of the member graphs (utils.py:115-131): slot c is the graph of store timestamp index
     ti[c]; keys = sorted slot * num_ent + entity of the batch's nodes, new_id their row numbers.  Returns the
     local (subject row, object row, relation) of every kept fact, slot-major in fact order.  Membership is a
@@ -347,6 +357,37 @@ def _induced_edges(store, ti, num_ent, keys, new_id):
     chunk for a training batch's <= 240 timestamps, many for the per-sequence graphs of batched inference)."""
     Tb = len(ti)
     L_ = _native()
+    if sparse and L_ is not None:
+        # many small member graphs (batched inference): per-node walk through the store's subject index
+        by_subj, subj_sorted = store.subject_index()
+        tic = np.ascontiguousarray(ti, dtype=np.int64)
+        tcnt = store.trip_ptr[tic + 1] - store.trip_ptr[tic]
+        nid32 = np.ascontiguousarray(new_id, dtype=np.int32)
+        table = _lookup_table(num_ent)
+        # output capacity per call: a kept fact belongs to its slot's timestamp => slot chunks of <= SPARSE_FACTS facts
+        bounds = [0]
+        acc = 0
+        for c in range(Tb):
+            acc += int(tcnt[c])
+            if acc > SPARSE_FACTS and c > bounds[-1]:
+                bounds.append(c)
+                acc = int(tcnt[c])
+        bounds.append(Tb)
+        outs = []
+        for c0, c1 in zip(bounds[:-1], bounds[1:]):
+            k0, k1 = np.searchsorted(keys, (c0 * num_ent, c1 * num_ent))
+            cap = int(tcnt[c0:c1].sum())
+            ls, lo, rr = np.empty(cap, np.int64), np.empty(cap, np.int64), np.empty(cap, np.int64)
+            kc = np.ascontiguousarray(keys[k0:k1] - c0 * num_ent, dtype=np.int64)
+            nc = np.ascontiguousarray(nid32[k0:k1])
+            tc = np.ascontiguousarray(tic[c0:c1])
+            m = L_.renet_host_filter_edges_sparse(_p(store.trip_ptr), _p(store.trip_s), _p(store.trip_r),
+                                                  _p(store.trip_o), _p(by_subj), _p(subj_sorted), _p(tc), c1 - c0,
+                                                  num_ent, _p(kc), _p(nc), k1 - k0, _p(table), _p(ls), _p(lo), _p(rr))
+            outs.append((ls[:m].copy(), lo[:m].copy(), rr[:m].copy()))
+        if len(outs) == 1:
+            return outs[0]
+        return tuple(np.concatenate([o[i] for o in outs]) for i in range(3))
     per = max(1, TABLE_ENTRIES // max(num_ent, 1))
     out_s, out_o, out_r = [], [], []
     nid32 = np.ascontiguousarray(new_id, dtype=np.int32)
@@ -456,7 +497,7 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None, 
 
     # node-induced edges of every member graph (utils.py:115-131)
     if Tb:
-        ls, lo, rr = _induced_edges(store, store.index_of(uniq_t), num_ent, keys, new_id)
+        ls, lo, rr = _induced_edges(store, store.index_of(uniq_t), num_ent, keys, new_id, sparse=group is not None)
     else:
         ls = lo = rr = np.zeros(0, np.int64)
     src = np.concatenate((ls, lo))

@@ -66,6 +66,9 @@ _SIGNATURES = {
                                 c_float, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     'renet_host_filter_edges': (ctypes.c_int64, [c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p,
                                                  ctypes.c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'renet_host_filter_edges_sparse': (ctypes.c_int64, [c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int64, c_void_p,
+                                                        c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p,
+                                                        c_void_p]),
     'renet_host_edge_layouts': (None, [ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p, c_void_p, ctypes.c_int64,
                                        ctypes.c_int64, ctypes.c_int64] + [c_void_p] * 12),
     'renet_host_segplan': (ctypes.c_int64, [c_void_p, ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p, c_void_p]),
@@ -81,6 +84,21 @@ class RenetHipError(RuntimeError):
     pass
 
 
+class _Bound(object):
+    """The bound entry points (attribute per symbol)."""
+
+
+def _exact_arity(fn, name, n):
+    # ctypes silently accepts EXTRA positional arguments and converts them as 32-bit ints (a pointer passed
+    # that way is truncated): insist on the declared arity
+    def call(*a):
+        if len(a) != n:
+            raise RenetHipError('%s takes %d arguments, %d given' % (name, n, len(a)))
+        return fn(*a)
+    call.__name__ = name
+    return call
+
+
 def lib():
     """Loads librenet_hip.so (once).  Raises if it has not been built -- no CPU/torch fallback."""
     global _lib
@@ -89,13 +107,16 @@ def lib():
             raise RenetHipError('librenet_hip.so not built (%s); run `python re-net_amd/build.py` '
                                 '-- there is no fallback path' % LIB_PATH)
         L = ctypes.CDLL(LIB_PATH)
+        ns = _Bound()
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)       # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if L.renet_version() != 1:
+            setattr(ns, name, _exact_arity(fn, name, len(args)))
+        if ns.renet_version() != 1:
             raise RenetHipError('ABI version mismatch')
-        _lib = L
+        ns._cdll = L
+        _lib = ns
     return _lib
 
 

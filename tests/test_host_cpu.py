@@ -330,11 +330,12 @@ def test_grouped_batch_equals_one_call_per_group():
     group = np.arange(len(idx)) // 2                     # pairs of sequences share their member graphs
     sigs = []
     for native, entries in ((False, 1 << 24), (True, 1 << 24), (True, 37 * ne), (False, 37 * ne)):
-        G.NATIVE, G.TABLE_ENTRIES = native, entries      # 37 slots per chunk: many chunks
+        # numpy: dense scan in chunks of 37 slots; native: the sparse per-node walk in chunks of ~3 timestamps' facts
+        G.NATIVE, G.TABLE_ENTRIES, G.SPARSE_FACTS = native, entries, (1 << 23 if entries == 1 << 24 else 5000)
         try:
             sigs.append(_subject_row_signature(G.build_batch(store, ne, nr, s, r, fh, sort=True, group=group)))
         finally:
-            G.NATIVE, G.TABLE_ENTRIES = True, 1 << 24
+            G.NATIVE, G.TABLE_ENTRIES, G.SPARSE_FACTS = True, 1 << 24, 1 << 23
     assert sigs[0] == sigs[1] == sigs[2] == sigs[3]
     want = {}
     for g in np.unique(group):
