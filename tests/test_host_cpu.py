@@ -372,3 +372,48 @@ def test_ctypes_signatures_match_the_header():
         got = ['size' if (g == 'u64' and w == 'size') else g for g, w in zip(got, want)] + got[len(want):]
         assert got == want, (name, got, want)
         assert (restype is None) == (ret == 'void') and (ret == 'void' or ckind[restype] in (kinds[ret], 'u64'))
+
+
+def _tile_of_block(L, nbx, nby):
+    """Python restatement of tile_of_block (csrc/gemm_split.hip): linear dispatch index -> (bx, by)."""
+    nb = nbx * nby
+    per = nb >> 3
+    t = (L & 7) * per + (L >> 3) if L < 8 * per else L
+    ns, nl = min(nbx, nby), max(nbx, nby)
+    w = min(ns, 8)
+    p, r = divmod(t, w * nl)
+    wp = min(w, ns - p * w)
+    l, sh = r // wp, p * w + r % wp
+    return (l, sh) if nby <= nbx else (sh, l)
+
+
+def test_gemm_virtual_tile_order_is_a_bijection():
+    """The XCD-aware tile order of the bf16x6 GEMM must visit every tile exactly once for every grid shape (the
+    formula here mirrors the device code line by line; the GPU tests cover a handful of shapes, this covers all
+    small ones), and consecutive workgroups of one XCD must share a slab of the long operand."""
+    src = open(os.path.join(ROOT, 're-net_amd', 'csrc', 'gemm_split.hip')).read()
+    for frag in ('(L & 7) * per + (L >> 3)', 'const int w = min(ns, 8);', 'const int wp = min(w, ns - p * w);',
+                 'const int l = r / wp, sh = p * w + (r - l * wp);'):
+        assert frag in src, 'tile_of_block changed: update the restatement in this test (%s)' % frag
+    for nbx in list(range(1, 41)) + [180, 181, 360]:
+        for nby in list(range(1, 41)) + [8, 180]:
+            seen = {_tile_of_block(L, nbx, nby) for L in range(nbx * nby)}
+            assert len(seen) == nbx * nby and all(0 <= x < nbx and 0 <= y < nby for x, y in seen), (nbx, nby)
+    # logits GEMM of the bench (8 x 180 tiles): the 8 row tiles of one column tile are consecutive on one XCD
+    nbx, nby = 180, 8
+    xcd0 = [_tile_of_block(L, nbx, nby) for L in range(0, nbx * nby, 8)]
+    assert [t[0] for t in xcd0[:16]] == [0] * 8 + [1] * 8 and [t[1] for t in xcd0[:8]] == list(range(8))
+
+
+def test_split_k_cost_model():
+    import renet_hip as K
+    assert K.auto_split_k(1024, 23033, 600) == 1 and K.auto_split_k(23033, 600, 1024) == 1     # full grids
+    assert K.auto_split_k(7624, 600, 800) == 1
+    assert 8 <= K.auto_split_k(1024, 600, 23033) <= 16                                          # swept optimum: 12
+    assert 10 <= K.auto_split_k(600, 800, 7624) <= 20                                           # swept optimum: 14
+    assert K.auto_split_k(200, 200, 46075) >= 64
+    assert K.auto_split_k(100, 100, 46075) >= 64          # a single tile must still be split (n_hidden = 100)
+    assert K.auto_split_k(64, 64, 96) == 1                # too few k-tiles to split
+    for m, n, k in ((1, 1, 1), (128, 128, 32), (300, 100, 7624), (1200, 400, 8000)):
+        s = K.auto_split_k(m, n, k)
+        assert 1 <= s <= max(1, ((k + 31) // 32))
