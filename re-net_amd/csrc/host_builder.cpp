@@ -19,21 +19,26 @@ int64_t renet_host_filter_edges(const int64_t* trip_ptr, const int64_t* trip_s, 
                                 const int64_t* trip_o, const int64_t* ti, int64_t Tb, int64_t num_ent,
                                 const int64_t* keys, const int32_t* new_id, int64_t N, int32_t* table,
                                 int64_t* out_ls, int64_t* out_lo, int64_t* out_rr) {
-    for (int64_t i = 0; i < N; ++i) table[keys[i]] = new_id[i];
-    int64_t m = 0;
+    // one slot at a time through the FIRST num_ent entries of the table (92 KB at 23k entities: cache resident;
+    // a (slot, entity) table of all slots is 22 MB and every endpoint lookup missed)
+    int64_t m = 0, k0 = 0;
     for (int64_t slot = 0; slot < Tb; ++slot) {
-        const int32_t* tab = table + slot * num_ent;
+        int64_t k1 = k0;
+        const int64_t base = slot * num_ent, lim = base + num_ent;
+        while (k1 < N && keys[k1] < lim) ++k1;                       // keys are sorted: this slot's nodes
+        for (int64_t i = k0; i < k1; ++i) table[keys[i] - base] = new_id[i];
         const int64_t b = trip_ptr[ti[slot]], e = trip_ptr[ti[slot] + 1];
         for (int64_t j = b; j < e; ++j) {
-            const int32_t ps = tab[trip_s[j]];
-            const int32_t po = tab[trip_o[j]];
+            const int32_t ps = table[trip_s[j]];
+            const int32_t po = table[trip_o[j]];
             if ((ps | po) >= 0) {                         // both non-negative
                 out_ls[m] = ps; out_lo[m] = po; out_rr[m] = trip_r[j];
                 ++m;
             }
         }
+        for (int64_t i = k0; i < k1; ++i) table[keys[i] - base] = -1;
+        k0 = k1;
     }
-    for (int64_t i = 0; i < N; ++i) table[keys[i]] = -1;
     return m;
 }
 
