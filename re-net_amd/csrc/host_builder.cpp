@@ -11,9 +11,9 @@
 
 extern "C" {
 
-// Marks table[keys[i]] = new_id[i], scans every fact of the timestamps ti[0..Tb), keeps those whose two
-// endpoints are both marked, restores the table to -1.  `table` is a caller-owned int32 scratch of at least
-// Tb * num_ent entries, all -1 on entry.  Outputs (capacity = total facts of those timestamps): local source /
+// Slot by slot (slot c = the graph of timestamp ti[c]; keys = sorted slot * num_ent + entity): marks the slot's
+// nodes in `table`, scans every fact of the timestamp, keeps those whose two endpoints are both marked,
+// restores the table to -1.  `table` is a caller-owned int32 scratch of at least num_ent entries, all -1 on entry.  Outputs (capacity = total facts of those timestamps): local source /
 // destination rows and relation of every kept fact, in (slot, fact) order.  Returns the number kept.
 int64_t renet_host_filter_edges(const int64_t* trip_ptr, const int64_t* trip_s, const int64_t* trip_r,
                                 const int64_t* trip_o, const int64_t* ti, int64_t Tb, int64_t num_ent,

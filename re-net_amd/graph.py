@@ -397,7 +397,7 @@ def _induced_edges(store, ti, num_ent, keys, new_id, sparse=False):
         tic = np.ascontiguousarray(ti[c0:c1], dtype=np.int64)
         tcnt = store.trip_ptr[tic + 1] - store.trip_ptr[tic]
         kc = np.ascontiguousarray(keys[k0:k1] - c0 * num_ent, dtype=np.int64)
-        table = _lookup_table((c1 - c0) * num_ent)
+        table = _lookup_table(num_ent if L_ is not None else (c1 - c0) * num_ent)
         if L_ is not None:
             cap = int(tcnt.sum())
             ls, lo, rr = np.empty(cap, np.int64), np.empty(cap, np.int64), np.empty(cap, np.int64)
