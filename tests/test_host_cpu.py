@@ -46,12 +46,38 @@ def _keys(slot_t, ent):
 @pytest.mark.parametrize('name,lo,hi,sort', [('small', 300, 420, True), ('small', 0, 64, True),
                                               ('tiny', 60, 100, True), ('small', 500, 510, True)])
 def test_batch_builder_matches_oracle(name, lo, hi, sort):
-    from collections import Counter
     cfg, tr, va, te = fixtures.split_dataset(name)
+    idx = np.arange(lo, min(hi, len(tr)))
+    _check_builder_against_oracle(tr, cfg['num_ent'], cfg['num_rels'], idx, sort)
+
+
+def test_batch_builder_matches_oracle_on_random_degenerate_streams():
+    """Tiny random streams with everything the fixtures rarely hold: self-loop facts (s == o), exact duplicate
+    facts inside a timestamp, one-fact timestamps, entities that appear only once, batches that are all empty."""
+    for seed in range(12):
+        rng = np.random.RandomState(100 + seed)
+        ne, nr, nt = int(rng.randint(3, 9)), int(rng.randint(1, 4)), int(rng.randint(3, 9))
+        rows = []
+        for t in range(nt):
+            k = int(rng.randint(1, 7))
+            q = np.stack((rng.randint(0, ne, k), rng.randint(0, nr, k), rng.randint(0, ne, k), np.full(k, t * 24)), 1)
+            if rng.rand() < 0.5:
+                q[0, 2] = q[0, 0]                                   # self loop
+            if k > 1 and rng.rand() < 0.5:
+                q[1] = q[0]                                         # duplicate fact
+            rows.append(q)
+        tr = np.concatenate(rows).astype(np.int64)
+        n = len(tr)
+        for idx in (np.arange(n), np.arange(min(2, n)), np.arange(n - min(3, n), n)):
+            _check_builder_against_oracle(tr, ne, nr, idx, True)
+
+
+def _check_builder_against_oracle(tr, num_ent, num_rels, idx, sort):
+    from collections import Counter
+    cfg = {'num_ent': num_ent, 'num_rels': num_rels}
     gd = U.build_graph_dict(tr, cfg['num_rels'])
     ogd = O.build_graph_dict(tr, cfg['num_rels'])
     (sh, sht), _, _ = O.build_histories(tr, cfg['num_ent'])
-    idx = np.arange(lo, min(hi, len(tr)))
     hist, hist_t = [sh[i] for i in idx], [sht[i] for i in idx]
     fh = G.FlatHistory.from_lists(hist, hist_t)
     hb = G.build_batch(G.store_for(gd), cfg['num_ent'], cfg['num_rels'], tr[idx, 0], tr[idx, 1], fh, sort=sort)

@@ -142,3 +142,66 @@ def test_filtered_rank_tie_rule():
     assert O.filtered_rank(pred, 1, []) == 1 + (3 - 1.0) / 2 + 1
     m = O.mrr_hits([1, 2, 4, 20])
     assert abs(m['mrr'] - (1 + .5 + .25 + .05) / 4) < 1e-12 and m['hits@3'] == 0.5 and m['hits@10'] == 0.75
+
+
+def test_oracle_batch_graph_matches_the_reference_on_degenerate_streams():
+    """Direct check (only where /root/reference exists): the UNMODIFIED reference's get_big_graph +
+    get_sorted_s_r_embed_rgcn (utils.py:68-93, 209-244) under the DGL shim vs oracle.batch_for_histories on tiny
+    random streams with self-loop facts, exact duplicate facts and one-fact timestamps -- the cases the dataset
+    fixtures rarely contain.  Compared as multisets keyed by (timestamp, entity)."""
+    from collections import Counter
+    from oracle import ref_loader
+    if not ref_loader.available():
+        pytest.skip('reference tree not present')
+    ref = ref_loader.load()
+    for seed in range(8):
+        rng = np.random.RandomState(300 + seed)
+        ne, nr, nt = int(rng.randint(3, 9)), int(rng.randint(1, 4)), int(rng.randint(3, 8))
+        rows = []
+        for t in range(nt):
+            k = int(rng.randint(1, 7))
+            q = np.stack((rng.randint(0, ne, k), rng.randint(0, nr, k), rng.randint(0, ne, k), np.full(k, t * 24)), 1)
+            if rng.rand() < 0.6:
+                q[0, 2] = q[0, 0]
+            if k > 1 and rng.rand() < 0.6:
+                q[1] = q[0]
+            rows.append(q)
+        tr = np.concatenate(rows).astype(np.int64)
+        ogd = O.build_graph_dict(tr, nr)
+        (sh, sht), _, _ = O.build_histories(tr, ne)
+        with ref_loader.cpu_mode():
+            rgd = {}
+            for t in np.unique(tr[:, 3]):
+                rgd[int(t)] = ref.utils.get_big_graph(tr[tr[:, 3] == t][:, :3], nr)
+            d = 4
+            ent = torch.randn(ne, d)
+            glob = {int(t): torch.zeros(1, 1, d) for t in np.unique(tr[:, 3])}
+            s_t, r_t = torch.from_numpy(tr[:, 0]), torch.from_numpy(tr[:, 1])
+            if sum(len(h) for h in sh) == 0:
+                continue
+            lens_r, s_tem, r_tem, g, node_ids, _ = ref.utils.get_sorted_s_r_embed_rgcn((sh, sht), s_t, r_t, ent, rgd, glob)
+            # timestamps of the member graphs in the reference's batch order (utils.py:149-170), via the same calls
+            hl = torch.LongTensor(list(map(len, sh)))
+            _, s_idx = hl.sort(0, descending=True)
+            nz = int((hl > 0).sum())
+            neighs_t = ref.utils.get_neighs_by_t([sh[i] for i in s_idx[:nz]], [sht[i] for i in s_idx[:nz]], s_t[s_idx])
+            r_times = [int(t) for t in neighs_t.keys()]
+        bg = O.batch_for_histories(sh, sht, tr[:, 0], ogd, sort=True)
+        nnz = len(bg.lens)       # torch.sort is not stable: ties (and the empty tail) may come in another order
+        assert lens_r.tolist() == bg.lens.tolist()
+        assert sorted(zip(lens_r.tolist(), s_tem[:nnz].tolist())) == sorted(zip(bg.lens.tolist(), tr[bg.perm[:nnz], 0].tolist()))
+        # node key = (timestamp of the member graph, entity)
+        r_ent = g.ndata['id'].view(-1).tolist()
+        r_graph = np.repeat(np.asarray(r_times), g.batch_num_nodes).tolist()
+        o_graph = np.repeat(np.asarray(bg.graph_t), np.diff(bg.graph_off + [bg.num_nodes])).tolist()
+        rk = list(zip(r_graph, r_ent))
+        ok = list(zip(o_graph, bg.ent.tolist()))
+        assert sorted(rk) == sorted(ok)
+        rsrc, rdst = g._src.tolist(), g._dst.tolist()
+        re = Counter((rk[a], rk[b], int(ts), int(to)) for a, b, ts, to in
+                     zip(rsrc, rdst, g.edata['type_s'].view(-1).tolist(), g.edata['type_o'].view(-1).tolist()))
+        oe = Counter((ok[a], ok[b], int(ts), int(to)) for a, b, ts, to in zip(bg.src, bg.dst, bg.type_s, bg.type_o))
+        assert re == oe, (seed, re - oe, oe - re)
+        rn = dict(zip(rk, g.ndata['norm'].view(-1).tolist()))
+        assert all(abs(rn[k] - float(v)) < 1e-7 for k, v in zip(ok, bg.norm))
+        assert Counter(rk[i] for i in node_ids) == Counter(ok[i] for i in bg.subj_row)
