@@ -160,6 +160,54 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     }
 }
 
+// Same, with the row staged in LDS (C * 4 <= 128 KB: 23 033 entities = 92 KB): the three passes of the kernel above
+// re-read the row from the fabric (all 1024 rows are in flight at once, 94 MB against 32 MB of L2); here the row is
+// read ONCE by 1024 threads (16 waves keep enough loads in flight for one workgroup per CU) and the max / sum / write
+// passes run out of LDS.
+__global__ __launch_bounds__(1024) void softmax_ce_lds_kernel(const float* __restrict__ logits,
+                                                              const int32_t* __restrict__ target, int C, int ld,
+                                                              float grad_scale, float* __restrict__ row_loss,
+                                                              float* __restrict__ dlogits) {
+    extern __shared__ float row[];
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* x = logits + (size_t)b * ld;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += 1024) {
+        const float v = x[c];
+        row[c] = v;
+        m = fmaxf(m, v);
+    }
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 1024) {
+        const float e = expf(row[c] - m);
+        row[c] = e;                                  // each thread revisits only its own elements
+        s += e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w];
+    const int t = target[b];
+    if (threadIdx.x == 0) row_loss[b] = logf(s) + m - x[t];
+    __syncthreads();                                  // x[t] read before dlogits may overwrite it (alias allowed)
+    if (dlogits) {
+        float* dx = dlogits + (size_t)b * ld;
+        const float inv = 1.f / s;
+        for (int c = threadIdx.x; c < C; c += 1024) dx[c] = (row[c] * inv - (c == t ? 1.f : 0.f)) * grad_scale;
+    }
+}
+
 // ---- dgl.max_nodes / mean_nodes (Aggregator.py:58-61) ------------------------------------------
 __global__ __launch_bounds__(256) void segment_pool_fwd_kernel(const float* __restrict__ h,
                                                                const int32_t* __restrict__ seg_ptr, int D,
@@ -303,8 +351,21 @@ int renet_softmax_ce(const float* logits, const int32_t* target, int B, int C, i
                      float grad_scale, float* row_loss, float* dlogits, void* stream) {
     if (B < 0 || C <= 0 || ld < C) return RENET_ERR_BADARG;
     if (B == 0) return RENET_OK;
-    RENET_LAUNCH(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, target, C, ld,
-                       grad_scale, row_loss, dlogits);
+    const size_t lds = (size_t)C * sizeof(float);
+    if (lds <= 128 * 1024 && C >= 4096) {
+        static bool attr_set = false;      // benign race: the attribute is idempotent
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)softmax_ce_lds_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        RENET_LAUNCH(softmax_ce_lds_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, logits, target, C, ld,
+                     grad_scale, row_loss, dlogits);
+    } else {
+        RENET_LAUNCH(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, target, C, ld,
+                     grad_scale, row_loss, dlogits);
+    }
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }

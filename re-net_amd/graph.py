@@ -102,6 +102,11 @@ class GraphStore(object):
         self.times = np.asarray(list(graph_dict.keys()), dtype=np.int64)
         self._sig = self.signature(graph_dict)
         gs = [graph_dict[t] for t in graph_dict]
+        # strong references: the signature compares object identities, and a freed TimeGraph's address can be
+        # handed to a NEW graph (same-shaped dicts rebuilt in a loop do exactly that) -- while the store lives,
+        # the ids it was built from cannot be reused
+        self._graphs = gs
+        self._keys = tuple(graph_dict.keys())
         cnt = np.asarray([len(g.ls) for g in gs], dtype=np.int64)
         self.trip_ptr = np.concatenate(([0], np.cumsum(cnt)))
         if gs:
@@ -129,7 +134,7 @@ class GraphStore(object):
         return (id(graph_dict), len(graph_dict), tuple(id(g) for g in graph_dict.values()))
 
     def matches(self, graph_dict):
-        return self._sig == self.signature(graph_dict)
+        return self._sig == self.signature(graph_dict) and self._keys == tuple(graph_dict.keys())
 
     def index_of(self, t):
         p = np.searchsorted(self._sorted_times, t)

@@ -443,3 +443,22 @@ def test_split_k_cost_model():
     for m, n, k in ((1, 1, 1), (128, 128, 32), (300, 100, 7624), (1200, 400, 8000)):
         s = K.auto_split_k(m, n, k)
         assert 1 <= s <= max(1, ((k + 31) // 32))
+
+
+def test_graph_store_cache_survives_address_reuse():
+    """store_for() recognises a graph_dict by object identities; graphs that were freed and re-created at the same
+    addresses (same-shaped dicts built in a loop) must not resurrect a stale store."""
+    import gc
+    import preprocess as P
+    seen = []
+    for k in range(6):
+        rng = np.random.RandomState(k)
+        q = np.stack((rng.randint(0, 9, 40), rng.randint(0, 3, 40), rng.randint(0, 9, 40), np.repeat(np.arange(4), 10) * 24), 1)
+        gd = P.build_graph_dict(q.astype(np.int64), 3)
+        st = G.store_for(gd)
+        s_, r_, o_ = st.trip_s.copy(), st.trip_r.copy(), st.trip_o.copy()
+        want = np.concatenate([np.stack(gd[t].global_triples(), 1) for t in gd])
+        assert np.array_equal(np.stack((s_, r_, o_), 1), want), k
+        seen.append(id(gd))
+        del gd, st
+        gc.collect()
