@@ -35,8 +35,11 @@ class GlobalEmbTable(object):
         self.times = None
         self.mat = None
 
+    def _signature(self, global_emb):
+        return (id(global_emb), len(global_emb), tuple(id(v) for v in global_emb.values()))
+
     def get(self, global_emb, dim, device):
-        key = (id(global_emb), len(global_emb), str(device))
+        key = (self._signature(global_emb), str(device))
         if key != self._key:
             ts = sorted(int(t) for t in global_emb.keys())
             self.times = np.asarray(ts, dtype=np.int64)
@@ -46,11 +49,15 @@ class GlobalEmbTable(object):
             else:
                 self.mat = torch.zeros(1, dim, device=device)
             self._key = key
+            # strong references: the signature is made of object identities, which a freed dict / tensor would
+            # hand on to its successor
+            self._alive = (global_emb, list(global_emb.values()))
         return self
 
     def invalidate(self):
         self._key = None
         self._host_key = None
+        self._alive = None
 
     def get_host(self, global_emb):
         """Host-only view (sorted timestamps for `index`); no device access."""
@@ -58,6 +65,7 @@ class GlobalEmbTable(object):
         if key != getattr(self, '_host_key', None):
             self.times = np.asarray(sorted(int(t) for t in global_emb.keys()), dtype=np.int64)
             self._host_key = key
+            self._host_alive = global_emb
         return self
 
     def index(self, t):
