@@ -241,6 +241,19 @@ int64_t renet_host_filter_edges_sparse(const int64_t* trip_ptr, const int64_t* t
                                        const int64_t* subj_sorted, const int64_t* ti, int64_t Tb,
                                        int64_t num_ent, const int64_t* keys, const int32_t* new_id, int64_t N,
                                        int32_t* table, int64_t* out_ls, int64_t* out_lo, int64_t* out_rr);
+/* The relation-bucketed chunk list of renet_host_edge_layouts restricted to edges with dst < n_out (a layer
+ * evaluated on a row prefix); returns the number of kept edges. */
+int64_t renet_host_type_chunks(int64_t E, const int64_t* src, const int64_t* dst, const int64_t* et, int64_t T,
+                               int64_t chunk, int64_t n_out, int32_t* e_src, int32_t* e_dst,
+                               int32_t* type_chunk_ptr, int32_t* chunk_type, int32_t* chunk_ptr,
+                               int64_t* n_chunks);
+/* Node sets of a batch (utils.py:149-156) -- per member graph the union of the subjects and history objects of its
+ * steps -- as sorted keys slot * num_ent + entity, with the rows that are some step's subject numbered first
+ * (graph.build_batch documents the outputs); `table`: num_ent entries, -1.  Returns the number of nodes. */
+int64_t renet_host_node_sets(int64_t S, const int64_t* slot_k, const int64_t* subj_ent, const int64_t* nbr_begin,
+                             const int64_t* nbr_cnt, const int64_t* nbr_o, int64_t Tb, int64_t num_ent,
+                             int32_t* table, int64_t* keys, int64_t* subj_pos, int64_t* new_id,
+                             int32_t* node_ent, int64_t* node_slot, int64_t* n_a);
 void renet_host_edge_layouts(int64_t n, int64_t E, const int64_t* src, const int64_t* dst, const int64_t* et,
                              int64_t T, int64_t chunk, int64_t heavy, int32_t* col, int32_t* etype,
                              int32_t* row_ptr, float* norm, int32_t* heavy_rows, int64_t* n_heavy,

@@ -147,4 +147,100 @@ int64_t renet_host_segplan(const int64_t* idx, int64_t n, int64_t bound, int32_t
     return U;
 }
 
+
+// The relation-bucketed chunk list restricted to edges whose destination is < n_out (evaluating a layer on a
+// row prefix: graph.HostBatch.set_out_rows) -- only the second half of renet_host_edge_layouts, on the kept
+// edges, without materialising the filtered edge list.  Capacity of e_src / e_dst: E; of the chunk arrays:
+// E / chunk + T + 1.  Returns the number of kept edges.
+int64_t renet_host_type_chunks(int64_t E, const int64_t* src, const int64_t* dst, const int64_t* et, int64_t T,
+                               int64_t chunk, int64_t n_out, int32_t* e_src, int32_t* e_dst,
+                               int32_t* type_chunk_ptr, int32_t* chunk_type, int32_t* chunk_ptr,
+                               int64_t* n_chunks) {
+    std::vector<int64_t> tstart(T + 1, 0);
+    for (int64_t e = 0; e < E; ++e)
+        if (dst[e] < n_out) ++tstart[et[e] + 1];
+    for (int64_t t = 0; t < T; ++t) tstart[t + 1] += tstart[t];
+    {
+        std::vector<int64_t> cur(tstart.begin(), tstart.end() - 1);
+        for (int64_t e = 0; e < E; ++e)
+            if (dst[e] < n_out) {
+                const int64_t k = cur[et[e]]++;
+                e_src[k] = (int32_t)src[e];
+                e_dst[k] = (int32_t)dst[e];
+            }
+    }
+    const int64_t kept = tstart[T];
+    int64_t nc = 0;
+    for (int64_t t = 0; t < T; ++t) {
+        type_chunk_ptr[t] = (int32_t)nc;
+        for (int64_t b = tstart[t]; b < tstart[t + 1]; b += chunk) {
+            chunk_type[nc] = (int32_t)t;
+            chunk_ptr[nc] = (int32_t)b;
+            ++nc;
+        }
+    }
+    type_chunk_ptr[T] = (int32_t)nc;
+    chunk_ptr[nc] = (int32_t)kept;
+    *n_chunks = nc;
+    return kept;
+}
+
+// Node sets of a batch (utils.py:149-156): per slot (member graph) the union of the subjects and the history
+// objects of the steps that fall into it.  Step k belongs to slot slot_k[k], has subject subj_ent[k] and the
+// objects nbr_o[nbr_begin[k] .. nbr_begin[k] + nbr_cnt[k]).  Outputs, identical to the numpy specification in
+// graph.build_batch (np.unique over slot * num_ent + entity, subject rows numbered first):
+//   keys[N]      sorted slot * num_ent + entity          new_id[N]   row of key i (rows that are a step's
+//   subj_pos[S]  index into keys of every step's subject             subject come first, in key order)
+//   node_ent[N], node_slot[N]  entity / slot of every ROW (new order);  *n_a = number of subject rows
+// `table`: int32 scratch of num_ent entries, -1 on entry and on return.  Returns N (capacity: S + total objects).
+int64_t renet_host_node_sets(int64_t S, const int64_t* slot_k, const int64_t* subj_ent, const int64_t* nbr_begin,
+                             const int64_t* nbr_cnt, const int64_t* nbr_o, int64_t Tb, int64_t num_ent,
+                             int32_t* table, int64_t* keys, int64_t* subj_pos, int64_t* new_id,
+                             int32_t* node_ent, int64_t* node_slot, int64_t* n_a) {
+    std::vector<int64_t> start(Tb + 1, 0), steps(S);
+    for (int64_t k = 0; k < S; ++k) ++start[slot_k[k] + 1];
+    for (int64_t t = 0; t < Tb; ++t) start[t + 1] += start[t];
+    {
+        std::vector<int64_t> cur(start.begin(), start.end() - 1);
+        for (int64_t k = 0; k < S; ++k) steps[cur[slot_k[k]]++] = k;
+    }
+    std::vector<int64_t> ents;
+    std::vector<uint8_t> is_a;
+    int64_t N = 0;
+    for (int64_t t = 0; t < Tb; ++t) {
+        ents.clear();
+        for (int64_t q = start[t]; q < start[t + 1]; ++q) {
+            const int64_t k = steps[q];
+            if (table[subj_ent[k]] < 0) { table[subj_ent[k]] = 0; ents.push_back(subj_ent[k]); }
+            for (int64_t j = nbr_begin[k]; j < nbr_begin[k] + nbr_cnt[k]; ++j)
+                if (table[nbr_o[j]] < 0) { table[nbr_o[j]] = 0; ents.push_back(nbr_o[j]); }
+        }
+        std::sort(ents.begin(), ents.end());
+        for (size_t i = 0; i < ents.size(); ++i) {
+            keys[N + (int64_t)i] = t * num_ent + ents[i];
+            table[ents[i]] = (int32_t)(N + (int64_t)i) + 1;              // position + 1 (0 = "seen")
+        }
+        is_a.resize((size_t)(N + (int64_t)ents.size()), 0);
+        for (int64_t q = start[t]; q < start[t + 1]; ++q) {
+            const int64_t k = steps[q];
+            const int64_t pos = (int64_t)table[subj_ent[k]] - 1;
+            subj_pos[k] = pos;
+            is_a[(size_t)pos] = 1;
+        }
+        for (int64_t e : ents) table[e] = -1;
+        N += (int64_t)ents.size();
+    }
+    int64_t na = 0;
+    for (int64_t i = 0; i < N; ++i) na += is_a[(size_t)i];
+    int64_t ia = 0, ib = na;
+    for (int64_t i = 0; i < N; ++i) {
+        const int64_t r = is_a[(size_t)i] ? ia++ : ib++;
+        new_id[i] = r;
+        node_ent[r] = (int32_t)(keys[i] % num_ent);
+        node_slot[r] = keys[i] / num_ent;
+    }
+    *n_a = na;
+    return N;
+}
+
 }  // extern "C"

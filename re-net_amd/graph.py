@@ -336,6 +336,23 @@ class HostBatch(object):
         self.nA = int(n_out)
         self.E_out = int(self.row_ptr[n_out])          # edges into rows < n_out (== edges out of them: paired)
         self.heavy_rows_out = self.heavy_rows[self.heavy_rows < n_out]
+        L = _native()
+        if L is not None:
+            src = np.ascontiguousarray(src, dtype=np.int64)
+            dst = np.ascontiguousarray(dst, dtype=np.int64)
+            et = np.ascontiguousarray(et, dtype=np.int64)
+            E, T = len(src), int(self.num_types)
+            e_src, e_dst = np.empty(E, np.int32), np.empty(E, np.int32)
+            self.type_chunk_ptr2 = np.empty(T + 1, np.int32)
+            cap = E // CHUNK + T + 1
+            ctype, cptr = np.empty(cap, np.int32), np.empty(cap + 1, np.int32)
+            nc = ctypes.c_int64(0)
+            kept = L.renet_host_type_chunks(E, _p(src), _p(dst), _p(et), T, CHUNK, int(n_out), _p(e_src), _p(e_dst),
+                                            _p(self.type_chunk_ptr2), _p(ctype), _p(cptr), ctypes.byref(nc))
+            self.e_src2, self.e_dst2 = e_src[:kept].copy(), e_dst[:kept].copy()
+            self.n_chunks2 = int(nc.value)
+            self.chunk_type2, self.chunk_ptr2 = ctype[:self.n_chunks2].copy(), cptr[:self.n_chunks2 + 1].copy()
+            return self
         m = np.asarray(dst) < n_out
         sub = HostBatch().set_edges(self.N, np.asarray(src)[m], np.asarray(dst)[m], np.asarray(et)[m],
                                     self.num_types)
@@ -480,25 +497,45 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None, 
     hb.graph_t = uniq_t
 
     # node sets per timestamp: {subject} U {history objects}  (utils.py:149-156)
-    ncnt = fh.nbr_ptr[step_idx + 1] - fh.nbr_ptr[step_idx]
-    nb_flat = ragged_arange(fh.nbr_ptr[step_idx], ncnt)
-    key_subj = slot_k * num_ent + s_sorted[step_seq]
-    key_nbr = np.repeat(slot_k, ncnt) * num_ent + fh.nbr_o[nb_flat]
-    keys = np.unique(np.concatenate((key_subj, key_nbr)))
-    N = len(keys)
-    hb.N = N
     # Row numbering: the rows that are read after the LAST RGCN layer -- the (subject, t) rows,
     # Aggregator.py:139-140 -- come first (rows [0, nA)), so that layer can be evaluated on a row prefix.
     # Every other node is an in-neighbour of a subject row, so layer 1 still needs all N rows.
-    subj_pos = np.searchsorted(keys, key_subj)
-    is_a = np.zeros(N, dtype=bool)
-    is_a[subj_pos] = True
-    order_new = np.concatenate((np.nonzero(is_a)[0], np.nonzero(~is_a)[0]))
-    new_id = np.empty(N, dtype=np.int64)
-    new_id[order_new] = np.arange(N)
-    hb.nA = int(is_a.sum())
-    hb.node_ent = (keys % num_ent)[order_new].astype(np.int32)
-    hb.node_slot = (keys // num_ent)[order_new]
+    ncnt = fh.nbr_ptr[step_idx + 1] - fh.nbr_ptr[step_idx]
+    L_ = _native()
+    if L_ is not None and S:
+        cap = S + int(ncnt.sum())
+        keys, new_id = np.empty(cap, np.int64), np.empty(cap, np.int64)
+        subj_pos = np.empty(S, np.int64)
+        node_ent, node_slot = np.empty(cap, np.int32), np.empty(cap, np.int64)
+        na = ctypes.c_int64(0)
+        slot_c = np.ascontiguousarray(slot_k, dtype=np.int64)
+        subj_c = np.ascontiguousarray(s_sorted[step_seq], dtype=np.int64)
+        nb_c = np.ascontiguousarray(fh.nbr_ptr[step_idx], dtype=np.int64)
+        ncnt_c = np.ascontiguousarray(ncnt, dtype=np.int64)
+        nbr_o = np.ascontiguousarray(fh.nbr_o, dtype=np.int64)
+        N = int(L_.renet_host_node_sets(S, _p(slot_c), _p(subj_c), _p(nb_c), _p(ncnt_c), _p(nbr_o), Tb, num_ent,
+                                        _p(_lookup_table(num_ent)), _p(keys), _p(subj_pos), _p(new_id),
+                                        _p(node_ent), _p(node_slot), ctypes.byref(na)))
+        keys, new_id = keys[:N], new_id[:N]
+        key_subj = None
+        hb.N, hb.nA = N, int(na.value)
+        hb.node_ent, hb.node_slot = node_ent[:N].copy(), node_slot[:N].copy()
+    else:
+        nb_flat = ragged_arange(fh.nbr_ptr[step_idx], ncnt)
+        key_subj = slot_k * num_ent + s_sorted[step_seq]
+        key_nbr = np.repeat(slot_k, ncnt) * num_ent + fh.nbr_o[nb_flat]
+        keys = np.unique(np.concatenate((key_subj, key_nbr)))
+        N = len(keys)
+        hb.N = N
+        subj_pos = np.searchsorted(keys, key_subj)
+        is_a = np.zeros(N, dtype=bool)
+        is_a[subj_pos] = True
+        order_new = np.concatenate((np.nonzero(is_a)[0], np.nonzero(~is_a)[0]))
+        new_id = np.empty(N, dtype=np.int64)
+        new_id[order_new] = np.arange(N)
+        hb.nA = int(is_a.sum())
+        hb.node_ent = (keys % num_ent)[order_new].astype(np.int32)
+        hb.node_slot = (keys // num_ent)[order_new]
 
     # node-induced edges of every member graph (utils.py:115-131)
     if Tb:

@@ -69,6 +69,10 @@ _SIGNATURES = {
     'renet_host_filter_edges_sparse': (ctypes.c_int64, [c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int64, c_void_p,
                                                         c_void_p, ctypes.c_int64, c_void_p, c_void_p, c_void_p,
                                                         c_void_p]),
+    'renet_host_node_sets': (ctypes.c_int64, [ctypes.c_int64] + [c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int64]
+                             + [c_void_p] * 7),
+    'renet_host_type_chunks': (ctypes.c_int64, [ctypes.c_int64, c_void_p, c_void_p, c_void_p, ctypes.c_int64,
+                                                ctypes.c_int64, ctypes.c_int64] + [c_void_p] * 6),
     'renet_host_edge_layouts': (None, [ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p, c_void_p, ctypes.c_int64,
                                        ctypes.c_int64, ctypes.c_int64] + [c_void_p] * 12),
     'renet_host_segplan': (ctypes.c_int64, [c_void_p, ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p, c_void_p]),
