@@ -72,12 +72,12 @@ def test_batch_builder_matches_oracle_on_random_degenerate_streams():
             _check_builder_against_oracle(tr, ne, nr, idx, True)
 
 
-def _check_builder_against_oracle(tr, num_ent, num_rels, idx, sort):
+def _check_builder_against_oracle(tr, num_ent, num_rels, idx, sort, history_len=10):
     from collections import Counter
     cfg = {'num_ent': num_ent, 'num_rels': num_rels}
     gd = U.build_graph_dict(tr, cfg['num_rels'])
     ogd = O.build_graph_dict(tr, cfg['num_rels'])
-    (sh, sht), _, _ = O.build_histories(tr, cfg['num_ent'])
+    (sh, sht), _, _ = O.build_histories(tr, cfg['num_ent'], history_len=history_len)
     hist, hist_t = [sh[i] for i in idx], [sht[i] for i in idx]
     fh = G.FlatHistory.from_lists(hist, hist_t)
     hb = G.build_batch(G.store_for(gd), cfg['num_ent'], cfg['num_rels'], tr[idx, 0], tr[idx, 1], fh, sort=sort)
@@ -462,3 +462,27 @@ def test_graph_store_cache_survives_address_reuse():
         seen.append(id(gd))
         del gd, st
         gc.collect()
+
+
+def test_history_index_and_builder_on_hypothesis_streams():
+    """Property test (hypothesis): for arbitrary small time-ordered quadruple streams -- including repeated facts,
+    self loops, entities that vanish and return, history_len shorter than the stream -- HistoryIndex equals the
+    restated reference loop and the batch builder equals the oracle for every window of the stream."""
+    import preprocess as P
+    from hypothesis import given, settings, strategies as st
+
+    fact = st.tuples(st.integers(0, 5), st.integers(0, 2), st.integers(0, 5))
+    stream = st.lists(st.lists(fact, min_size=1, max_size=5), min_size=2, max_size=7)
+
+    @settings(max_examples=40, deadline=None)
+    @given(stream, st.integers(1, 4))
+    def check(per_t, hist_len):
+        q = np.asarray([(s, r, o, 24 * t) for t, facts in enumerate(per_t) for (s, r, o) in facts], dtype=np.int64)
+        ne, nr = 6, 3
+        (sh, sht), (oh, oht), _ = O.build_histories(q, ne, history_len=hist_len)
+        for role, ref in (('s', (sh, sht)), ('o', (oh, oht))):
+            hi = P.HistoryIndex(q, role, history_len=hist_len)
+            assert fixtures.histories_equal(hi.to_lists(np.arange(len(q))), ref), role
+        _check_builder_against_oracle(q, ne, nr, np.arange(len(q)), True, history_len=hist_len)
+
+    check()
