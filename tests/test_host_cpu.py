@@ -6,6 +6,7 @@ import re
 
 import numpy as np
 import pytest
+import torch
 
 from helpers import O, fixtures, ROOT
 
@@ -486,3 +487,30 @@ def test_history_index_and_builder_on_hypothesis_streams():
         _check_builder_against_oracle(q, ne, nr, np.arange(len(q)), True, history_len=hist_len)
 
     check()
+
+
+def test_batched_filtered_ranks_equal_the_per_quadruple_rule():
+    """model._known_pairs + model._rank_rows (evaluate_filter_batch) vs the restated reference rule
+    (model.py:384-419: sigmoid scores, all other known-true completions zeroed, ties averaged), row by row."""
+    import model as M
+    rng = np.random.RandomState(3)
+    ne, nr, n = 17, 4, 40
+    at = np.stack((rng.randint(0, ne, 300), rng.randint(0, nr, 300), rng.randint(0, ne, 300), rng.randint(0, 9, 300)), 1)
+    tr = at[rng.choice(len(at), n, replace=False)]
+    scores = torch.from_numpy(np.round(rng.randn(n, ne), 1).astype(np.float32))        # rounded: plenty of exact ties
+    s, r, o = tr[:, 0], tr[:, 1], tr[:, 2]
+    ro, co = M._known_pairs(torch.from_numpy(at), (0, 1), 2, np.stack((s, r), 1))
+    ranks = M._rank_rows(scores.clone(), torch.from_numpy(o), torch.from_numpy(ro), torch.from_numpy(co))
+    for i in range(n):
+        known = at[(at[:, 0] == s[i]) & (at[:, 1] == r[i]), 2]
+        want = O.filtered_rank(scores[i].clone(), int(o[i]), torch.from_numpy(known))
+        assert ranks[i] == want, (i, ranks[i], want)
+    rs, cs = M._known_pairs(at, (2, 1), 0, np.stack((o, r), 1))
+    ranks_s = M._rank_rows(scores.clone(), torch.from_numpy(s), torch.from_numpy(rs), torch.from_numpy(cs))
+    for i in range(n):
+        known = at[(at[:, 2] == o[i]) & (at[:, 1] == r[i]), 0]
+        assert ranks_s[i] == O.filtered_rank(scores[i].clone(), int(s[i]), torch.from_numpy(known))
+    raw = M._rank_rows(scores.clone(), torch.from_numpy(o))                             # raw (unfiltered) variant
+    for i in range(n):
+        g = scores[i, o[i]]
+        assert raw[i] == float((scores[i] > g).sum()) + (float((scores[i] == g).sum()) - 1.0) / 2 + 1
