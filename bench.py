@@ -135,7 +135,7 @@ def main():
     #  e2e_value  : builder in forked worker processes (pipeline.BatchPrefetcher), uploads on this thread
     e2e = e2e_inline = None
     e2e_workers = 0
-    if args.e2e_steps > 0:
+    if args.e2e_steps > 0 and world == 1:      # single-GPU extra; multi-GPU runs time the device path only
         sync_all()
         t0 = time.perf_counter()
         for k in range(args.e2e_steps):
