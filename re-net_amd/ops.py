@@ -12,10 +12,23 @@ import renet_hip as K
 _seed_state = {'counter': 0}
 
 
+def _rank():
+    import torch.distributed as dist
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
 def next_seed():
-    """Fresh 63-bit seed for one dropout site, derived from torch's global seed (train.py:31 seeds it)."""
+    """Fresh 63-bit seed for one dropout site, derived from torch's global seed (train.py:31 seeds it), the
+    data-parallel rank (every rank runs with the same torch seed, and identical masks on every rank would
+    correlate the ranks' dropout noise) and a per-process site counter."""
     _seed_state['counter'] += 1
-    return (torch.initial_seed() * 0x9E3779B1 + _seed_state['counter'] * 0x85EBCA77) & 0x7FFFFFFFFFFFFFFF
+    x = torch.initial_seed() * 0x9E3779B1 + (_rank() + 1) * 0xC2B2AE3D27D4EB4F + _seed_state['counter'] * 0x85EBCA77
+    return x & 0x7FFFFFFFFFFFFFFF
+
+
+def reset_seed_counter(value=0):
+    """Restart the per-process dropout site counter (reproducible runs: call next to torch.manual_seed)."""
+    _seed_state['counter'] = int(value)
 
 
 def _c(t):
@@ -28,10 +41,18 @@ def _c(t):
 # (4 uses per direction, 18 MB each) and linear.weight (55 MB) that removes ~45 add/fill kernels per step.
 INPLACE_GRADS = True
 
+# Test hook (tests/test_gpu_config.py): when set to a callable(name, tensor), the training path reports its
+# internal activations (GRU final states, entity logits before the in-place CE) -- None in production.
+debug_tap = None
+
 
 def grad_target(t):
     """The slice of a leaf parameter's existing .grad that corresponds to tensor `t` (the parameter itself or
-    a contiguous row-slice view of it), or None if there is nothing to accumulate into."""
+    a contiguous row-slice view of it), or None if there is nothing to accumulate into.
+    Always called from BACKWARD (the Functions keep `t` on ctx, not the resolved buffer): a loop that calls
+    zero_grad(set_to_none=True) or replaces .grad between forward and backward must not leave the kernels
+    accumulating into an orphaned tensor -- with .grad gone the Functions fall back to returning a
+    materialised gradient and autograd sets .grad as usual."""
     if not INPLACE_GRADS or t is None:
         return None
     base = t if t.is_leaf else getattr(t, '_base', None)
@@ -54,13 +75,14 @@ class GatherRowsFn(Function):
 
     @staticmethod
     def forward(ctx, table, idx, plan):
-        ctx.plan, ctx.shape, ctx.tgt = plan, table.shape, grad_target(table)
+        ctx.plan, ctx.shape, ctx.src = plan, table.shape, table
         return K.gather_rows(_c(table), idx)
 
     @staticmethod
     def backward(ctx, g):
-        if ctx.tgt is not None:
-            K.segment_add(_c(g), ctx.plan, ctx.tgt)
+        tgt = grad_target(ctx.src)
+        if tgt is not None:
+            K.segment_add(_c(g), ctx.plan, tgt)
             return None, None, None
         d = torch.zeros(ctx.shape, device=g.device, dtype=torch.float32)
         K.segment_add(_c(g), ctx.plan, d)
@@ -74,6 +96,7 @@ class RGCNLayerFn(Function):
 
     @staticmethod
     def forward(ctx, h, weight, loop_weight, g, reverse, relu, drop_p, seed, n_out):
+        ctx.src_w, ctx.src_loop = weight, loop_weight
         h, weight, loop_weight = _c(h), _c(weight), _c(loop_weight)
         n = h.shape[0]
         n_out = n if (n_out is None or n_out >= n) else int(n_out)
@@ -84,8 +107,6 @@ class RGCNLayerFn(Function):
                       g.heavy_rows_out if pruned else g.heavy_rows, g.heavy_thresh,
                       n_edges=g.E_out if pruned else None)
         ctx.g, ctx.relu, ctx.drop_p, ctx.seed, ctx.shift, ctx.n_out = g, relu, drop_p, seed, shift, n_out
-        ctx.tgt_loop = grad_target(loop_weight)
-        ctx.tgt_w = grad_target(weight)
         ctx.save_for_backward(h, weight, loop_weight, out)
         return out
 
@@ -93,6 +114,7 @@ class RGCNLayerFn(Function):
     def backward(ctx, g_out):
         h, weight, loop_weight, out = ctx.saved_tensors
         g, n_out = ctx.g, ctx.n_out
+        tgt_loop, tgt_w = grad_target(ctx.src_loop), grad_target(ctx.src_w)
         g_out = _c(g_out)
         n, d = h.shape
         pruned = n_out < n
@@ -101,8 +123,8 @@ class RGCNLayerFn(Function):
         K.rgcn_bwd_prep(g_out, out, g.norm, ctx.relu, ctx.drop_p, ctx.seed, gn, g_loop)
         dh = torch.empty(n, d, device=h.device, dtype=torch.float32)
         K.gemm(g_loop, loop_weight, tb=True, out=dh[:n_out])           # g_loop @ W_loop^T (rows < n_out)
-        if ctx.tgt_loop is not None:                                   # h^T @ g_loop (auto split-K), accumulated
-            K.gemm(h[:n_out], g_loop, ta=True, out=ctx.tgt_loop, beta=1.0)
+        if tgt_loop is not None:                                       # h^T @ g_loop (auto split-K), accumulated
+            K.gemm(h[:n_out], g_loop, ta=True, out=tgt_loop, beta=1.0)
             d_loop = None
         else:
             d_loop = K.gemm(h[:n_out], g_loop, ta=True)
@@ -112,8 +134,8 @@ class RGCNLayerFn(Function):
         K.rgcn_gather(gn, g.row_ptr, g.col, g.etype, None, weight, pair_shift, True, dh, 0.0, 0, False, dh,
                       g.heavy_rows, g.heavy_thresh, n_out if pruned else 0, n_out if pruned else 0,
                       n_edges=g.E_out if pruned else None)
-        acc = ctx.tgt_w is not None                                    # straight into weight.grad (beta = 1)
-        d_w = ctx.tgt_w if acc else torch.empty_like(weight)
+        acc = tgt_w is not None                                        # straight into weight.grad (beta = 1)
+        d_w = tgt_w if acc else torch.empty_like(weight)
         if pruned:
             K.rgcn_bwd_w(h, gn, g.e_src2, g.e_dst2, g.chunk_ptr2, g.chunk_type2, g.n_chunks2, g.type_chunk_ptr2,
                          g.num_types, ctx.shift, d_w, beta=1.0 if acc else 0.0)
@@ -128,31 +150,32 @@ class SeqAssembleFn(Function):
 
     @staticmethod
     def forward(ctx, h2, ent, rel, glob, g, drop_p, seed_x, seed_xr):
+        ctx.src_ent, ctx.src_rel = ent, rel
         h2, ent, rel, glob = _c(h2), _c(ent), _c(rel), _c(glob)
         x, xr = K.seq_assemble_fwd(h2, ent, rel, glob, g.subj_row, g.row_ent, g.row_rel, g.glob_row,
                                    drop_p, seed_x, seed_xr)
         ctx.g, ctx.drop_p, ctx.seeds = g, drop_p, (seed_x, seed_xr)
         ctx.shapes = (h2.shape, ent.shape, rel.shape)
-        ctx.tgt_ent, ctx.tgt_rel = grad_target(ent), grad_target(rel)
         return x, xr
 
     @staticmethod
     def backward(ctx, dx, dxr):
         g = ctx.g
         d = ctx.shapes[0][1]
+        tgt_ent, tgt_rel = grad_target(ctx.src_ent), grad_target(ctx.src_rel)
         d_rows, d_ent_seq, d_rel_seq = K.seq_assemble_bwd(_c(dx), _c(dxr), g.step_off, g.L, g.B, d, ctx.drop_p,
                                                           *ctx.seeds)
         dev = dx.device
         d_h2 = torch.zeros(ctx.shapes[0], device=dev, dtype=torch.float32)
         K.segment_add(d_rows, g.plan_subj_row, d_h2)
         d_ent = d_rel = None
-        if ctx.tgt_ent is not None:
-            K.segment_add(d_ent_seq, g.plan_s, ctx.tgt_ent)       # per-sequence sums, keyed by s[perm]
+        if tgt_ent is not None:
+            K.segment_add(d_ent_seq, g.plan_s, tgt_ent)           # per-sequence sums, keyed by s[perm]
         else:
             d_ent = torch.zeros(ctx.shapes[1], device=dev, dtype=torch.float32)
             K.segment_add(d_ent_seq, g.plan_s, d_ent)
-        if ctx.tgt_rel is not None:
-            K.segment_add(d_rel_seq, g.plan_r, ctx.tgt_rel)
+        if tgt_rel is not None:
+            K.segment_add(d_rel_seq, g.plan_r, tgt_rel)
         else:
             d_rel = torch.zeros(ctx.shapes[2], device=dev, dtype=torch.float32)
             K.segment_add(d_rel_seq, g.plan_r, d_rel)
@@ -196,6 +219,8 @@ class DualGRUFn(Function):
 
     @staticmethod
     def forward(ctx, x, xr, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, step_off, total_rows):
+        ctx.src_w = (w_ih, w_hh, w_ih_r, w_hh_r)
+        ctx.src_b = (b_ih, b_hh, b_ih_r, b_hh_r)
         ts = [_c(t) for t in (x, xr, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)]
         x, xr, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r = ts
         hdim = w_hh.shape[1]
@@ -206,20 +231,23 @@ class DualGRUFn(Function):
         nnz = int(step_off[1] - step_off[0]) if len(step_off) > 1 else 0
         outs = [h.unsqueeze(0), q.unsqueeze(0)]
         ctx.step_off, ctx.nnz, ctx.hdim = step_off, nnz, hdim
-        ctx.tgts = [grad_target(t) for t in (w_ih, w_hh, w_ih_r, w_hh_r)]
-        ctx.btgts = [grad_target(t) for t in (b_ih, b_hh, b_ih_r, b_hh_r)]
         ctx.save_for_backward(x, xr, w_ih, w_hh, w_ih_r, w_hh_r, sv, svr)
+        if debug_tap is not None:
+            debug_tap('h_n', h)
+            debug_tap('q_n', q)
         return outs[0], outs[1]
 
     @staticmethod
     def backward(ctx, dh, dq):
         x, xr, w_ih, w_hh, w_ih_r, w_hh_r, sv, svr = ctx.saved_tensors
         hdim, nnz = ctx.hdim, ctx.nnz
+        tgts = [grad_target(t) for t in ctx.src_w]
+        btgts = [grad_target(t) for t in ctx.src_b]
         (d_gi, d_gir), (d_gh, d_ghr) = K.gru_bwd_multi([_c(dh[0, :nnz]), _c(dq[0, :nnz])], ctx.step_off, hdim,
                                                        [w_hh, w_hh_r], [sv, svr])
         res = []
         for k, (xx, wi, dgi, dgh, s_) in enumerate(((x, w_ih, d_gi, d_gh, sv), (xr, w_ih_r, d_gir, d_ghr, svr))):
-            t_ih, t_hh = ctx.tgts[2 * k], ctx.tgts[2 * k + 1]
+            t_ih, t_hh = tgts[2 * k], tgts[2 * k + 1]
             if t_ih is not None:
                 K.gemm(dgi, xx, ta=True, out=t_ih, beta=1.0)
                 dwi_ = None
@@ -230,7 +258,7 @@ class DualGRUFn(Function):
                 dwh_ = None
             else:
                 dwh_ = K.gemm(dgh, s_[:, 4 * hdim:], ta=True)
-            t_bi, t_bh = ctx.btgts[2 * k], ctx.btgts[2 * k + 1]
+            t_bi, t_bh = btgts[2 * k], btgts[2 * k + 1]
             dbi_ = dbh_ = None
             if t_bi is not None:
                 K.colsum(dgi, out=t_bi, beta=1.0)
@@ -252,19 +280,20 @@ class HeadCEFn(Function):
 
     @staticmethod
     def forward(ctx, a, ia, hmid, c, ic, weight, bias, target, plan_a, plan_c, drop_p, seed):
+        ctx.srcs = (a, c, weight, bias)
         a, hmid, weight, bias = _c(a), _c(hmid), _c(weight), _c(bias)
         c = _c(c) if c is not None else None
         b, d = hmid.shape
         feat = K.concat3_fwd(a, ia, hmid, c, ic, drop_p, seed)
         logits = K.gemm(feat, weight, tb=True, bias=bias)                # [B, C]
+        if debug_tap is not None:
+            debug_tap('logits', logits)
         need_grad = any(ctx.needs_input_grad)
         row_loss = K.softmax_ce(logits, target, 1.0 / b, need_grad)
         ctx.meta = (d, 3 if c is not None else 2, drop_p, seed, plan_a, plan_c, a.shape,
                     c.shape if c is not None else None)
         if need_grad:
             ctx.save_for_backward(feat, logits, weight)
-            ctx.tgts = (grad_target(a), grad_target(c) if c is not None else None, grad_target(weight),
-                        grad_target(bias))
             ctx.consumed = False
         return row_loss.mean()
 
@@ -272,7 +301,7 @@ class HeadCEFn(Function):
     def backward(ctx, g):
         feat, dlogits, weight = ctx.saved_tensors
         d, parts, drop_p, seed, plan_a, plan_c, a_shape, c_shape = ctx.meta
-        t_a, t_c, t_w, t_b = ctx.tgts
+        t_a, t_c, t_w, t_b = [grad_target(t) for t in ctx.srcs]
         if ctx.consumed:
             raise RuntimeError('HeadCEFn: the saved (softmax - onehot) buffer was scaled in place by the first '
                                'backward pass; a second pass over the same graph is not supported')

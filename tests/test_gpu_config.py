@@ -1,0 +1,151 @@
+"""GPU parity at CONFIG SCALE (run with -m gpu on an MI355X): ONE eval-mode training step (both directions +
+backward, model.py:64-104 / train.py:136-138) through the C ABI on the bench workload itself (ICEWS18-shaped,
+N_ent 23 033, R 256, B 1024, D 200 -- the R = 256 relation-bucketed dW path, hub rows with hundreds of
+in-edges, the 180-tile head GEMM), on WIKI- and GDELT-shaped streams and on YAGO-shaped n_hidden = 400 /
+seq_len = 15, compared with
+
+  (a) the UNMODIFIED reference's outputs (tests/golden/config_*.npz, tools/make_config_golden.py): losses,
+      h_n / q_n / entity logits and every parameter gradient at 4096 seeded positions + Frobenius norms;
+  (b) the oracle restatement run here on the host cores: every gradient tensor in full.
+
+Tolerances (fp32 results, different summation order): losses 1e-4 relative; activations 5e-4 of the tensor's
+max |value|; gradients 2e-3 of the tensor's max |value| (the bound the small-scale tests use).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+from oracle import config_cases as C, fixtures
+
+pytestmark = pytest.mark.gpu
+
+CASE_NAMES = ['icews18_d200', 'wiki_d200', 'gdelt_d200', 'yago_d400_l15']
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    import renet_hip
+    renet_hip.lib()                      # fails loudly if the extension is missing
+    return torch.device('cuda:0')
+
+
+def hip_step(case, dev, hist_s, hist_o, tap=None):
+    """The product path on a case: -> (net, loss_s, loss_o) after backward (eval mode: dropout off)."""
+    import model as M
+    import ops
+    import preprocess as P
+    spec = case['spec']
+    net = M.RENet(case['num_ent'], spec['hidden'], case['num_rels'], dropout=0.0, seq_len=spec['seq_len'])
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in case['params'].items()})
+    net.global_emb = {t: torch.from_numpy(v).view(1, 1, -1) for t, v in case['global_emb'].items()}
+    net.to(dev)
+    net.eval()
+    gd = P.build_graph_dict(case['quads'], case['num_rels'])
+    batch = torch.from_numpy(case['batch']).to(dev)
+    ops.debug_tap = tap
+    try:
+        loss_s = net(batch, hist_s, hist_o, gd, subject=True)
+        loss_o = net(batch, hist_s, hist_o, gd, subject=False)
+    finally:
+        ops.debug_tap = None
+    (loss_s + loss_o).backward()
+    torch.cuda.synchronize()
+    return net, loss_s, loss_o
+
+
+@pytest.mark.parametrize('name', CASE_NAMES)
+def test_training_step_at_config_scale_matches_reference_and_oracle(dev, name):
+    import preprocess as P
+    gold = load_golden('config_%s.npz' % name)
+    case = C.build_case(name, gold=gold)
+    spec, quads, idx = case['spec'], case['quads'], case['idx']
+    B, L = spec['batch'], spec['seq_len']
+
+    # product-side histories (vectorised index) == the reference's streaming loop, bit for bit, at scale
+    hidx = {'s': P.HistoryIndex(quads, 's', history_len=L), 'o': P.HistoryIndex(quads, 'o', history_len=L)}
+    fh = {}
+    for tag in ('s', 'o'):
+        fh[tag] = hidx[tag].take(idx)
+        assert np.array_equal(fh[tag].seq_ptr, gold['hist_%s_seq_ptr' % tag])
+        assert np.array_equal(fh[tag].step_t, gold['hist_%s_step_t' % tag])
+        assert np.array_equal(fh[tag].nbr_ptr, gold['hist_%s_nbr_ptr' % tag])
+        assert np.array_equal(fh[tag].nbr_o, gold['hist_%s_nbr' % tag][:, 1])
+
+    taps = []
+    net, loss_s, loss_o = hip_step(case, dev, fh['s'], fh['o'], tap=lambda n, t: taps.append((n, t.detach().clone())))
+
+    # (a) against the unmodified reference
+    for tag, loss in (('s', loss_s), ('o', loss_o)):
+        ref = float(gold['loss_' + tag])
+        assert abs(loss.item() - ref) < 1e-4 * abs(ref), (tag, loss.item(), ref)
+    # taps per direction, in call order: h_n, q_n, logits (entity head), logits (relation head)
+    per_dir = {'s': taps[:4], 'o': taps[4:8]}
+    for tag in ('s', 'o'):
+        names = [n for n, _ in per_dir[tag]]
+        assert names == ['h_n', 'q_n', 'logits', 'logits'], names
+        lens = np.diff(np.asarray(gold['hist_%s_seq_ptr' % tag]))
+        perm = np.argsort(-lens, kind='stable')                 # the one stable length sort of the product path
+        for key, t in (('h_n', per_dir[tag][0][1]), ('q_n', per_dir[tag][1][1]), ('logits', per_dir[tag][2][1])):
+            a = t.cpu().numpy()
+            full = np.zeros_like(a)
+            full[perm] = a
+            ok, err, scale = C.compare_packed(gold, '%s_%s' % (tag, key), full, rel=5e-4)
+            assert ok, (tag, key, err, scale)
+    for k, p in net.named_parameters():
+        g = p.grad.cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+        ok, err, scale = C.compare_packed(gold, 'grad.' + k, g, rel=2e-3)
+        assert ok, ('reference', k, err, scale)
+
+    # (b) against the oracle, every gradient entry
+    lo_s, lo_o, oparams = C.oracle_step(case)
+    assert abs(loss_s.item() - lo_s.item()) < 1e-4 * abs(lo_s.item())
+    assert abs(loss_o.item() - lo_o.item()) < 1e-4 * abs(lo_o.item())
+    for k, p in net.named_parameters():
+        ref = oparams[k].grad.numpy() if oparams[k].grad is not None else np.zeros(tuple(p.shape), np.float32)
+        scale = float(np.abs(ref).max())
+        err = float(np.abs(p.grad.cpu().numpy() - ref).max())
+        assert err <= 2e-3 * scale + 1e-9, ('oracle', k, err, scale)
+
+
+def test_zero_grad_set_to_none_between_forward_and_backward(dev):
+    """`loss = model(..); opt.zero_grad(set_to_none=True); loss.backward()` (the torch >= 2 default
+    order of many loops) must produce the same gradients as the reference order -- the kernels resolve their
+    in-place accumulation targets at backward time and fall back to returned gradients when .grad is gone."""
+    import model as M
+    import preprocess as P
+    import synth
+    quads, num_ent, num_rels, _ = synth.make_stream('YAGO', seed=5, num_t=40)
+    hs, ho = P.HistoryIndex(quads, 's'), P.HistoryIndex(quads, 'o')
+    gd = P.build_graph_dict(quads, num_rels)
+    idx = np.random.RandomState(3).permutation(len(quads))[:256]
+    torch.manual_seed(1)
+    net = M.RENet(num_ent, 200, num_rels, dropout=0.0, seq_len=10)
+    gen = torch.Generator().manual_seed(2)
+    net.global_emb = {int(t): torch.randn(1, 1, 200, generator=gen) * 0.1 for t in gd}
+    net.to(dev)
+    net.eval()
+    batch = torch.from_numpy(quads[idx]).to(dev)
+
+    def grads(order):
+        opt = torch.optim.SGD(net.parameters(), lr=0.0)
+        opt.zero_grad(set_to_none=True)
+        for _ in range(2):                                     # second iteration: .grad existed during forward
+            loss = net(batch, hs.take(idx), ho.take(idx), gd, subject=True) + \
+                net(batch, hs.take(idx), ho.take(idx), gd, subject=False)
+            if order == 'zero_between':
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+            else:
+                loss.backward()
+                out = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+                opt.zero_grad(set_to_none=True)
+        if order == 'zero_between':
+            out = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        return out
+    ref, got = grads('reference_order'), grads('zero_between')
+    for k in ref:
+        assert got[k] is not None
+        scale = float(ref[k].abs().max())
+        assert float((got[k] - ref[k]).abs().max()) <= 1e-5 * scale + 1e-12, k

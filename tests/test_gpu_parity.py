@@ -586,6 +586,43 @@ def test_evaluate_filter_matches_reference_golden(dev):
     assert abs(mine['mrr'] - ref['mrr']) < 2e-3
 
 
+@pytest.mark.parametrize('api', ['sequential', 'stream'])
+def test_reference_shadowing_switch_reproduces_the_reference_on_every_row(dev, api):
+    """RENet.reference_shadowing = True reproduces model.py:229-297's name shadowing: the first quadruple of every
+    new timestamp is scored for the entities of the last unsorted-top-k candidates.  Which candidate comes last is
+    device dependent, so the test hands the model the entities the reference run recorded (fixture `shadow`) through
+    `shadow_pick`, after asserting they ARE candidates of our own top-k -- then EVERY row (the first-of-timestamp
+    rows included) matches the reference's losses and ranks."""
+    gold = load_golden('eval_small_100.npz')
+    n_eval = int(gold['n_eval'])
+    net, gnet, H, gd, samples, total, valid, va = _eval_setup(dev, gold)
+    shadow = [tuple(int(x) for x in row) for row in gold['shadow']]
+    picks = []
+
+    def pick(side, cands):
+        k = len(picks) // 2
+        want = shadow[k][0 if side == 's' else 1]
+        assert want in cands, (side, want, cands)
+        picks.append(want)
+        return want
+    net.reference_shadowing, net.shadow_pick = True, pick
+    (vs, vst), (vo, vot) = H['valid']
+    with torch.no_grad():
+        if api == 'sequential':
+            res = [net.evaluate_filter(valid[i], (vs[i], vst[i]), (vo[i], vot[i]), gnet, total) for i in range(n_eval)]
+            ranks = np.asarray([r for r, _ in res])
+            losses = np.asarray([float(l) for _, l in res])
+        else:
+            ranks, losses = net.evaluate_filter_stream(valid[:n_eval], (vs[:n_eval], vst[:n_eval]),
+                                                       (vo[:n_eval], vot[:n_eval]), gnet, total)
+    assert len(picks) == 2 * len(shadow) and len(samples) == 0
+    np.testing.assert_allclose(losses, gold['losses'], rtol=2e-4, atol=2e-4)
+    assert float(np.mean(ranks == gold['ranks'])) >= 0.97 and np.abs(ranks - gold['ranks']).max() <= 2
+    first_of_t = np.nonzero(np.diff(va[:n_eval, 3]) != 0)[0] + 1
+    np.testing.assert_allclose(losses[first_of_t], gold['losses'][first_of_t], rtol=2e-4, atol=2e-4)
+    # and the default (False) differs from the reference exactly on those rows (the existing golden test)
+
+
 def test_aggregator_predict_with_appended_graph_matches_oracle(dev):
     """Aggregator.predict / predict_batch (unsorted path) on a history whose last step lives in a graph
     that was appended to graph_dict out of timeline order (what inference does, model.py:301)."""

@@ -232,3 +232,28 @@ def test_update_cache_matches_the_reference_method():
             with ref_loader.cpu_mode():
                 theirs = ref_f(Stub(), theirs if len(theirs) else [], torch.tensor(r), torch.from_numpy(cand))
             assert np.array_equal(np.asarray(mine), theirs.numpy()), (trial, step, mine, theirs)
+
+
+# ---------------------------------------------------------------------------------------------
+# config-scale: the oracle against the UNMODIFIED reference at BASELINE.json's sizes
+# (tools/make_config_golden.py; ICEWS18-shaped N_ent 23 033 / R 256 / B 1024, WIKI-, GDELT-shaped, D=400 L=15)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['icews18_d200', 'wiki_d200', 'gdelt_d200', 'yago_d400_l15'])
+def test_oracle_matches_reference_at_config_scale(name):
+    from oracle import config_cases as C
+    gold = load_golden('config_%s.npz' % name)
+    case = C.build_case(name, gold=gold)
+    loss_s, loss_o, params, parts = C.oracle_step(case, return_parts=True)
+    for tag, loss in (('s', loss_s), ('o', loss_o)):
+        ref = float(gold['loss_' + tag])
+        assert abs(loss.item() - ref) < 1e-5 * abs(ref), (tag, loss.item(), ref)
+        assert parts[tag]['bg'].num_nodes == int(gold[tag + '_graph_nodes'])
+        assert len(parts[tag]['bg'].src) == int(gold[tag + '_graph_edges'])
+        un = C.unsort(parts[tag], case['spec']['batch'])
+        for key in ('h_n', 'q_n', 'logits'):
+            ok, err, scale = C.compare_packed(gold, '%s_%s' % (tag, key), un[key], rel=2e-4)
+            assert ok, (tag, key, err, scale)
+    for k, p in params.items():
+        g = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+        ok, err, scale = C.compare_packed(gold, 'grad.' + k, g, rel=1e-3)
+        assert ok, (k, err, scale)

@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""Config-scale golden fixtures: ONE eval-mode training step (model.RENet.forward for both directions +
+backward, train.py:136-138) of the UNMODIFIED reference (/root/reference under oracle/dgl_shim.py, CPU) on
+the cases of oracle/config_cases.py -- the bench workload (ICEWS18-shaped, N_ent 23 033, R 256, B 1024), the
+WIKI- and GDELT-shaped streams and YAGO-shaped n_hidden=400 / seq_len=15.  Build container only.
+
+    python tools/make_config_golden.py [case ...]
+
+Writes tests/golden/config_<case>.npz: losses, graph sizes, and for every big tensor (h_n, q_n, logits in
+original batch order, the gradient of every parameter) its Frobenius norm + 4096 seeded samples
+(tools/make_golden.py:pack_tensor), plus the batch's flattened histories -- a few hundred KB per case.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+
+from oracle import config_cases as C, fixtures, ref_loader   # noqa: E402
+from make_golden import pack_tensor                # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def gen(name):
+    ref = ref_loader.load()
+    t0 = time.time()
+    case = C.build_case(name)
+    spec, quads, num_ent, num_rels = case['spec'], case['quads'], case['num_ent'], case['num_rels']
+    d, seq_len, B = spec['hidden'], spec['seq_len'], spec['batch']
+    print('%s: %d quads, histories built in %.0f s' % (name, len(quads), time.time() - t0), flush=True)
+    out = dict(idx=case['idx'], d=d, seq_len=seq_len)
+    for tag in ('s', 'o'):       # the batch's histories (oracle.build_histories, pinned by tests/golden/prep_*.npz)
+        sp, st, npt, nb = fixtures.flatten_histories(*case['hists'][tag])
+        out.update({'hist_%s_seq_ptr' % tag: sp, 'hist_%s_step_t' % tag: st, 'hist_%s_nbr_ptr' % tag: npt,
+                    'hist_%s_nbr' % tag: nb})
+    cap = {}
+    with ref_loader.cpu_mode():
+        graph_dict = {}
+        order = np.argsort(quads[:, 3], kind='stable')
+        q = quads[order]
+        times, starts = np.unique(q[:, 3], return_index=True)
+        ends = np.concatenate((starts[1:], [len(q)]))
+        for t, a, b in zip(times, starts, ends):                       # data/*/get_history_graph.py:137-140
+            graph_dict[int(t)] = ref.utils.get_big_graph(q[a:b, :3], num_rels)
+        model = ref.model.RENet(num_ent, d, num_rels, dropout=0.0, model=0, seq_len=seq_len, num_k=10)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in case['params'].items()})
+        model.global_emb = {t: torch.from_numpy(v).view(1, 1, d) for t, v in case['global_emb'].items()}
+        model.eval()
+        hooks = [model.encoder.register_forward_hook(lambda m, i, o: cap.setdefault('enc', []).append(o[1].detach().clone())),
+                 model.encoder_r.register_forward_hook(lambda m, i, o: cap.setdefault('enc_r', []).append(o[1].detach().clone())),
+                 model.linear.register_forward_hook(lambda m, i, o: cap.setdefault('lin', []).append(o.detach().clone())),
+                 model.aggregator.rgcn2.register_forward_hook(
+                     lambda m, i, o: cap.setdefault('gsz', []).append((int(o.number_of_nodes()), int(o.number_of_edges()))))]
+        batch = torch.from_numpy(case['batch']).long()
+        hs, ho = case['hists']['s'], case['hists']['o']
+        t0 = time.time()
+        loss_s = model(batch, hs, ho, graph_dict, subject=True)
+        loss_o = model(batch, hs, ho, graph_dict, subject=False)
+        (loss_s + loss_o).backward()
+        print('  reference step: %.1f s, loss_s %.6f loss_o %.6f' % (time.time() - t0, loss_s.item(), loss_o.item()),
+              flush=True)
+        for h in hooks:
+            h.remove()
+    out['loss_s'] = np.float64(loss_s.item())
+    out['loss_o'] = np.float64(loss_o.item())
+    for k, p in model.named_parameters():
+        pack_tensor(out, 'grad.' + k, p.grad)
+    for di, (tag, hist) in enumerate((('s', hs[0]), ('o', ho[0]))):
+        lens = torch.LongTensor([len(h) for h in hist])
+        _, perm = lens.sort(0, descending=True)                        # the permutation model.py:81 computed
+        perm = perm.numpy()
+        nnz = int((lens > 0).sum())
+        for key, capk in (('h_n', 'enc'), ('q_n', 'enc_r')):
+            hn = cap[capk][di].view(-1, d)
+            full = torch.zeros(B, d)
+            full[torch.from_numpy(perm[:nnz])] = hn
+            pack_tensor(out, '%s_%s' % (tag, key), full)
+        logits = cap['lin'][di]
+        un = torch.zeros_like(logits)
+        un[torch.from_numpy(perm)] = logits
+        pack_tensor(out, '%s_logits' % tag, un)
+        out['%s_graph_nodes' % tag] = np.int64(cap['gsz'][di][0])
+        out['%s_graph_edges' % tag] = np.int64(cap['gsz'][di][1])
+        out['%s_nnz' % tag] = np.int64(nnz)
+        print('  %s: graph N=%d E=%d, non-empty %d' % (tag, cap['gsz'][di][0], cap['gsz'][di][1], nnz), flush=True)
+    np.savez_compressed(os.path.join(OUT, 'config_%s.npz' % name), **out)
+
+
+if __name__ == '__main__':
+    for n in (sys.argv[1:] or sorted(C.CASES)):
+        gen(n)

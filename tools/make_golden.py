@@ -311,6 +311,19 @@ def gen_eval(name, d, seq_len, num_k, n_eval, prep):
     (s_hist, s_hist_t), (o_hist, o_hist_t) = prep['train']
     ranks, losses = [], []
     Cat.sample = rec_sample
+    # model.py:229-297 re-uses the names `s` / `o` as loop variables, so the FIRST quadruple of every new timestamp
+    # is scored for the entity of the LAST candidate `torch.topk(prob_tensor, num_k, sorted=False)` returned
+    # (s = s_to_id[indices[-1]], model.py:254-255 / 291-292) instead of its own subject / object.  The order of an
+    # unsorted top-k is device dependent, so the shadowing entities are recorded per advanced timestamp.
+    cand_topk = []
+    orig_topk = torch.topk
+
+    def rec_topk(inp, k, *a, **kw):
+        out = orig_topk(inp, k, *a, **kw)
+        if inp.dim() == 1 and inp.numel() == num_k * num_k and k == num_k:
+            cand_topk.append(out[1].clone())
+        return out
+    torch.topk = rec_topk
     try:
         with ref_loader.cpu_mode(), torch.no_grad():
             times = np.unique(tr[:, 3])
@@ -325,7 +338,12 @@ def gen_eval(name, d, seq_len, num_k, n_eval, prep):
                 losses.append(loss.item())
     finally:
         Cat.sample = orig_sample
-    out = dict(d=d, seq_len=seq_len, num_k=num_k, n_eval=n_eval, model_seed=cfg['seed'] * 17 + d,
+        torch.topk = orig_topk
+    # per advanced timestamp: samples[2a] = subjects, samples[2a+1] = objects; cand_topk likewise
+    assert len(cand_topk) == len(samples) and len(samples) % 2 == 0
+    shadow = np.asarray([[int(samples[2 * a + side][int(cand_topk[2 * a + side][-1]) // num_k]) for side in (0, 1)]
+                         for a in range(len(samples) // 2)], dtype=np.int64).reshape(-1, 2)
+    out = dict(d=d, seq_len=seq_len, num_k=num_k, n_eval=n_eval, model_seed=cfg['seed'] * 17 + d, shadow=shadow,
                global_seed=cfg['seed'] * 19 + d, ranks=np.asarray(ranks), losses=np.asarray(losses),
                samples=np.stack([x.numpy() for x in samples]) if samples else np.zeros((0, num_k), np.int64),
                n_new_graphs=np.int64(len(graph_dict) - len(prep['graphs'])))
