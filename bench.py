@@ -35,15 +35,20 @@ MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA dense peak (neve
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--shape', default='ICEWS18')
     ap.add_argument('--batch', type=int, default=1024)
     ap.add_argument('--hidden', type=int, default=200)
     ap.add_argument('--seq-len', type=int, default=10)
     ap.add_argument('--dropout', type=float, default=0.5)
-    ap.add_argument('--cpu-steps', type=int, default=2, help='oracle steps timed for cpu_baseline (0 = skip)')
+    ap.add_argument('--cpu-steps', type=int, default=3,
+                    help='oracle steps timed for cpu_baseline after 1 warm-up (0 = skip; ~8 s each on the GPU box: '
+                         'the default keeps the whole run within a few minutes, SURVEY 8d asks for >= 10)')
+    ap.add_argument('--cpu-threads', type=int, default=0, help='torch threads for the CPU baseline (0 = min(32, cores))')
     ap.add_argument('--e2e-steps', type=int, default=5)
+    ap.add_argument('--f32-steps', type=int, default=40,
+                    help='steps of the exact-fp32 companion run (RENET_GEMM=f32, child process; 0 = skip)')
     return ap.parse_args()
 
 
@@ -172,15 +177,21 @@ def main():
         return
 
     # ---- roofline of the dominant kernel class (HIP events recorded on the launch stream) ---------
-    # `traffic`: HBM bytes per launch from the PMC pass of this same command (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE in separate runs, FETCH doubled for 16 B/lane reads per MI355X_MICROARCH.md), committed as
-    # profiles/r01_pmc_traffic.json -- counters cannot be read from inside the process.
-    pmc = {}
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
-            pmc = json.load(f).get('classes', {})
-    except (OSError, ValueError):
-        pmc = {}
+    # `traffic`: HBM bytes per launch.  Hardware counters cannot be read from inside the process: they come from
+    # the rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled
+    # for 16 B/lane reads per MI355X_MICROARCH.md; tools/pmc_traffic.py), committed under profiles/ -- the newest
+    # round's file is used, and only for the workload it was collected on; otherwise null.
+    pmc, pmc_file = {}, None
+    for name in sorted(os.listdir(os.path.join(ROOT, 'profiles')), reverse=True) \
+            if os.path.isdir(os.path.join(ROOT, 'profiles')) else []:
+        if name.endswith('_pmc_traffic.json'):
+            try:
+                with open(os.path.join(ROOT, 'profiles', name)) as f:
+                    pmc = json.load(f).get('classes', {})
+                pmc_file = 'profiles/' + name
+                break
+            except (OSError, ValueError):
+                pmc = {}
     same_workload = (args.shape == 'ICEWS18' and args.batch == 1024 and args.hidden == 200 and args.seq_len == 10)
 
     def traffic_of(name):
@@ -215,22 +226,69 @@ def main():
             ach = st['bytes'] / (st['ms'] * 1e-3) / 1e9
             roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': ach / HBM_PEAK_GBS, 'traffic': traffic_of(dom)}
-    gather = None
-    if 'rgcn_gather' in stats:
-        st = stats['rgcn_gather']
-        ach = st['bytes'] / (st['ms'] * 1e-3) / 1e9
-        gather = {'kernel': 'rgcn_gather', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                  'frac': ach / HBM_PEAK_GBS, 'traffic': traffic_of('rgcn_gather'),
-                  'avg_us': st['ms'] * 1e3 / st['calls'],
-                  'algorithmic_bytes_per_launch': st['bytes'] / st['calls']}
+    # the north-star kernel: one entry per launch class of the step (distinct kernel names in a rocprof trace).
+    # `achieved` uses SURVEY 8d's bytes incl. the fused self-loop addend row; `frac_strict` drops that re-read.
+    gather = {}
+    d = args.hidden
+    for name in ('rgcn_gather_fwd_full', 'rgcn_gather_bwdh_full', 'rgcn_gather_fwd_pruned', 'rgcn_gather_bwdh_pruned'):
+        if name in stats:
+            st = stats[name]
+            ach = st['bytes'] / (st['ms'] * 1e-3) / 1e9
+            rows = g0.N if (name.endswith('full') or 'bwdh' in name) else g0.nA
+            strict = (st['bytes'] - st['calls'] * rows * d * 4) / (st['ms'] * 1e-3) / 1e9
+            gather[name] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': ach / HBM_PEAK_GBS, 'frac_strict': strict / HBM_PEAK_GBS,
+                            'traffic': traffic_of(name), 'avg_us': st['ms'] * 1e3 / st['calls'],
+                            'calls_per_step': st['calls'] / args.steps,
+                            'algorithmic_bytes_per_launch': st['bytes'] / st['calls']}
+    gru = None
+    if 'gru_recurrence' in stats:
+        st = stats['gru_recurrence']
+        ach = st['flops'] / (st['ms'] * 1e-3) / 1e12
+        peak = MFMA_BF16_PEAK_TF / 6.0 if K.GEMM_MODE == 'bf16x6' else MFMA_F32_PEAK_TF
+        gru = {'kernel': 'gru_fwd/bwd recurrence (both encoders per launch)', 'bound': 'mfma', 'achieved': ach,
+               'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'avg_us': st['ms'] * 1e3 / st['calls'],
+               'calls_per_step': st['calls'] / args.steps}
 
-    # ---- CPU baseline: the oracle (restated reference path) on this box's host cores -------------
-    cpu = None
+    # ---- CPU baseline: the oracle (restated reference path) on this box's host cores; the same oracle steps give
+    # the parity check: HIP eval-mode loss vs oracle loss on identical batches and (current) parameters ----------
+    cpu = parity = None
     if args.cpu_steps > 0 and world == 1:
-        cpu = cpu_baseline(args, quads, num_ent, num_rels, hist_s, hist_o, net, perm)
+        cpu, oracle_losses, cpu_steps_idx = cpu_baseline(args, quads, num_ent, num_rels, hist_s, hist_o, net, perm)
+        net.eval()
+        hip_losses = []
+        with torch.no_grad():
+            for k in cpu_steps_idx:
+                idx = parallel.shard_indices(perm, k, 0, 1, args.batch)
+                b = quads[idx]
+                ls = net.loss_prepared(net.prepare(b, hist_s.take(idx), graph_dict, subject=True)) + \
+                    net.loss_prepared(net.prepare(b, hist_o.take(idx), graph_dict, subject=False))
+                hip_losses.append(float(ls.item()))
+        net.train()
+        rel = [abs(a - b_) / abs(b_) for a, b_ in zip(hip_losses, oracle_losses)]
+        parity = {'hip_loss': hip_losses[0], 'oracle_loss': oracle_losses[0], 'rel_err': max(rel),
+                  'batches': len(rel), 'mode': 'eval (dropout off), parameters after the timed steps',
+                  'tolerance': 2e-4}
+
+    # ---- exact-fp32 companion (RENET_GEMM=f32: v_mfma_f32_32x32x2_f32 products instead of bf16x6) ------------
+    exact = None
+    if args.f32_steps > 0 and world == 1 and K.GEMM_MODE != 'f32':
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.f32_steps), '--warmup', str(args.warmup),
+               '--shape', args.shape, '--batch', str(args.batch), '--hidden', str(args.hidden), '--seq-len',
+               str(args.seq_len), '--dropout', str(args.dropout), '--cpu-steps', '0', '--e2e-steps', '0',
+               '--f32-steps', '0']
+        r = subprocess.run(cmd, env=dict(os.environ, RENET_GEMM='f32'), capture_output=True, text=True)
+        try:
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            exact = {'value': j['value'], 'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'gemm_mode': 'f32',
+                     'last_loss': j['last_loss']}
+        except (ValueError, IndexError, KeyError):
+            exact = {'error': (r.stderr or r.stdout)[-300:]}
 
     out = {
-        'metric': 'RGCN+GRU encoder triples/s at bs=1024 n_hidden=200 (full training step, both directions)',
+        'metric': 'RGCN+GRU encoder triples/s at bs=%d n_hidden=%d (full training step, both directions)'
+                  % (args.batch, args.hidden),
         'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'gemm_mode': K.GEMM_MODE,
@@ -240,7 +298,8 @@ def main():
                    'num_entities': num_ent, 'num_relations': num_rels, 'parallelism': 'dp%d' % world,
                    'batch_graph': {'nodes': int(g0.N), 'edges': int(g0.E), 'history_steps': int(g0.S),
                                    'nonempty': int(g0.nnz)}},
-        'roofline': roofline, 'roofline_rgcn_gather': gather, 'kernels': kernels, 'cpu_baseline': cpu,
+        'roofline': roofline, 'roofline_rgcn_gather': gather, 'roofline_gru': gru, 'parity': parity,
+        'value_exact_f32': exact, 'pmc_source': pmc_file, 'kernels': kernels, 'cpu_baseline': cpu,
         'host_build_ms': host_build_ms, 'e2e_value': e2e, 'e2e_workers': e2e_workers, 'e2e_inline': e2e_inline,
         'last_loss': last_loss,
     }
@@ -250,31 +309,49 @@ def main():
 
 
 def cpu_baseline(args, quads, num_ent, num_rels, hist_s, hist_o, net, perm):
-    """Times the oracle (oracle/renet_oracle.py: the reference's algorithm restated on torch-CPU) on a
-    bounded sample of the SAME workload: `cpu_steps` training steps (forward both directions +
-    backward) at the same batch size.  Reported baseline, not a target."""
+    """Times the oracle (oracle/renet_oracle.py: the reference's algorithm restated on torch-CPU; the reference
+    itself is not on this box) on a bounded sample of the SAME workload: `cpu_steps` training steps (forward both
+    directions + backward, eval-mode dropout) at the same batch size after one warm-up, per-stage medians.
+    Returns (record, oracle losses per timed step, the step indices used).  Reported baseline, not a target."""
     from oracle import renet_oracle as O
     import parallel
+    threads = args.cpu_threads or min(32, os.cpu_count() or 1)
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
     params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()}
     ge = {t: v.view(-1).cpu() for t, v in net.global_emb.items()}
     ogd = O.build_graph_dict(quads, num_rels)
-    times = []
+    times, stages, losses, steps_idx = [], [], [], []
     for k in range(args.cpu_steps + 1):
-        idx = parallel.shard_indices(perm, 1000 + k, 0, 1, args.batch)
+        step = 1000 + k
+        idx = parallel.shard_indices(perm, step, 0, 1, args.batch)
         hs, hst = hist_s.to_lists(idx)
         ho, hot = hist_o.to_lists(idx)
+        tm = O.StageTimer()
         t0 = time.perf_counter()
-        loss = O.renet_forward_loss(params, quads[idx], hs, hst, ogd, ge, num_rels, args.seq_len, subject=True) + \
-            O.renet_forward_loss(params, quads[idx], ho, hot, ogd, ge, num_rels, args.seq_len, subject=False)
+        loss = O.renet_forward_loss(params, quads[idx], hs, hst, ogd, ge, num_rels, args.seq_len, subject=True,
+                                    timer=tm) + \
+            O.renet_forward_loss(params, quads[idx], ho, hot, ogd, ge, num_rels, args.seq_len, subject=False, timer=tm)
+        tm.reset()
         loss.backward()
-        times.append(time.perf_counter() - t0)
+        tm.mark('backward')
+        dt = time.perf_counter() - t0
         for p in params.values():
             p.grad = None
-    t = float(np.mean(times[1:])) if len(times) > 1 else times[0]
-    return {'value': args.batch / t, 'unit': 'triples/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
-            'host_cpus': os.cpu_count(),
-            'sample': '%d training steps (fwd both directions + bwd, eval-mode dropout) of batch %d after 1 warm-up, '
-                      'oracle/renet_oracle.py on torch-CPU' % (args.cpu_steps, args.batch)}
+        if k > 0 or args.cpu_steps == 0:
+            times.append(dt)
+            stages.append(dict(tm.t))
+            losses.append(float(loss.item()))
+            steps_idx.append(step)
+    torch.set_num_threads(old_threads)
+    t = float(np.median(times))
+    stage_ms = {k: float(np.median([s_[k] for s_ in stages])) * 1e3 for k in stages[0]}
+    rec = {'value': args.batch / t, 'unit': 'triples/s', 'cores': int(threads), 'kind': 'port',
+           'host_cpus': os.cpu_count(), 'ms_per_step': t * 1e3, 'stage_ms_median': stage_ms,
+           'sample': '%d training steps (fwd both directions + bwd, eval-mode dropout) of batch %d after 1 warm-up, '
+                     'oracle/renet_oracle.py on torch-CPU with %d threads; medians'
+                     % (len(times), args.batch, threads)}
+    return rec, losses, steps_idx
 
 
 if __name__ == '__main__':

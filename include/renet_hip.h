@@ -80,6 +80,24 @@ int renet_rgcn_gather(const float* x, int D, const int32_t* row_ptr, const int32
                       float* out, int N, const int32_t* heavy_rows, int n_heavy, int heavy_thresh,
                       int src_limit, int addend_rows, void* stream);
 
+/* The same operator on the planned ITEM STREAM of the graph (the production path; renet_rgcn_gather above needs no
+ * plan and stays as the plain-CSR entry).  The host planner (renet_host_gather_items / graph.plan_gather_items)
+ * linearises every LIGHT row (in-degree <= heavy) as its in-edges (it_src = source row, it_type = type_s) followed
+ * by a flush item (it_src = the row, it_type = -1) and cuts the stream into n_groups groups of <= 64 items
+ * (grp_ptr[n_groups + 1]); one wave takes one group, all of its loads are unconditional buffer loads UNR items at a
+ * time (the self-loop addend and norm of a row are loaded by its flush item like any edge's operands), hub rows
+ * (heavy_rows[n_heavy], in-degree > heavy, NOT in the stream) are reduced by one workgroup each in the same
+ * launch.  row_ptr / col / etype are only read for hub rows.  pruned != 0 only selects the kernel NAME
+ * (rgcn_gather_{fwd,bwdh}_{full,pruned}: a kernel trace separates the four launch classes of a training step);
+ * the caller passes the group / hub-row prefix that covers rows < N.  x, addend, W must each be smaller than 1 GiB.
+ * Replaces RGCN.py:79-94 + 42-50 exactly as renet_rgcn_gather does. */
+int renet_rgcn_gather_items(const float* x, int D, const int32_t* it_src, const int32_t* it_type,
+                            const int32_t* grp_ptr, int n_groups, const int32_t* row_ptr, const int32_t* col,
+                            const int32_t* etype, const float* scale, const float* W, int T, int type_shift,
+                            int transpose_w, const float* addend, float drop_p, uint64_t seed, int relu,
+                            float* out, int N, const int32_t* heavy_rows, int n_heavy, int src_limit,
+                            int addend_rows, int pruned, void* stream);
+
 /* Backward prologue of one RGCN layer (element-wise, RGCN.py:42-50 + :93-94 reversed):
  *   g_pre = g_out * (relu ? out > 0 : 1);  gn = g_pre * norm[v];  g_loop = g_pre * dropmask       */
 int renet_rgcn_bwd_prep(const float* g_out, const float* out, const float* norm, int relu,
@@ -261,6 +279,12 @@ void renet_host_edge_layouts(int64_t n, int64_t E, const int64_t* src, const int
                              int32_t* chunk_ptr, int64_t* n_chunks);
 int64_t renet_host_segplan(const int64_t* idx, int64_t n, int64_t bound, int32_t* order, int32_t* seg_ptr,
                            int32_t* target);
+/* Item stream + wave groups consumed by renet_rgcn_gather_items, from the CSR of renet_host_edge_layouts (its
+ * contract is stated there and in graph.plan_gather_items, the numpy specification).  Capacities: it_src / it_type
+ * E + N, grp_ptr N + 2.  Returns the number of groups, or -1 if budget + heavy + 1 > 64. */
+int64_t renet_host_gather_items(int64_t N, const int32_t* row_ptr, const int32_t* col, const int32_t* etype,
+                                int64_t heavy, int64_t budget, int64_t n_out, int32_t* it_src, int32_t* it_type,
+                                int32_t* grp_ptr, int64_t* n_items, int64_t* n_groups_out);
 
 #ifdef __cplusplus
 }

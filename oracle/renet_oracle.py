@@ -242,16 +242,40 @@ def soft_cross_entropy(pred, soft_targets):
 # --------------------------------------------------------------------------------------------
 # RGCNAggregator.forward (Aggregator.py:124-167) and RENet.forward (model.py:64-104)
 # --------------------------------------------------------------------------------------------
+class StageTimer(object):
+    """Optional wall-clock accounting per stage of the restated path (bench.py's cpu_baseline)."""
+
+    def __init__(self):
+        import time
+        self._now = time.perf_counter
+        self.t = {}
+        self._last = self._now()
+
+    def mark(self, stage):
+        now = self._now()
+        self.t[stage] = self.t.get(stage, 0.0) + (now - self._last)
+        self._last = now
+
+    def reset(self):
+        self._last = self._now()
+
+
 def aggregator_sequences(params, hist, hist_t, s, r, rel_embeds, graph_dict, global_emb, reverse,
-                         seq_len, sort=True):
+                         seq_len, sort=True, timer=None):
     """Returns (bg, h2, X[B_nz, L, 4D], Xr[B_nz, L, 3D]) in eval mode (no dropout) -- the padded
     tensors of Aggregator.py:144-155 before packing.  global_emb: dict t -> tensor[..., D]."""
+    if timer is not None:
+        timer.reset()
     bg = batch_for_histories(hist, hist_t, s, graph_dict, sort=sort)
+    if timer is not None:
+        timer.mark('batch_graph')
     ent = params['ent_embeds']
     d = ent.shape[1]
     h0 = ent[torch.as_tensor(bg.ent)]                                   # utils.py:239
     etype = bg.type_o if reverse else bg.type_s                         # RGCN.py:80-85
     h2 = rgcn_two_layers(params, 'aggregator.', h0, bg.src, bg.dst, etype, bg.norm)
+    if timer is not None:
+        timer.mark('rgcn_x2')
     rows = h2[torch.as_tensor(bg.subj_row)]                             # Aggregator.py:139-140
     glob = torch.stack([torch.as_tensor(global_emb[int(t)]).reshape(d) for t in bg.step_t]) \
         if len(bg.step_t) else torch.zeros(0, d)
@@ -274,11 +298,13 @@ def aggregator_sequences(params, hist, hist_t, s, r, rel_embeds, graph_dict, glo
         pos += li
     if nnz:
         x, xr = torch.stack(xs), torch.stack(xrs)
+    if timer is not None:
+        timer.mark('sequence_assembly')
     return bg, h2, x, xr
 
 
 def renet_forward_loss(params, triplets, hist, hist_t, graph_dict, global_emb, num_rels, seq_len,
-                       subject=True, return_parts=False):
+                       subject=True, return_parts=False, timer=None):
     """model.py:64-104 in eval mode (dropout = identity).  triplets: int array [B, >=3] (s, r, o)."""
     triplets = np.asarray(triplets, dtype=np.int64)
     if subject:                                                         # model.py:65-71
@@ -293,24 +319,32 @@ def renet_forward_loss(params, triplets, hist, hist_t, graph_dict, global_emb, n
     d = ent.shape[1]
     b = len(s)
     bg, h2, x, xr = aggregator_sequences(params, hist, hist_t, s, r, rel_embeds, graph_dict,
-                                         global_emb, reverse, seq_len, sort=True)
+                                         global_emb, reverse, seq_len, sort=True, timer=timer)
     nnz = len(bg.lens)
     pad = torch.zeros(b - nnz, d, dtype=ent.dtype)                      # model.py:88
     s_h = gru_last_state(x, bg.lens, params['encoder.weight_ih_l0'], params['encoder.weight_hh_l0'],
                          params['encoder.bias_ih_l0'], params['encoder.bias_hh_l0'])      # model.py:86
     s_h = torch.cat((s_h, pad), dim=0)
+    if timer is not None:
+        timer.mark('gru')
     sp = torch.as_tensor(s[bg.perm])
     rp = torch.as_tensor(r[bg.perm])
     feat = torch.cat((ent[sp], s_h, rel_embeds[rp]), dim=1)             # model.py:89-90
     ob_pred = feat @ params['linear.weight'].t() + params['linear.bias']
     loss_sub = cross_entropy_mean(ob_pred, o[bg.perm])                  # model.py:91
+    if timer is not None:
+        timer.mark('head_ce')
     s_q = gru_last_state(xr, bg.lens, params['encoder_r.weight_ih_l0'], params['encoder_r.weight_hh_l0'],
                          params['encoder_r.bias_ih_l0'], params['encoder_r.bias_hh_l0'])  # model.py:94
     s_q = torch.cat((s_q, pad), dim=0)
+    if timer is not None:
+        timer.mark('gru')
     feat_r = torch.cat((ent[sp], s_q), dim=1)                           # model.py:98-99
     ob_pred_r = feat_r @ params['linear_r.weight'].t() + params['linear_r.bias']
     loss_r = cross_entropy_mean(ob_pred_r, r[bg.perm])                  # model.py:100
     loss = loss_sub + 0.1 * loss_r                                      # model.py:103
+    if timer is not None:
+        timer.mark('head_ce')
     if return_parts:
         return loss, dict(bg=bg, h2=h2, x=x, xr=xr, s_h=s_h, s_q=s_q, ob_pred=ob_pred,
                           ob_pred_r=ob_pred_r, loss_sub=loss_sub, loss_r=loss_r)

@@ -243,4 +243,34 @@ int64_t renet_host_node_sets(int64_t S, const int64_t* slot_k, const int64_t* su
     return N;
 }
 
+// Item stream + wave groups of the gather-SpMM kernels (renet_rgcn_gather_items); numpy specification:
+// graph.plan_gather_items.  Light rows (in-degree <= heavy) contribute their in-edges (col, etype) in CSR order
+// followed by a flush item (row, -1); a new group starts at the first light row, when a row's first item falls
+// into a new `budget`-sized window of the stream, and at the first light row >= n_out.
+// Capacity: it_src / it_type E + N entries, grp_ptr N + 2.  Returns the number of groups (-1: budget + heavy + 1 > 64).
+int64_t renet_host_gather_items(int64_t N, const int32_t* row_ptr, const int32_t* col, const int32_t* etype,
+                                int64_t heavy, int64_t budget, int64_t n_out, int32_t* it_src, int32_t* it_type,
+                                int32_t* grp_ptr, int64_t* n_items, int64_t* n_groups_out) {
+    if (budget + heavy + 1 > 64 || budget < 1 || heavy < 0) return -1;
+    int64_t pos = 0, ng = 0, ngo = 0, prev_key = -1;
+    bool any = false, prev_side = false;
+    for (int64_t v = 0; v < N; ++v) {
+        const int64_t e0 = row_ptr[v], e1 = row_ptr[v + 1];
+        if (e1 - e0 > heavy) continue;
+        const int64_t key = pos / budget;
+        const bool side = v >= n_out;
+        if (!any || key != prev_key || side != prev_side) {
+            grp_ptr[ng++] = (int32_t)pos;
+            if (!side) ++ngo;
+        }
+        any = true; prev_key = key; prev_side = side;
+        for (int64_t e = e0; e < e1; ++e) { it_src[pos] = col[e]; it_type[pos] = etype[e]; ++pos; }
+        it_src[pos] = (int32_t)v; it_type[pos] = -1; ++pos;
+    }
+    grp_ptr[ng] = (int32_t)pos;
+    *n_items = pos;
+    *n_groups_out = ngo;
+    return ng;
+}
+
 }  // extern "C"

@@ -8,6 +8,7 @@
 // 72-97 % of rows) so no cross-lane reduction and no atomics are needed, and the epilogue
 // (norm, self-loop addend with dropout, ReLU) is fused.  HBM-bound integer/gather work: no MFMA.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -289,6 +290,293 @@ int launch_gather(const GatherArgs& a, bool tr, hipStream_t st) {
     return RENET_OK;
 }
 
+
+// =================================================================================================
+// Item-stream gather (renet_rgcn_gather_items): the row-group kernel above walks CSR rows and pays one
+// dependent load chain per row boundary (the epilogue's self-loop addend is fetched only when the row
+// is flushed) on top of {row_ptr} -> {indices} -> {rows}: 16+ serialised memory latencies per wave and
+// 91-105 VGPRs (4-5 waves per SIMD, a 2048-block launch needs two rounds) -- latency-, not bandwidth-bound.
+//
+// Here the host planner (graph.plan_gather_items) linearises the light rows (in-degree <= heavy_thresh) into
+// ONE item stream: the in-edges of row v as (source row, edge type) followed by a FLUSH item (v, -1), cut
+// into groups of <= 64 items (balanced by item count, never straddling the pruned-layer row prefix).  A wave
+// takes one group: one coalesced fetch brings all of its items, then the items go through the load pipe
+// UNR at a time -- an edge item loads the source row + its relation blocks, a flush item loads the row's
+// self-loop addend and norm -- so the addend is just another in-flight load and nothing in the loop depends on
+// anything but the item registers.  Chain per wave: {group bounds} -> {items} -> ceil(n/UNR) batches.
+// Hub rows (in-degree > heavy_thresh) are not in the stream: the first n_heavy workgroups of the launch reduce
+// one each with all their waves (longest work first), prefetching 64 edge indices per coalesced fetch.
+// Every branch is wave-uniform; no atomics; results do not depend on the launch geometry.
+// =================================================================================================
+struct ItemArgs {
+    GatherArgs g;
+    const int32_t* it_src;      // item stream: source row of an edge item / destination row of a flush item
+    const int32_t* it_type;     // edge type (type_s) or -1 for a flush item
+    const int32_t* grp_ptr;     // [n_groups + 1] item offsets of the groups
+    int n_groups;
+};
+
+// Buffer-descriptor loads (raw_buffer_load, hardware bounds check): an access past num_records returns 0 and
+// touches no memory.  Every load of the item loop is therefore UNCONDITIONAL -- a skipped item, a lane beyond the
+// feature row (lanes 50..63 at D = 200) or a flush item's relation block simply gets a descriptor with
+// num_records = 0 / an offset past the row.  This matters more than it looks: with `if (valid) x = *p;` around the
+// loads hipcc (ROCm 7.2) branches around each one and drains vmcnt at every merge point, i.e. the "UNR loads in
+// flight" of the row-group kernel above were in fact issued and waited for one at a time.
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    // {base[31:0], base[47:32] (stride 0), num_records, dst_sel/format word of gfx9-family raw buffers}
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float4 buf_load4s(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+// Span of a whole-tensor descriptor and the "skip" vector offset.  The hardware compares the offset with
+// num_records (whether or not the scalar offset takes part in the comparison, kOob + soffset stays above kBufSpan
+// and a valid lane's offset below it as long as the tensor is smaller than 1 GiB; the entry point checks that).
+constexpr uint32_t kBufSpan = 0x80000000u;
+constexpr uint32_t kOob = 0xC0000000u;
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, uint32_t voff, float4 o) {
+    u32x4 v;
+    v.x = __float_as_uint(o.x); v.y = __float_as_uint(o.y); v.z = __float_as_uint(o.z); v.w = __float_as_uint(o.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, 0);
+}
+
+constexpr int kItemFlush = -1;   // it_type of a flush item
+constexpr int kItemNop = -2;     // lanes past the end of a group
+
+template <int SI, int NCH, bool TR>
+__device__ __forceinline__ void row_epilogue(const GatherArgs& g, int row, bool has_ad, float sc, int lane,
+                                             const float4 (&acc)[NCH], const float4 (&ad)[NCH]) {
+    constexpr int CH = 100 * SI / 4;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(g.out + (size_t)row * (CH * 4), CH * 16);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        float4 o = f4_scale(acc[c], sc);
+        if (has_ad) o = f4_add(o, f4_mul(ad[c], renet_drop4(g.drop, (uint64_t)row * CH + ch)));
+        if (g.relu) {
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+        buf_store4(ro, (uint32_t)ch * 16u, o);               // lanes past the row: out of range => dropped
+    }
+}
+
+template <int SI, int NCH, int UNR, bool TR>
+__device__ __forceinline__ void gather_item_group(const ItemArgs& a, int grp) {
+    constexpr int D = 100 * SI;
+    constexpr int CH = D / 4;
+    constexpr int WCH = SI;
+    constexpr uint32_t ROWB = D * 4;                     // bytes of one feature row
+    constexpr uint32_t WROWB = D * SI * 4;               // bytes of one relation's blocks
+    const int lane = threadIdx.x & 63;
+    const GatherArgs& g = a.g;
+    const int i0 = a.grp_ptr[grp];
+    const int n = a.grp_ptr[grp + 1] - i0;               // <= 64 by construction of the plan
+    int my_src = 0, my_t = kItemNop;
+    if (lane < n) { my_src = a.it_src[i0 + lane]; my_t = a.it_type[i0 + lane]; }
+    // pin the wait for the item fetch HERE: left to the compiler it becomes an `s_waitcnt vmcnt(0)` at the loop
+    // header, which from the second batch on also waits for the previous batch's output stores
+    asm volatile("" : "+v"(my_src), "+v"(my_t));
+    const float* sp = g.scale ? g.scale : g.x;           // always a readable address
+    // whole-tensor descriptors (kernel arguments => provably wave-uniform, no waterfall loops); the row goes into
+    // the scalar offset, the lane into the vector offset; kOob in the vector offset = "do not load, return 0"
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, kBufSpan);
+    const __amdgpu_buffer_rsrc_t rad = make_rsrc(g.addend ? g.addend : g.x, kBufSpan);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.W, kBufSpan);
+    uint32_t xoff[NCH], woff[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t ch = (uint32_t)(lane + 64 * c);
+        xoff[c] = ch < (uint32_t)CH ? ch * 16u : kOob;
+        woff[c] = ch < (uint32_t)CH ? ch * (16u * WCH) : kOob;
+    }
+    float4 acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int k = 0; k < n; k += UNR) {
+        float4 xv[UNR][NCH];
+        float4 wv[UNR][NCH][WCH];
+        float scv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = min(k + u, 63);
+            const int src = __builtin_amdgcn_readlane(my_src, idx);            // wave-uniform (SGPR)
+            const int t = __builtin_amdgcn_readlane(my_t, idx);
+            const bool edge = t >= 0 && src < g.src_limit;
+            const bool flush = t == kItemFlush;
+            const bool flush_ad = flush && g.addend != nullptr && src < g.addend_rows;
+            int tt = t + g.shift;
+            if (tt >= g.T) tt -= g.T;
+            const uint32_t xs = (edge || flush_ad) ? (uint32_t)src * ROWB : 0u;
+            const uint32_t ws = edge ? (uint32_t)tt * WROWB : 0u;
+            scv[u] = sp[flush ? src : 0];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                // an item that loads nothing gets the out-of-range vector offset (a per-item descriptor with
+                // num_records = 0 would do the same in SGPRs, but costs 4 SGPRs per load in flight: > 96 SGPRs
+                // and one wave per SIMD less)
+                const uint32_t xo = (edge || flush_ad) ? xoff[c] : kOob;
+                const uint32_t wo = edge ? woff[c] : kOob;
+                xv[u][c] = flush_ad ? buf_load4s(rad, xo, xs) : buf_load4s(rx, xo, xs);
+#pragma unroll
+                for (int q = 0; q < WCH; ++q) wv[u][c][q] = buf_load4s(rw, wo + 16u * q, ws);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = min(k + u, 63);
+            const int src = __builtin_amdgcn_readlane(my_src, idx);
+            const int t = __builtin_amdgcn_readlane(my_t, idx);
+            if (t >= 0) {                                     // (a skipped edge multiplied zeros: harmless)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) blockmul<SI, TR>(xv[u][c], wv[u][c], acc[c]);
+            } else if (t == kItemFlush) {
+                const bool has_ad = g.addend != nullptr && src < g.addend_rows;
+                row_epilogue<SI, NCH, TR>(g, src, has_ad, g.scale ? scv[u] : 1.f, lane, acc, xv[u]);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+}
+
+// One workgroup per hub row: 64 edge indices per coalesced fetch, wave w takes entries w, w + WAVES, ... of
+// the window UNR at a time (unconditional buffer loads as above); wave 0 prefetches the row's addend;
+// fixed-order LDS combine => deterministic.
+template <int SI, int NCH, int UNR, bool TR, int WAVES>
+__device__ __forceinline__ void gather_hub_row(const GatherArgs& a, int v) {
+    constexpr int D = 100 * SI;
+    constexpr int CH = D / 4;
+    constexpr int WCH = SI;
+    constexpr uint32_t ROWB = D * 4;
+    constexpr uint32_t WROWB = D * SI * 4;
+    __shared__ float4 red[WAVES][CH];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int e0 = a.row_ptr[v], e1 = a.row_ptr[v + 1];
+    const bool has_ad = a.addend != nullptr && v < a.addend_rows;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, kBufSpan);
+    const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.addend ? a.addend : a.x, kBufSpan);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.W, kBufSpan);
+    uint32_t xoff[NCH], woff[NCH];
+    float4 adv[NCH];
+    float4 acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t ch = (uint32_t)(lane + 64 * c);
+        xoff[c] = ch < (uint32_t)CH ? ch * 16u : kOob;
+        woff[c] = ch < (uint32_t)CH ? ch * (16u * WCH) : kOob;
+        acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        adv[c] = buf_load4s(rad, (has_ad && wave == 0) ? xoff[c] : kOob, has_ad ? (uint32_t)v * ROWB : 0u);
+    }
+    for (int base = e0; base < e1; base += 64) {
+        const int cnt = min(64, e1 - base);
+        int my_col = 0x7fffffff, my_t = 0;
+        if (lane < cnt) {
+            my_col = a.col[base + lane];
+            my_t = a.etype[base + lane] + a.shift;
+            if (my_t >= a.T) my_t -= a.T;
+        }
+        for (int k = wave; k < cnt; k += WAVES * UNR) {
+            float4 xv[UNR][NCH];
+            float4 wv[UNR][NCH][WCH];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int kk = min(k + u * WAVES, 63);
+                const int src = __builtin_amdgcn_readlane(my_col, kk);      // lanes >= cnt hold INT_MAX => skipped
+                const int t = __builtin_amdgcn_readlane(my_t, kk);
+                const bool ok = (k + u * WAVES) < cnt && src < a.src_limit;
+                const uint32_t xs = ok ? (uint32_t)src * ROWB : 0u;
+                const uint32_t ws = ok ? (uint32_t)t * WROWB : 0u;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    xv[u][c] = buf_load4s(rx, ok ? xoff[c] : kOob, xs);
+#pragma unroll
+                    for (int q = 0; q < WCH; ++q) wv[u][c][q] = buf_load4s(rw, (ok ? woff[c] : kOob) + 16u * q, ws);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) blockmul<SI, TR>(xv[u][c], wv[u][c], acc[c]);   // zeros when skipped
+            }
+        }
+    }
+    if (wave != 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (lane + 64 * c < CH) red[wave][lane + 64 * c] = acc[c];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const float sc = a.scale ? a.scale[v] : 1.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < CH) {
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) acc[c] = f4_add(acc[c], red[w][ch]);
+            }
+        }
+        row_epilogue<SI, NCH, TR>(a, v, has_ad, sc, lane, acc, adv);
+    }
+}
+
+template <int SI, int NCH, int UNR, bool TR>
+__device__ __forceinline__ void gather_items_body(const ItemArgs& a) {
+    if ((int)blockIdx.x < a.g.n_heavy) {
+        gather_hub_row<SI, NCH, UNR, TR, kWaves>(a.g, a.g.heavy[blockIdx.x]);
+        return;
+    }
+    const int nb = gridDim.x - a.g.n_heavy;
+    const int vb = renet_xcd_block(blockIdx.x - a.g.n_heavy, nb);
+    const int grp = vb * kWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // neighbouring rows share an XCD
+    if (grp < a.n_groups) gather_item_group<SI, NCH, UNR, TR>(a, grp);
+}
+
+// Four entry kernels with distinct names so that a rocprof kernel trace separates the launch classes of a
+// training step: forward over the full batch graph (layer 1), forward over the subject-row prefix (layer 2),
+// and their backward-wrt-h counterparts (transposed relation blocks).
+#define RENET_GATHER_KERNEL(NAME, TRV)                                                                  \
+    template <int SI, int NCH, int UNR>                                                                 \
+    __global__ __launch_bounds__(kThreads) void NAME(ItemArgs a) { gather_items_body<SI, NCH, UNR, TRV>(a); }
+RENET_GATHER_KERNEL(rgcn_gather_fwd_full, false)
+RENET_GATHER_KERNEL(rgcn_gather_fwd_pruned, false)
+RENET_GATHER_KERNEL(rgcn_gather_bwdh_full, true)
+RENET_GATHER_KERNEL(rgcn_gather_bwdh_pruned, true)
+#undef RENET_GATHER_KERNEL
+
+template <int SI, int NCH, int UNR>
+int launch_gather_items(const ItemArgs& a, bool tr, bool pruned, hipStream_t st) {
+    int blocks = (a.n_groups + kWaves - 1) / kWaves;
+    blocks = max(8, (blocks + 7) & ~7);                    // multiple of 8 for the XCD remap
+    const dim3 grid(blocks + a.g.n_heavy), blk(kThreads);  // hub rows first, then the groups, in ONE launch
+    if (!tr && !pruned) RENET_LAUNCH((rgcn_gather_fwd_full<SI, NCH, UNR>), grid, blk, 0, st, a);
+    else if (!tr) RENET_LAUNCH((rgcn_gather_fwd_pruned<SI, NCH, UNR>), grid, blk, 0, st, a);
+    else if (!pruned) RENET_LAUNCH((rgcn_gather_bwdh_full<SI, NCH, UNR>), grid, blk, 0, st, a);
+    else RENET_LAUNCH((rgcn_gather_bwdh_pruned<SI, NCH, UNR>), grid, blk, 0, st, a);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+// edges in flight per wave (tuning knob, read once): RENET_GATHER_UNR in {2, 3, 4, 6, 8}; 0 / unset = default
+int gather_unr() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RENET_GATHER_UNR");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 // ---- backward prologue ----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rgcn_bwd_prep_kernel(const float4* __restrict__ g_out,
                                                             const float4* __restrict__ out,
@@ -550,6 +838,49 @@ int renet_rgcn_gather(const float* x, int D, const int32_t* row_ptr, const int32
         case 100: return launch_gather<1, 1, 4>(a, transpose_w != 0, st);
         case 200: return launch_gather<2, 1, 4>(a, transpose_w != 0, st);
         default: return launch_gather<4, 2, 2>(a, transpose_w != 0, st);
+    }
+}
+
+int renet_rgcn_gather_items(const float* x, int D, const int32_t* it_src, const int32_t* it_type,
+                            const int32_t* grp_ptr, int n_groups, const int32_t* row_ptr, const int32_t* col,
+                            const int32_t* etype, const float* scale, const float* W, int T, int type_shift,
+                            int transpose_w, const float* addend, float drop_p, uint64_t seed, int relu,
+                            float* out, int N, const int32_t* heavy_rows, int n_heavy, int src_limit,
+                            int addend_rows, int pruned, void* stream) {
+    if (!renet_dim_ok(D)) return RENET_ERR_UNSUPPORTED;
+    if (n_heavy < 0 || (n_heavy > 0 && !heavy_rows) || n_groups < 0) return RENET_ERR_BADARG;
+    if (N < 0 || T <= 0 || type_shift < 0 || type_shift >= T || drop_p < 0.f || drop_p >= 1.f)
+        return RENET_ERR_BADARG;
+    if (N == 0 || (n_groups == 0 && n_heavy == 0)) return RENET_OK;
+    // 32-bit buffer offsets with the skip marker above the span (kBufSpan / kOob): tensors must stay below 1 GiB
+    if ((size_t)N * D * sizeof(float) >= ((size_t)1 << 30) || (size_t)T * D * (D / 100) * sizeof(float) >= ((size_t)1 << 30))
+        return RENET_ERR_UNSUPPORTED;
+    ItemArgs a;
+    a.g.x = x; a.g.row_ptr = row_ptr; a.g.col = col; a.g.etype = etype; a.g.scale = scale; a.g.W = W;
+    a.g.addend = addend; a.g.out = out; a.g.N = N; a.g.T = T; a.g.shift = type_shift; a.g.relu = relu;
+    a.g.heavy = heavy_rows; a.g.n_heavy = n_heavy; a.g.heavy_thresh = 0;
+    a.g.src_limit = src_limit > 0 ? src_limit : 0x7fffffff;
+    a.g.addend_rows = addend_rows > 0 ? addend_rows : 0x7fffffff;
+    a.g.drop = make_drop(drop_p, seed);
+    a.it_src = it_src; a.it_type = it_type; a.grp_ptr = grp_ptr; a.n_groups = n_groups;
+    hipStream_t st = (hipStream_t)stream;
+    const bool tr = transpose_w != 0, pr = pruned != 0;
+    const int unr = gather_unr();
+    switch (D) {
+        case 100:
+            if (unr == 8) return launch_gather_items<1, 1, 8>(a, tr, pr, st);
+            if (unr == 4) return launch_gather_items<1, 1, 4>(a, tr, pr, st);
+            return launch_gather_items<1, 1, 6>(a, tr, pr, st);
+        case 200:
+            if (unr == 2) return launch_gather_items<2, 1, 2>(a, tr, pr, st);
+            if (unr == 3) return launch_gather_items<2, 1, 3>(a, tr, pr, st);
+            if (unr == 6) return launch_gather_items<2, 1, 6>(a, tr, pr, st);
+            if (unr == 8) return launch_gather_items<2, 1, 8>(a, tr, pr, st);
+            return launch_gather_items<2, 1, 4>(a, tr, pr, st);
+        default:
+            if (unr == 3) return launch_gather_items<4, 2, 3>(a, tr, pr, st);
+            if (unr == 4) return launch_gather_items<4, 2, 4>(a, tr, pr, st);
+            return launch_gather_items<4, 2, 2>(a, tr, pr, st);
     }
 }
 

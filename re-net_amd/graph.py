@@ -36,7 +36,53 @@ def _native():
 
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
-HEAVY = 8           # in-degree above which a row is reduced by a whole workgroup (hub rows; swept in tools/gather_bench.py)
+import os as _os
+# in-degree above which a row is reduced by a whole workgroup (hub rows), and the item budget of one wave's
+# row group in the gather kernel's item stream (plan_gather_items); swept in tools/gather_bench.py
+HEAVY = int(_os.environ.get('RENET_GATHER_HEAVY', '24'))
+GROUP_ITEMS = int(_os.environ.get('RENET_GATHER_GROUP', '32'))
+
+
+def plan_gather_items(row_ptr, col, etype, n_out, heavy, budget):
+    """Item stream of the gather-SpMM kernels (renet_rgcn_gather_items) -- numpy specification of
+    csrc/host_builder.cpp:renet_host_gather_items.
+
+    Every LIGHT row v (in-degree <= heavy) contributes its in-edges, in CSR order, as items (col[e], etype[e])
+    followed by one FLUSH item (v, -1); hub rows contribute nothing (a workgroup each reduces them).  The
+    stream is cut into groups, one per wave: a new group starts at the first light row, whenever a row's first
+    item falls into a new `budget`-sized window of the stream, and at the first light row >= n_out (so the
+    groups of rows < n_out are a prefix: the pruned last layer launches only those).  A group therefore holds
+    fewer than budget + heavy + 1 <= 64 items.
+    Returns (it_src[I], it_type[I], grp_ptr[G+1], n_groups_out) as int32 arrays / int."""
+    if budget + heavy + 1 > 64 or budget < 1 or heavy < 0:
+        raise ValueError('gather plan needs budget + heavy + 1 <= 64')
+    row_ptr = np.asarray(row_ptr, dtype=np.int64)
+    n = len(row_ptr) - 1
+    deg = np.diff(row_ptr)
+    light = np.nonzero(deg <= heavy)[0]
+    cnt = deg[light] + 1
+    start = np.concatenate(([0], np.cumsum(cnt)))                  # item offset of every light row (+ total)
+    total = int(start[-1])
+    it_src = np.empty(total, np.int32)
+    it_type = np.empty(total, np.int32)
+    if len(light):
+        e_idx = ragged_arange(row_ptr[light], deg[light])           # the light rows' edges, CSR order
+        e_pos = ragged_arange(start[:-1], deg[light])
+        it_src[e_pos] = np.asarray(col)[e_idx]
+        it_type[e_pos] = np.asarray(etype)[e_idx]
+        fpos = start[:-1] + deg[light]
+        it_src[fpos] = light
+        it_type[fpos] = -1
+        key = start[:-1] // budget
+        side = light >= n_out
+        first = np.ones(len(light), dtype=bool)
+        first[1:] = (key[1:] != key[:-1]) | (side[1:] != side[:-1])
+        grp_ptr = np.concatenate((start[:-1][first], [total])).astype(np.int32)
+        n_groups_out = int(np.count_nonzero(first & ~side))
+    else:
+        grp_ptr = np.zeros(1, np.int32)
+        n_groups_out = 0
+    return it_src, it_type, grp_ptr, n_groups_out
 
 
 class TimeGraph(object):
@@ -276,10 +322,10 @@ class HostBatch(object):
     INT_FIELDS = ('node_ent', 'row_ptr', 'col', 'etype', 'e_src', 'e_dst', 'chunk_ptr', 'chunk_type',
                   'type_chunk_ptr', 'subj_row', 'row_ent', 'row_rel', 'glob_row', 's_sorted', 'r_sorted',
                   'step_off', 'heavy_rows', 'heavy_rows_out', 'e_src2', 'e_dst2', 'chunk_ptr2', 'chunk_type2',
-                  'type_chunk_ptr2')
+                  'type_chunk_ptr2', 'it_src', 'it_type', 'grp_ptr')
     PLANS = ('plan_node_ent', 'plan_subj_row', 'plan_s', 'plan_r')
 
-    def set_edges(self, n, src, dst, et, num_types):
+    def set_edges(self, n, src, dst, et, num_types, heavy=None):
         """Directed edges (src -> dst, type et = type_s) -> the two device layouts:
         CSR by destination with relation-sorted rows (gather-SpMM forward / backward-wrt-h) and the
         relation-bucketed edge list cut into <= CHUNK-edge work items (backward-wrt-W)."""
@@ -288,6 +334,7 @@ class HostBatch(object):
         et = np.ascontiguousarray(et, dtype=np.int64)
         E = len(src)
         self.N, self.E, self.num_types = int(n), E, int(num_types)
+        thr = HEAVY if heavy is None else int(heavy)
         L = _native()
         if L is not None:
             T = int(num_types)
@@ -299,7 +346,7 @@ class HostBatch(object):
             cap = E // CHUNK + T + 1
             ctype, cptr = np.empty(cap, np.int32), np.empty(cap + 1, np.int32)
             nh, nc = ctypes.c_int64(0), ctypes.c_int64(0)
-            L.renet_host_edge_layouts(int(n), E, _p(src), _p(dst), _p(et), T, CHUNK, HEAVY, _p(self.col),
+            L.renet_host_edge_layouts(int(n), E, _p(src), _p(dst), _p(et), T, CHUNK, thr, _p(self.col),
                                       _p(self.etype), _p(self.row_ptr), _p(self.norm), _p(heavy),
                                       ctypes.byref(nh), _p(self.e_src), _p(self.e_dst), _p(self.type_chunk_ptr),
                                       _p(ctype), _p(cptr), ctypes.byref(nc))
@@ -314,7 +361,7 @@ class HostBatch(object):
         deg = np.bincount(dst, minlength=n)
         self.row_ptr = np.concatenate(([0], np.cumsum(deg))).astype(np.int32)
         self.norm = (1.0 / np.maximum(deg, 1)).astype(np.float32)            # utils.py:89-93
-        self.heavy_rows = np.nonzero(deg > HEAVY)[0].astype(np.int32)
+        self.heavy_rows = np.nonzero(deg > thr)[0].astype(np.int32)
         order2 = by_type
         self.e_src = src[order2].astype(np.int32)
         self.e_dst = dst[order2].astype(np.int32)
@@ -361,10 +408,37 @@ class HostBatch(object):
         self.type_chunk_ptr2, self.n_chunks2 = sub.type_chunk_ptr, sub.n_chunks
         return self
 
+    def set_gather_plan(self, n_out=None, heavy=None, budget=None):
+        """Item stream + wave groups of the gather kernels (plan_gather_items) for this CSR; n_out = rows of the
+        pruned last layer (default: all rows)."""
+        heavy = HEAVY if heavy is None else int(heavy)
+        budget = GROUP_ITEMS if budget is None else int(budget)
+        n_out = self.N if n_out is None else int(n_out)
+        self.heavy_thresh = heavy
+        L = _native()
+        if L is not None:
+            cap = self.E + self.N
+            it_src, it_type = np.empty(max(cap, 1), np.int32), np.empty(max(cap, 1), np.int32)
+            grp = np.empty(self.N + 2, np.int32)
+            ni, ngo = ctypes.c_int64(0), ctypes.c_int64(0)
+            ng = L.renet_host_gather_items(self.N, _p(self.row_ptr), _p(self.col), _p(self.etype), heavy, budget,
+                                           n_out, _p(it_src), _p(it_type), _p(grp), ctypes.byref(ni),
+                                           ctypes.byref(ngo))
+            if ng < 0:
+                raise ValueError('gather plan needs budget + heavy + 1 <= 64')
+            self.it_src, self.it_type = it_src[:ni.value].copy(), it_type[:ni.value].copy()
+            self.grp_ptr, self.n_groups, self.n_groups_out = grp[:ng + 1].copy(), int(ng), int(ngo.value)
+            return self
+        self.it_src, self.it_type, self.grp_ptr, self.n_groups_out = plan_gather_items(
+            self.row_ptr, self.col, self.etype, n_out, heavy, budget)
+        self.n_groups = len(self.grp_ptr) - 1
+        return self
+
     @classmethod
-    def from_edges(cls, n, src, dst, type_s, num_rels):
+    def from_edges(cls, n, src, dst, type_s, num_rels, heavy=None, budget=None):
         """A bare batch graph from explicit edge lists (tests, benchmarks)."""
-        return cls().set_edges(n, src, dst, type_s, 2 * num_rels)
+        return cls().set_edges(n, src, dst, type_s, 2 * num_rels, heavy=heavy).set_gather_plan(heavy=heavy,
+                                                                                               budget=budget)
 
 
 TABLE_ENTRIES = 1 << 24          # (slot, entity) lookup-table entries per chunk of _induced_edges
@@ -550,6 +624,7 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None, 
 
     hb.set_edges(N, src, dst, et, 2 * num_rels)
     hb.set_out_rows(hb.nA, src, dst, et)
+    hb.set_gather_plan(hb.nA)
 
     # packed (time-major) layout: row p = off[j] + i  <->  step j of sorted sequence i
     bs = (ln[None, :] > np.arange(L)[:, None]).sum(axis=1) if L else np.zeros(0, np.int64)
@@ -595,11 +670,13 @@ def build_full_graphs(graph_dict, times):
     dst = np.concatenate(dsts) if gs else np.zeros(0, np.int64)
     et = np.concatenate(ets) if gs else np.zeros(0, np.int64)
     hb.set_edges(hb.N, src, dst, et, 2 * num_rels)
+    hb.set_gather_plan()
     hb.plan_node_ent = SegPlan.host(hb.node_ent)
     return hb
 
 
-SCALARS = ('N', 'E', 'S', 'B', 'nnz', 'L', 'n_chunks', 'n_chunks2', 'nA', 'E_out', 'num_types', 'G')
+SCALARS = ('N', 'E', 'S', 'B', 'nnz', 'L', 'n_chunks', 'n_chunks2', 'nA', 'E_out', 'num_types', 'G', 'n_groups',
+           'n_groups_out', 'heavy_thresh')
 
 
 class PackedBatch(object):
@@ -665,7 +742,7 @@ class DeviceGraph(object):
             setattr(self, pn, p)
         self.norm = torch.from_numpy(pb.norm).to(device)
         self.ndata = {}                  # 'h' lives here, as on the reference's DGL graph
-        self.heavy_thresh = HEAVY
+        self.heavy_thresh = pb.scalars.get('heavy_thresh', HEAVY)
         for f in ('heavy_rows', 'heavy_rows_out'):
             if getattr(self, f, None) is not None and getattr(self, f).numel() == 0:
                 setattr(self, f, None)

@@ -103,9 +103,7 @@ class RGCNLayerFn(Function):
         pruned = n_out < n
         shift = g.num_types // 2 if reverse else 0                     # type_o = type_s +- R (utils.py:75-76)
         out = K.gemm(h[:n_out], loop_weight)                           # RGCN.py:35
-        K.rgcn_gather(h, g.row_ptr, g.col, g.etype, g.norm, weight, shift, False, out, drop_p, seed, relu, out,
-                      g.heavy_rows_out if pruned else g.heavy_rows, g.heavy_thresh,
-                      n_edges=g.E_out if pruned else None)
+        K.rgcn_gather_items(h, g, weight, shift, False, out, drop_p, seed, relu, out, use_norm=True, pruned=pruned)
         ctx.g, ctx.relu, ctx.drop_p, ctx.seed, ctx.shift, ctx.n_out = g, relu, drop_p, seed, shift, n_out
         ctx.save_for_backward(h, weight, loop_weight, out)
         return out
@@ -131,9 +129,8 @@ class RGCNLayerFn(Function):
         # dh += sum over out-edges W[type]^T gn[dst]  == same CSR rows, the PAIRED edge's type; with a pruned
         # forward only destinations < n_out carry gradient: skip the other sources, no addend past n_out
         pair_shift = (ctx.shift + g.num_types // 2) % g.num_types
-        K.rgcn_gather(gn, g.row_ptr, g.col, g.etype, None, weight, pair_shift, True, dh, 0.0, 0, False, dh,
-                      g.heavy_rows, g.heavy_thresh, n_out if pruned else 0, n_out if pruned else 0,
-                      n_edges=g.E_out if pruned else None)
+        K.rgcn_gather_items(gn, g, weight, pair_shift, True, dh, 0.0, 0, False, dh, use_norm=False, pruned=pruned,
+                            src_limit=n_out if pruned else 0, addend_rows=n_out if pruned else 0)
         acc = tgt_w is not None                                        # straight into weight.grad (beta = 1)
         d_w = tgt_w if acc else torch.empty_like(weight)
         if pruned:

@@ -27,6 +27,9 @@ _SIGNATURES = {
     'renet_rgcn_gather': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_int, c_int, c_void_p, c_float, c_u64, c_int, c_void_p, c_int, c_void_p,
                                   c_int, c_int, c_int, c_int, c_void_p]),
+    'renet_rgcn_gather_items': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_u64,
+                                        c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'renet_rgcn_bwd_prep': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_u64, c_int, c_int,
                                     c_void_p, c_void_p, c_void_p]),
     'renet_rgcn_bwd_w_workspace': (c_size_t, [c_int, c_int]),
@@ -76,6 +79,8 @@ _SIGNATURES = {
     'renet_host_edge_layouts': (None, [ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p, c_void_p, ctypes.c_int64,
                                        ctypes.c_int64, ctypes.c_int64] + [c_void_p] * 12),
     'renet_host_segplan': (ctypes.c_int64, [c_void_p, ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p, c_void_p]),
+    'renet_host_gather_items': (ctypes.c_int64, [ctypes.c_int64, c_void_p, c_void_p, c_void_p, ctypes.c_int64,
+                                                 ctypes.c_int64, ctypes.c_int64] + [c_void_p] * 5),
     'renet_segment_pool_fwd': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'renet_segment_pool_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),
@@ -220,6 +225,44 @@ def rgcn_gather(x, row_ptr, col, etype, scale, weight, type_shift, transpose_w, 
         # launches over the full batch graph (layer 1 and its backward) and the pruned ones (last layer:
         # subject rows only, a few thousand short rows -- launch-latency bound) are different regimes
         _timer.end('rgcn_gather' if n_edges is None else 'rgcn_gather_pruned', t0, nbytes=float(nbytes))
+    return out
+
+
+def gather_bytes(n_edges, n_rows, d, weight_numel, has_addend):
+    """Algorithmic bytes of one gather-SpMM launch: per edge one source row + its source and type
+    index; per output row the row itself + row_ptr + norm (+ the fused self-loop addend row, which the formula
+    allows to count when the epilogue is fused); the relation weight table once."""
+    return (n_edges * (d * 4 + 8) + n_rows * (d * 4 + 8) + weight_numel * 4 + (n_rows * d * 4 if has_addend else 0))
+
+
+def rgcn_gather_items(x, g, weight, type_shift, transpose_w, addend, drop_p, seed, relu, out, use_norm=True,
+                      pruned=False, src_limit=0, addend_rows=0):
+    """renet_rgcn_gather_items on the planned item stream of DeviceGraph `g` (graph.plan_gather_items).
+    pruned: the launch covers the row prefix [0, out.shape[0]) = g.nA (groups / hub rows of that prefix) in the
+    forward, or all rows with the edges whose source is >= src_limit skipped in the backward."""
+    d = x.shape[1]
+    n_rows = out.shape[0]
+    prefix = n_rows < g.N
+    n_groups = g.n_groups_out if prefix else g.n_groups
+    heavy = g.heavy_rows_out if prefix else g.heavy_rows
+    if max(x.numel(), out.numel()) * 4 >= (1 << 30):
+        # the item kernels address with 32-bit buffer offsets (< 1 GiB per tensor); beyond that (the global model
+        # over thousands of GDELT-sized graphs) the plain-CSR kernel with 64-bit addressing takes over
+        return rgcn_gather(x, g.row_ptr, g.col, g.etype, g.norm if use_norm else None, weight, type_shift,
+                           transpose_w, addend, drop_p, seed, relu, out, heavy, g.heavy_thresh, src_limit,
+                           addend_rows, n_edges=g.E_out if pruned else None)
+    t0 = _timer.begin() if _timer is not None else None
+    _check(lib().renet_rgcn_gather_items(_f32(x), d, _i32(g.it_src), _i32(g.it_type), _i32(g.grp_ptr), int(n_groups),
+                                         _i32(g.row_ptr), _i32(g.col), _i32(g.etype),
+                                         _f32(g.norm) if use_norm else None, _f32(weight), weight.shape[0],
+                                         int(type_shift), int(transpose_w), _f32(addend), float(drop_p), int(seed),
+                                         int(relu), _f32(out), n_rows, _i32(heavy) if heavy is not None else None,
+                                         heavy.numel() if heavy is not None else 0, int(src_limit),
+                                         int(addend_rows), int(pruned), _stream()), 'rgcn_gather_items')
+    if t0 is not None:
+        e = g.E_out if pruned else g.E
+        name = 'rgcn_gather_%s_%s' % ('bwdh' if transpose_w else 'fwd', 'pruned' if pruned else 'full')
+        _timer.end(name, t0, nbytes=float(gather_bytes(e, n_rows, d, weight.numel(), addend is not None)))
     return out
 
 
@@ -399,9 +442,12 @@ def gru_fwd_multi(gis, step_off_host, hdim, w_hhs, b_hhs, out_rows=0):
         _f32(t)
     nbytes = len(gis) * lib().renet_gru_workspace(b, hdim)
     ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
+    t0 = _timer.begin() if _timer is not None else None
     _check(lib().renet_gru_fwd_multi(len(gis), _ptrs(gis), ctypes.cast(step_off_host, c_void_p), L, hdim,
                                      _ptrs(w_hhs), _ptrs(b_hhs), _ptrs(hs), out_rows, _ptrs(svs), ws.data_ptr(),
                                      nbytes, _stream()), 'gru_fwd_multi')
+    if t0 is not None:      # recurrence only: h_{t-1} @ W_hh^T per step, 2 * 3H * H flops per packed row
+        _timer.end('gru_recurrence', t0, flops=sum(2.0 * 3 * hdim * hdim * g.shape[0] for g in gis))
     return hs, svs
 
 
@@ -415,9 +461,12 @@ def gru_bwd_multi(dh_lasts, step_off_host, hdim, w_hhs, saveds):
         _f32(t)
     nbytes = n * lib().renet_gru_workspace(dh_lasts[0].shape[0], hdim)
     ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
+    t0 = _timer.begin() if _timer is not None else None
     _check(lib().renet_gru_bwd_multi(n, _ptrs(dh_lasts), ctypes.cast(step_off_host, c_void_p), L, hdim,
                                      _ptrs(w_hhs), _ptrs(saveds), _ptrs(d_gis), _ptrs(d_ghs), ws.data_ptr(),
                                      nbytes, _stream()), 'gru_bwd_multi')
+    if t0 is not None:      # dh_{t-1} += d_gates @ W_hh per step: the same 2 * 3H * H flops per packed row
+        _timer.end('gru_recurrence', t0, flops=sum(2.0 * 3 * hdim * hdim * s_.shape[0] for s_ in saveds))
     return d_gis, d_ghs
 
 

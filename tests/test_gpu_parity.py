@@ -385,8 +385,11 @@ def test_full_size_gather_properties(dev):
 
     def A(x, shift=0, tr=False, graph=g, heavy=True):
         out = torch.empty_like(x)
-        K.rgcn_gather(x, graph.row_ptr, graph.col, graph.etype, graph.norm if not tr else None, w, shift, tr,
-                      None, 0.0, 0, False, out, graph.heavy_rows if heavy else None, graph.heavy_thresh)
+        if heavy:       # the production kernel: planned item stream + one workgroup per hub row
+            K.rgcn_gather_items(x, graph, w, shift, tr, None, 0.0, 0, False, out, use_norm=not tr)
+        else:           # the plain-CSR kernel walking every row, hubs included, in one wave
+            K.rgcn_gather(x, graph.row_ptr, graph.col, graph.etype, graph.norm if not tr else None, w, shift, tr,
+                          None, 0.0, 0, False, out, None, 0)
         return out
     y1, y2, y12 = A(x1), A(x2), A(2.0 * x1 - 3.0 * x2)
     # hub rows (in-degree > graph.HEAVY) go through the workgroup-per-row kernel: same values as the

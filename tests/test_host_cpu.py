@@ -514,3 +514,59 @@ def test_batched_filtered_ranks_equal_the_per_quadruple_rule():
     for i in range(n):
         g = scores[i, o[i]]
         assert raw[i] == float((scores[i] > g).sum()) + (float((scores[i] == g).sum()) - 1.0) / 2 + 1
+
+
+@pytest.mark.parametrize('heavy,budget', [(24, 32), (8, 16), (0, 1), (40, 23), (62, 1)])
+def test_gather_item_plan_covers_every_light_row_once(heavy, budget):
+    """graph.plan_gather_items (numpy specification) and csrc/host_builder.cpp:renet_host_gather_items: the item
+    stream replays the CSR of the light rows exactly (edges in row order, then the row's flush item), hub rows are
+    absent, every group holds <= 64 items, the groups of rows < n_out are a prefix and no group straddles n_out."""
+    rng = np.random.RandomState(heavy * 100 + budget)
+    n = 700
+    deg = np.minimum(rng.zipf(1.6, n) - 1, 300)                   # many 0/1/2, a Zipf tail of hubs
+    deg[rng.randint(0, n, 40)] = 0
+    dst = np.repeat(np.arange(n), deg)
+    src = rng.randint(0, n, len(dst))
+    et = rng.randint(0, 14, len(dst))
+    n_out = 233
+    plans = {}
+    for native in (False, True):
+        G.NATIVE = native
+        try:
+            hb = G.HostBatch().set_edges(n, src, dst, et, 14, heavy=heavy)
+            hb.set_out_rows(n_out, src, dst, et)
+            hb.set_gather_plan(n_out, heavy=heavy, budget=budget)
+            plans[native] = hb
+        finally:
+            G.NATIVE = True
+    a, b = plans[False], plans[True]
+    for f in ('it_src', 'it_type', 'grp_ptr', 'heavy_rows', 'heavy_rows_out'):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert (a.n_groups, a.n_groups_out) == (b.n_groups, b.n_groups_out)
+    hb = b
+    d = np.diff(hb.row_ptr)
+    assert np.array_equal(hb.heavy_rows, np.nonzero(d > heavy)[0])
+    sizes = np.diff(hb.grp_ptr)
+    assert len(sizes) == hb.n_groups and sizes.min() >= 1 and sizes.max() <= 64 and hb.grp_ptr[0] == 0
+    assert hb.grp_ptr[-1] == len(hb.it_src) == int(d[d <= heavy].sum() + np.count_nonzero(d <= heavy))
+    # replay
+    seen, cur = [], []
+    grp_of_row = {}
+    for gi in range(hb.n_groups):
+        for i in range(hb.grp_ptr[gi], hb.grp_ptr[gi + 1]):
+            if hb.it_type[i] >= 0:
+                cur.append((int(hb.it_src[i]), int(hb.it_type[i])))
+            else:
+                assert hb.it_type[i] == -1
+                v = int(hb.it_src[i])
+                e0, e1 = hb.row_ptr[v], hb.row_ptr[v + 1]
+                assert cur == list(zip(hb.col[e0:e1].tolist(), hb.etype[e0:e1].tolist())), v
+                seen.append(v)
+                grp_of_row[v] = gi
+                cur = []
+        assert cur == []                                           # a row never straddles two groups
+    assert seen == np.nonzero(d <= heavy)[0].tolist()              # each light row once, ascending
+    for v, gi in grp_of_row.items():
+        assert (gi < hb.n_groups_out) == (v < n_out)
+    with pytest.raises(ValueError):
+        G.plan_gather_items(hb.row_ptr, hb.col, hb.etype, n_out, 40, 24)
