@@ -89,7 +89,7 @@ int renet_rgcn_gather(const float* x, int D, const int32_t* row_ptr, const int32
  * (heavy_rows[n_heavy], in-degree > heavy, NOT in the stream) are reduced by one workgroup each in the same
  * launch.  row_ptr / col / etype are only read for hub rows.  pruned != 0 only selects the kernel NAME
  * (rgcn_gather_{fwd,bwdh}_{full,pruned}: a kernel trace separates the four launch classes of a training step);
- * the caller passes the group / hub-row prefix that covers rows < N.  x, addend, W must each be smaller than 1 GiB.
+ * the caller passes the group / hub-row prefix that covers rows < N.  x, addend, out, W must each be smaller than 2 GiB (32-bit buffer offsets).
  * Replaces RGCN.py:79-94 + 42-50 exactly as renet_rgcn_gather does. */
 int renet_rgcn_gather_items(const float* x, int D, const int32_t* it_src, const int32_t* it_type,
                             const int32_t* grp_ptr, int n_groups, const int32_t* row_ptr, const int32_t* col,
@@ -110,7 +110,8 @@ int renet_rgcn_bwd_prep(const float* g_out, const float* out, const float* norm,
  *   chunk c covers sorted edges [chunk_ptr[c], chunk_ptr[c+1]) , all of type chunk_type[c];
  *   type_chunk_ptr[T+1] lists, per type, its range of chunks; the stored type t accumulates into
  *   dW[(t + type_shift) mod T] (same convention as renet_rgcn_gather).  Two deterministic passes:
- *   per-chunk partial sums into `workspace` (n_chunks * D*D/100 floats), then a per-type reduction. */
+ *   per-chunk partial sums into `workspace` (n_chunks * D*D/100 floats), then a per-type reduction.
+ *   x and gn must each be smaller than 2 GiB (rows are addressed with 32-bit buffer offsets). */
 size_t renet_rgcn_bwd_w_workspace(int n_chunks, int D);
 int renet_rgcn_bwd_w(const float* x, const float* gn, const int32_t* e_src, const int32_t* e_dst,
                      const int32_t* chunk_ptr, const int32_t* chunk_type, int n_chunks,

@@ -338,10 +338,11 @@ __device__ __forceinline__ float4 buf_load4s(__amdgpu_buffer_rsrc_t r, uint32_t 
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 // Span of a whole-tensor descriptor and the "skip" vector offset.  The hardware compares the offset with
-// num_records (whether or not the scalar offset takes part in the comparison, kOob + soffset stays above kBufSpan
-// and a valid lane's offset below it as long as the tensor is smaller than 1 GiB; the entry point checks that).
+// num_records: whether or not the scalar (row) offset takes part in that comparison, kOob (+ row offset, no 32-bit
+// wrap) is out of range and a valid lane's offset (+ row offset) in range as long as the tensor is smaller than
+// 2 GiB; the entry points check that.
 constexpr uint32_t kBufSpan = 0x80000000u;
-constexpr uint32_t kOob = 0xC0000000u;
+constexpr uint32_t kOob = 0x80000000u;
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, uint32_t voff, float4 o) {
     u32x4 v;
     v.x = __float_as_uint(o.x); v.y = __float_as_uint(o.y); v.z = __float_as_uint(o.z); v.w = __float_as_uint(o.w);
@@ -409,7 +410,7 @@ __device__ __forceinline__ void gather_item_group(const ItemArgs& a, int grp) {
         for (int u = 0; u < UNR; ++u) {
             const int idx = min(k + u, 63);
             const int src = __builtin_amdgcn_readlane(my_src, idx);            // wave-uniform (SGPR)
-            const int t = __builtin_amdgcn_readlane(my_t, idx);
+            const int t = (k + u) < n ? __builtin_amdgcn_readlane(my_t, idx) : kItemNop;   // (n may be 64)
             const bool edge = t >= 0 && src < g.src_limit;
             const bool flush = t == kItemFlush;
             const bool flush_ad = flush && g.addend != nullptr && src < g.addend_rows;
@@ -434,7 +435,7 @@ __device__ __forceinline__ void gather_item_group(const ItemArgs& a, int grp) {
         for (int u = 0; u < UNR; ++u) {
             const int idx = min(k + u, 63);
             const int src = __builtin_amdgcn_readlane(my_src, idx);
-            const int t = __builtin_amdgcn_readlane(my_t, idx);
+            const int t = (k + u) < n ? __builtin_amdgcn_readlane(my_t, idx) : kItemNop;
             if (t >= 0) {                                     // (a skipped edge multiplied zeros: harmless)
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) blockmul<SI, TR>(xv[u][c], wv[u][c], acc[c]);
@@ -601,19 +602,27 @@ __global__ __launch_bounds__(256) void rgcn_bwd_prep_kernel(const float4* __rest
 
 // ---- dW: per-chunk partial outer products -----------------------------------------------------
 // one wave per chunk (all edges of the chunk have the same relation type); lane = float4 chunk of
-// the feature row; SI*4 accumulators per lane-chunk (the si x so block entries).
+// the feature row; SI*4 accumulators per lane-chunk (the si x so block entries).  Row loads are unconditional
+// buffer loads (see the item-stream gather): an edge slot past the chunk's end reads nothing and multiplies zeros.
 template <int SI, int NCH>
 __global__ __launch_bounds__(kThreads) void rgcn_bwd_w_partial_kernel(
-    const float4* __restrict__ x4, const float4* __restrict__ g4, const int32_t* __restrict__ e_src,
+    const float* __restrict__ x, const float* __restrict__ gmat, const int32_t* __restrict__ e_src,
     const int32_t* __restrict__ e_dst, const int32_t* __restrict__ chunk_ptr, int n_chunks,
     float4* __restrict__ partial) {
     constexpr int D = 100 * SI;
     constexpr int CH = D / 4;
     constexpr int WROW4 = D * SI / 4;
+    constexpr uint32_t ROWB = D * 4;
+    constexpr int UNR = (SI == 4) ? 2 : 4;              // edges with both row loads in flight together
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const int c = blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (c >= n_chunks) return;
     const int e0 = chunk_ptr[c], e1 = chunk_ptr[c + 1];
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, kBufSpan);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(gmat, kBufSpan);
+    uint32_t off[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) off[q] = (uint32_t)(lane + 64 * q) < (uint32_t)CH ? (uint32_t)(lane + 64 * q) * 16u : kOob;
     float4 acc[NCH][SI];
 #pragma unroll
     for (int q = 0; q < NCH; ++q)
@@ -624,57 +633,50 @@ __global__ __launch_bounds__(kThreads) void rgcn_bwd_w_partial_kernel(
         const int my_e = eb + lane;
         int my_s = 0, my_d = 0;
         if (my_e < e1) { my_s = e_src[my_e]; my_d = e_dst[my_e]; }
+        asm volatile("" : "+v"(my_s), "+v"(my_d));          // wait for the indices here, not inside the loop
         const int cnt = min(64, e1 - eb);
-        constexpr int UNR = (SI == 4) ? 2 : 4;              // edges with both row loads in flight together
         for (int k0 = 0; k0 < cnt; k0 += UNR) {
             float4 xv[UNR][NCH], gv[UNR][NCH];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                if (k0 + u < cnt) {
-                    const int s = __builtin_amdgcn_readlane(my_s, k0 + u);
-                    const int d = __builtin_amdgcn_readlane(my_d, k0 + u);
+                const int kk = min(k0 + u, 63);
+                const bool ok = (k0 + u) < cnt;
+                const uint32_t so = ok ? (uint32_t)__builtin_amdgcn_readlane(my_s, kk) * ROWB : 0u;
+                const uint32_t dof = ok ? (uint32_t)__builtin_amdgcn_readlane(my_d, kk) * ROWB : 0u;
 #pragma unroll
-                    for (int q = 0; q < NCH; ++q) {
-                        const int ch = lane + 64 * q;
-                        if (ch < CH) {
-                            xv[u][q] = x4[(size_t)s * CH + ch];
-                            gv[u][q] = g4[(size_t)d * CH + ch];
-                        }
-                    }
+                for (int q = 0; q < NCH; ++q) {
+                    xv[u][q] = buf_load4s(rx, ok ? off[q] : kOob, so);
+                    gv[u][q] = buf_load4s(rg, ok ? off[q] : kOob, dof);
                 }
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                if (k0 + u < cnt) {
 #pragma unroll
-                    for (int q = 0; q < NCH; ++q) {
-                        if (lane + 64 * q < CH) {
-                        if constexpr (SI == 1) {
-                            acc[q][0].x = fmaf(xv[u][q].x, gv[u][q].x, acc[q][0].x);
-                            acc[q][0].y = fmaf(xv[u][q].y, gv[u][q].y, acc[q][0].y);
-                            acc[q][0].z = fmaf(xv[u][q].z, gv[u][q].z, acc[q][0].z);
-                            acc[q][0].w = fmaf(xv[u][q].w, gv[u][q].w, acc[q][0].w);
-                        } else if constexpr (SI == 2) {
-                            // block0: dW[i][j] = x_i g_j (i,j in {0,1}); block1 with elements 2,3
-                            acc[q][0].x = fmaf(xv[u][q].x, gv[u][q].x, acc[q][0].x);
-                            acc[q][0].y = fmaf(xv[u][q].x, gv[u][q].y, acc[q][0].y);
-                            acc[q][0].z = fmaf(xv[u][q].y, gv[u][q].x, acc[q][0].z);
-                            acc[q][0].w = fmaf(xv[u][q].y, gv[u][q].y, acc[q][0].w);
-                            acc[q][1].x = fmaf(xv[u][q].z, gv[u][q].z, acc[q][1].x);
-                            acc[q][1].y = fmaf(xv[u][q].z, gv[u][q].w, acc[q][1].y);
-                            acc[q][1].z = fmaf(xv[u][q].w, gv[u][q].z, acc[q][1].z);
-                            acc[q][1].w = fmaf(xv[u][q].w, gv[u][q].w, acc[q][1].w);
-                        } else {
-                            const float xs[4] = {xv[u][q].x, xv[u][q].y, xv[u][q].z, xv[u][q].w};
-    #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                acc[q][i].x = fmaf(xs[i], gv[u][q].x, acc[q][i].x);
-                                acc[q][i].y = fmaf(xs[i], gv[u][q].y, acc[q][i].y);
-                                acc[q][i].z = fmaf(xs[i], gv[u][q].z, acc[q][i].z);
-                                acc[q][i].w = fmaf(xs[i], gv[u][q].w, acc[q][i].w);
-                            }
+                for (int q = 0; q < NCH; ++q) {
+                    if constexpr (SI == 1) {
+                        acc[q][0].x = fmaf(xv[u][q].x, gv[u][q].x, acc[q][0].x);
+                        acc[q][0].y = fmaf(xv[u][q].y, gv[u][q].y, acc[q][0].y);
+                        acc[q][0].z = fmaf(xv[u][q].z, gv[u][q].z, acc[q][0].z);
+                        acc[q][0].w = fmaf(xv[u][q].w, gv[u][q].w, acc[q][0].w);
+                    } else if constexpr (SI == 2) {
+                        // block0: dW[i][j] = x_i g_j (i,j in {0,1}); block1 with elements 2,3
+                        acc[q][0].x = fmaf(xv[u][q].x, gv[u][q].x, acc[q][0].x);
+                        acc[q][0].y = fmaf(xv[u][q].x, gv[u][q].y, acc[q][0].y);
+                        acc[q][0].z = fmaf(xv[u][q].y, gv[u][q].x, acc[q][0].z);
+                        acc[q][0].w = fmaf(xv[u][q].y, gv[u][q].y, acc[q][0].w);
+                        acc[q][1].x = fmaf(xv[u][q].z, gv[u][q].z, acc[q][1].x);
+                        acc[q][1].y = fmaf(xv[u][q].z, gv[u][q].w, acc[q][1].y);
+                        acc[q][1].z = fmaf(xv[u][q].w, gv[u][q].z, acc[q][1].z);
+                        acc[q][1].w = fmaf(xv[u][q].w, gv[u][q].w, acc[q][1].w);
+                    } else {
+                        const float xs[4] = {xv[u][q].x, xv[u][q].y, xv[u][q].z, xv[u][q].w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            acc[q][i].x = fmaf(xs[i], gv[u][q].x, acc[q][i].x);
+                            acc[q][i].y = fmaf(xs[i], gv[u][q].y, acc[q][i].y);
+                            acc[q][i].z = fmaf(xs[i], gv[u][q].z, acc[q][i].z);
+                            acc[q][i].w = fmaf(xs[i], gv[u][q].w, acc[q][i].w);
                         }
-                    }
                     }
                 }
             }
@@ -852,8 +854,8 @@ int renet_rgcn_gather_items(const float* x, int D, const int32_t* it_src, const 
     if (N < 0 || T <= 0 || type_shift < 0 || type_shift >= T || drop_p < 0.f || drop_p >= 1.f)
         return RENET_ERR_BADARG;
     if (N == 0 || (n_groups == 0 && n_heavy == 0)) return RENET_OK;
-    // 32-bit buffer offsets with the skip marker above the span (kBufSpan / kOob): tensors must stay below 1 GiB
-    if ((size_t)N * D * sizeof(float) >= ((size_t)1 << 30) || (size_t)T * D * (D / 100) * sizeof(float) >= ((size_t)1 << 30))
+    // 32-bit buffer offsets with the skip marker at the span (kBufSpan / kOob): tensors must stay below 2 GiB
+    if ((size_t)N * D * sizeof(float) >= ((size_t)1 << 31) || (size_t)T * D * (D / 100) * sizeof(float) >= ((size_t)1 << 31))
         return RENET_ERR_UNSUPPORTED;
     ItemArgs a;
     a.g.x = x; a.g.row_ptr = row_ptr; a.g.col = col; a.g.etype = etype; a.g.scale = scale; a.g.W = W;
@@ -873,10 +875,10 @@ int renet_rgcn_gather_items(const float* x, int D, const int32_t* it_src, const 
             return launch_gather_items<1, 1, 6>(a, tr, pr, st);
         case 200:
             if (unr == 2) return launch_gather_items<2, 1, 2>(a, tr, pr, st);
-            if (unr == 3) return launch_gather_items<2, 1, 3>(a, tr, pr, st);
+            if (unr == 4) return launch_gather_items<2, 1, 4>(a, tr, pr, st);
             if (unr == 6) return launch_gather_items<2, 1, 6>(a, tr, pr, st);
             if (unr == 8) return launch_gather_items<2, 1, 8>(a, tr, pr, st);
-            return launch_gather_items<2, 1, 4>(a, tr, pr, st);
+            return launch_gather_items<2, 1, 3>(a, tr, pr, st);      // 60 VGPRs: 8 waves per SIMD
         default:
             if (unr == 3) return launch_gather_items<4, 2, 3>(a, tr, pr, st);
             if (unr == 4) return launch_gather_items<4, 2, 4>(a, tr, pr, st);
@@ -915,8 +917,8 @@ int renet_rgcn_bwd_w(const float* x, const float* gn, const int32_t* e_src, cons
     const int WROW4 = D * SI / 4;
     if (n_chunks > 0) {
         dim3 grid((n_chunks + kWaves - 1) / kWaves);
-        const float4* x4 = (const float4*)x;
-        const float4* g4 = (const float4*)gn;
+        const float* x4 = x;
+        const float* g4 = gn;
         float4* p4 = (float4*)workspace;
         switch (D) {
             case 100:

@@ -125,10 +125,13 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits,
+// `dlogits` may ALIAS `logits` (the training path turns the logits into their gradient in place): neither pointer
+// may be __restrict__ -- with it hipcc is free to sink thread 0's read of x[target] below the barrier, past other
+// waves' stores to the same row (seen as a rare wrong LOSS with correct gradients).
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* logits,
                                                          const int32_t* __restrict__ target, int C, int ld,
                                                          float grad_scale, float* __restrict__ row_loss,
-                                                         float* __restrict__ dlogits) {
+                                                         float* dlogits) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -164,10 +167,10 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
 // re-read the row from the fabric (all 1024 rows are in flight at once, 94 MB against 32 MB of L2); here the row is
 // read ONCE by 1024 threads (16 waves keep enough loads in flight for one workgroup per CU) and the max / sum / write
 // passes run out of LDS.
-__global__ __launch_bounds__(1024) void softmax_ce_lds_kernel(const float* __restrict__ logits,
+__global__ __launch_bounds__(1024) void softmax_ce_lds_kernel(const float* logits,
                                                               const int32_t* __restrict__ target, int C, int ld,
                                                               float grad_scale, float* __restrict__ row_loss,
-                                                              float* __restrict__ dlogits) {
+                                                              float* dlogits) {
     extern __shared__ float row[];
     __shared__ float red[16];
     const int b = blockIdx.x;
@@ -185,6 +188,8 @@ __global__ __launch_bounds__(1024) void softmax_ce_lds_kernel(const float* __res
     m = red[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    const int t = target[b];
+    const float xt = row[t];                         // the staged copy, before the exp pass overwrites it
     __syncthreads();
     float s = 0.f;
     for (int c = threadIdx.x; c < C; c += 1024) {
@@ -198,9 +203,7 @@ __global__ __launch_bounds__(1024) void softmax_ce_lds_kernel(const float* __res
     s = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) s += red[w];
-    const int t = target[b];
-    if (threadIdx.x == 0) row_loss[b] = logf(s) + m - x[t];
-    __syncthreads();                                  // x[t] read before dlogits may overwrite it (alias allowed)
+    if (threadIdx.x == 0) row_loss[b] = logf(s) + m - xt;
     if (dlogits) {
         float* dx = dlogits + (size_t)b * ld;
         const float inv = 1.f / s;

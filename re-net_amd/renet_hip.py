@@ -245,9 +245,9 @@ def rgcn_gather_items(x, g, weight, type_shift, transpose_w, addend, drop_p, see
     prefix = n_rows < g.N
     n_groups = g.n_groups_out if prefix else g.n_groups
     heavy = g.heavy_rows_out if prefix else g.heavy_rows
-    if max(x.numel(), out.numel()) * 4 >= (1 << 30):
-        # the item kernels address with 32-bit buffer offsets (< 1 GiB per tensor); beyond that (the global model
-        # over thousands of GDELT-sized graphs) the plain-CSR kernel with 64-bit addressing takes over
+    if max(x.numel(), out.numel()) * 4 >= (1 << 31):
+        # the item kernels address with 32-bit buffer offsets (< 2 GiB per tensor: 2.6 M rows at D = 200); beyond
+        # that the plain-CSR kernel with 64-bit addressing takes over
         return rgcn_gather(x, g.row_ptr, g.col, g.etype, g.norm if use_norm else None, weight, type_shift,
                            transpose_w, addend, drop_p, seed, relu, out, heavy, g.heavy_thresh, src_limit,
                            addend_rows, n_edges=g.E_out if pruned else None)
@@ -275,6 +275,8 @@ def rgcn_bwd_prep(g_out, out, norm, relu, drop_p, seed, gn, g_loop):
 def rgcn_bwd_w(x, gn, e_src, e_dst, chunk_ptr, chunk_type, n_chunks, type_chunk_ptr, num_types, type_shift,
                dW, beta=0.0):
     d = x.shape[1]
+    if max(x.numel(), gn.numel()) * 4 >= (1 << 31):
+        raise RenetHipError('rgcn_bwd_w addresses rows with 32-bit buffer offsets: x / gn must be smaller than 2 GiB')
     nbytes = lib().renet_rgcn_bwd_w_workspace(n_chunks, d)
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
     t0 = _timer.begin() if _timer is not None else None

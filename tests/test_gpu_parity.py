@@ -440,6 +440,28 @@ def test_full_size_dw_matches_fp64_sampled(dev):
         np.testing.assert_allclose(got[t], ref, rtol=1e-4, atol=1e-4 * max(1.0, len(e)) ** 0.5)
 
 
+def test_softmax_ce_in_place_is_race_free(dev):
+    """renet_softmax_ce with dlogits aliasing logits (the training path): the row loss must not depend on when other
+    waves overwrite the row.  (Round 2 found thread 0's read of x[target] sunk below the barrier by the compiler
+    because both pointers were declared __restrict__: a rare wrong LOSS with correct gradients.)  Repeated launches
+    on recycled allocations, against torch's cross entropy; both kernels (row in LDS / streamed)."""
+    import renet_hip as K
+    torch.manual_seed(3)
+    for b, c in ((96, 150), (64, 23033), (33, 40000)):
+        logits0 = torch.randn(b, c, device=dev) * 3
+        tgt = torch.randint(0, c, (b,), device=dev)
+        ref = torch.nn.functional.cross_entropy(logits0, tgt, reduction='none')
+        p = torch.softmax(logits0, dim=1)
+        p[torch.arange(b, device=dev), tgt] -= 1.0
+        for it in range(60):
+            junk = torch.full((b * c + it,), float('nan'), device=dev)
+            del junk
+            lg = logits0.clone()
+            loss = K.softmax_ce(lg, tgt.int(), 0.5, True)
+            assert float((loss - ref).abs().max()) < 1e-4, (b, c, it)
+            assert float((lg - 0.5 * p).abs().max()) < 1e-5, (b, c, it)
+
+
 def test_stale_hip_error_of_another_caller_does_not_fail_our_launches(dev):
     """hipGetLastError() is per-thread state shared with every other HIP user in the process: an expected-to-fail
     call of the host framework (here: hipMalloc of an absurd size) must not be reported as OUR launch failure."""

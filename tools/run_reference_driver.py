@@ -18,6 +18,10 @@ def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
     script = os.path.abspath(sys.argv[1])
+    # The drivers were written for torch 1.6 (README.md:37): torch.load(path, map_location=...) on checkpoints that
+    # hold numpy arrays (the per-entity history lists, train.py:189-195).  torch >= 2.6 defaults to
+    # weights_only=True and refuses those; restore the old default for this run instead of editing the drivers.
+    os.environ.setdefault('TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD', '1')
     sys.path.insert(0, os.path.join(ROOT, 're-net_amd'))
     sys.argv = [script] + sys.argv[2:]
     runpy.run_path(script, run_name='__main__')
