@@ -40,7 +40,7 @@ import os as _os
 # in-degree above which a row is reduced by a whole workgroup (hub rows), and the item budget of one wave's
 # row group in the gather kernel's item stream (plan_gather_items); swept in tools/gather_bench.py
 HEAVY = int(_os.environ.get('RENET_GATHER_HEAVY', '8'))
-GROUP_ITEMS = int(_os.environ.get('RENET_GATHER_GROUP', '16'))
+GROUP_ITEMS = int(_os.environ.get('RENET_GATHER_GROUP', '12'))
 
 
 def plan_gather_items(row_ptr, col, etype, n_out, heavy, budget):

@@ -125,9 +125,9 @@ def main():
         results.append(bench_graph(build(), nr, dev, label=mode))
     elif mode == 'sweep':
         build, nr = workload('batch')
-        for heavy, budget in ((8, 16), (16, 24), (16, 32), (24, 32), (24, 39), (32, 31), (48, 15), (62, 1)):
+        for heavy, budget in ((4, 8), (6, 12), (8, 8), (8, 12), (8, 16), (8, 24), (12, 16), (16, 24), (24, 32)):
             G.HEAVY, G.GROUP_ITEMS = heavy, budget
-            results.append(bench_graph(build(), nr, dev, legacy=(heavy == 24 and budget == 32),
+            results.append(bench_graph(build(), nr, dev, legacy=(heavy == 8 and budget == 16),
                                        label='h%d_b%d' % (heavy, budget)))
         if 'RENET_GATHER_UNR' not in os.environ:
             for unr in ('2', '3', '4', '6', '8'):
