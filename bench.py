@@ -47,6 +47,9 @@ def parse():
                          'the default keeps the whole run within a few minutes, SURVEY 8d asks for >= 10)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='torch threads for the CPU baseline (0 = min(32, cores))')
     ap.add_argument('--e2e-steps', type=int, default=5)
+    ap.add_argument('--no-pair', action='store_true',
+                    help='run the subject and object passes strictly one after the other (RENet.loss_prepared twice) '
+                         'instead of RENet.loss_prepared_pair')
     ap.add_argument('--f32-steps', type=int, default=40,
                     help='steps of the exact-fp32 companion run (RENET_GEMM=f32, child process; 0 = skip)')
     return ap.parse_args()
@@ -99,7 +102,10 @@ def main():
                 net.prepare(b, hist_o.take(idx), graph_dict, subject=False))
 
     def train_step(ps, po):
-        loss = net.loss_prepared(ps) + net.loss_prepared(po)
+        if args.no_pair:
+            loss = net.loss_prepared(ps) + net.loss_prepared(po)
+        else:           # same arithmetic; the four GRU recurrences of the two passes share one launch
+            loss = net.loss_prepared_pair(ps, po)
         loss.backward()
         opt.step()                       # gradient all-reduce (N>1) -> clip -> Adam -> zero_grad
         return loss

@@ -198,7 +198,7 @@ int renet_gru_fwd(const float* Gi, const int32_t* step_off, int L, int H, const 
 int renet_gru_bwd(const float* dh_last, const int32_t* step_off, int L, int H, const float* Whh,
                   const float* saved, float* dGi, float* dGh, float* workspace,
                   size_t workspace_bytes, void* stream);
-/* n (1 or 2) independent GRUs over the SAME packed layout in one launch (RE-Net's `encoder` and
+/* n (1..4) independent GRUs over the SAME packed layout in one launch (RE-Net's `encoder` and
  * `encoder_r`, model.py:86,94): every pointer argument is a HOST array of n device pointers;
  * the workspace is n * renet_gru_workspace bytes. */
 int renet_gru_fwd_multi(int n, const float* const* Gi, const int32_t* step_off, int L, int H,
@@ -207,6 +207,17 @@ int renet_gru_fwd_multi(int n, const float* const* Gi, const int32_t* step_off, 
 int renet_gru_bwd_multi(int n, const float* const* dh_last, const int32_t* step_off, int L, int H,
                         const float* const* Whh, const float* const* saved, float* const* dGi,
                         float* const* dGh, float* workspace, size_t workspace_bytes, void* stream);
+/* n (<= 4) GRUs of up to TWO packed layouts in one launch: step_off[k] / L[k] / out_rows[k] describe problem k
+ * (problems that pass the same step_off pointer share a layout).  The subject and the object pass of a training
+ * step (train.py:136-137) are independent until their losses are added: their four recurrences -- ~60 workgroups
+ * each -- then run side by side on the 256 CUs.  Equal Whh pointers are split into planes once. */
+int renet_gru_fwd_layouts(int n, const float* const* Gi, const int32_t* const* step_off, const int* L, int H,
+                          const float* const* Whh, const float* const* bhh, float* const* h_last,
+                          const int* out_rows, float* const* saved, float* workspace, size_t workspace_bytes,
+                          void* stream);
+int renet_gru_bwd_layouts(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
+                          const float* const* Whh, const float* const* saved, float* const* dGi,
+                          float* const* dGh, float* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Score head (model.py:89-91, 98-100).

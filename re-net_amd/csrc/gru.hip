@@ -35,6 +35,19 @@ struct StepOff {
     int off[MAXL + 1];
 };
 
+// Up to MAXP independent GRUs run in ONE launch (blockIdx.y selects the problem); they may belong to up to MAXLAY
+// different packed layouts: RE-Net's `encoder` and `encoder_r` consume the same batch (model.py:86,94), and the
+// subject and object passes of a training step (train.py:136-137) are independent until their losses are added, so
+// a step can run all four recurrences -- each only ~60 workgroups -- side by side on the 256 CUs.
+constexpr int MAXP = 4;
+constexpr int MAXLAY = 2;
+struct Layouts {
+    StepOff so[MAXLAY];
+    int L[MAXLAY];
+    int rows[MAXLAY];           // forward: rows of h_last (>= B); backward: B
+    int lay_of[MAXP];
+};
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 template <int H>
@@ -50,17 +63,17 @@ struct Cfg {
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-// Up to MAXP independent GRUs with the same packed layout (RE-Net's `encoder` and `encoder_r` consume the
-// same batch, model.py:86,94) run in ONE launch: blockIdx.y selects the problem, so the two recurrences
-// -- each only ~60 workgroups -- share the chip instead of running back to back.
-constexpr int MAXP = 2;
 struct FwdProb { const float* Gi; const float* Whh; const float* bhh; float* h_last; float* saved; };
 struct FwdProbs { FwdProb p[MAXP]; };
 struct BwdProb { const float* dh_last; const float* WhhT; const float* saved; float* dGi; float* dGh; };
 struct BwdProbs { BwdProb p[MAXP]; };
 
 template <int H>
-__global__ __launch_bounds__(NT) void gru_fwd_kernel(FwdProbs ps, StepOff so, int L, int out_rows) {
+__global__ __launch_bounds__(NT) void gru_fwd_kernel(FwdProbs ps, Layouts ly) {
+    const int lay = ly.lay_of[blockIdx.y];
+    const StepOff& so = ly.so[lay];
+    const int L = ly.L[lay], out_rows = ly.rows[lay];
+    if ((int)blockIdx.x * MT >= out_rows) return;
     using C = Cfg<H>;
     const float* __restrict__ Gi = ps.p[blockIdx.y].Gi;
     const float* __restrict__ Whh = ps.p[blockIdx.y].Whh;
@@ -163,7 +176,11 @@ __global__ __launch_bounds__(NT) void gru_fwd_kernel(FwdProbs ps, StepOff so, in
 // LDS as the A operand of   dh_prev = dh * z + dGh W_hh   (K = 3H, B fragments from W_hh^T [H, 3H]).
 // ---------------------------------------------------------------------------------------------
 template <int H>
-__global__ __launch_bounds__(NT) void gru_bwd_kernel(BwdProbs ps, StepOff so, int L) {
+__global__ __launch_bounds__(NT) void gru_bwd_kernel(BwdProbs ps, Layouts ly) {
+    const int lay = ly.lay_of[blockIdx.y];
+    const StepOff& so = ly.so[lay];
+    const int L = ly.L[lay];
+    if ((int)blockIdx.x * MT >= ly.rows[lay]) return;
     using C = Cfg<H>;
     const float* __restrict__ dh_last = ps.p[blockIdx.y].dh_last;
     const float* __restrict__ WhhT = ps.p[blockIdx.y].WhhT;          // [H, 3H]
@@ -321,7 +338,11 @@ struct BwdProbsB { BwdProbB p[MAXP]; };
 
 // Wp: bf16 planes of W_hh in fragment order (split_frag_kernel with G = 3 gates)
 template <int H>
-__global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, StepOff so, int L, int out_rows) {
+__global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly) {
+    const int lay = ly.lay_of[blockIdx.y];
+    const StepOff& so = ly.so[lay];
+    const int L = ly.L[lay], out_rows = ly.rows[lay];
+    if ((int)blockIdx.x * MT >= out_rows) return;
     using C = Cfg<H>;
     using Bc = BCfg<H>;
     const float* __restrict__ Gi = ps.p[blockIdx.y].Gi;
@@ -407,7 +428,11 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, StepOff so
 
 // WTp: bf16 planes of W_hh^T (unit = hidden unit, k over the 3H gate columns) in fragment order (G = 1)
 template <int H>
-__global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, StepOff so, int L) {
+__global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly) {
+    const int lay = ly.lay_of[blockIdx.y];
+    const StepOff& so = ly.so[lay];
+    const int L = ly.L[lay];
+    if ((int)blockIdx.x * MT >= ly.rows[lay]) return;
     using C = Cfg<H>;
     using Bc = BCfg<H>;
     const float* __restrict__ dh_last = ps.p[blockIdx.y].dh_last;
@@ -532,47 +557,47 @@ int set_lds(KernelT kernel, size_t lds, bool& done) {
     return RENET_OK;
 }
 
+inline int max_rows(const Layouts& ly) { return ly.rows[0] > ly.rows[1] ? ly.rows[0] : ly.rows[1]; }
+
 template <int H>
-int launch_fwd(const FwdProbs& ps, int np, const StepOff& so, int L, int out_rows, hipStream_t st) {
-    RENET_LAUNCH((gru_fwd_kernel<H>), dim3((out_rows + MT - 1) / MT, np), dim3(NT), 0, st, ps, so, L,
-                       out_rows);
+int launch_fwd(const FwdProbs& ps, int np, const Layouts& ly, hipStream_t st) {
+    RENET_LAUNCH((gru_fwd_kernel<H>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(NT), 0, st, ps, ly);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
 
 template <int H>
-int launch_fwd_bf(const FwdProbsB& ps, int np, const StepOff& so, int L, int out_rows, hipStream_t st) {
+int launch_fwd_bf(const FwdProbsB& ps, int np, const Layouts& ly, hipStream_t st) {
     using C = Cfg<H>;
     const size_t lds = (size_t)2 * MT * C::LDH * sizeof(float) + (size_t)3 * MT * BCfg<H>::LDP * sizeof(__bf16);
     static bool attr_set = false;
     const int e = set_lds(gru_fwd_bf_kernel<H>, lds, attr_set);
     if (e != RENET_OK) return e;
-    RENET_LAUNCH((gru_fwd_bf_kernel<H>), dim3((out_rows + MT - 1) / MT, np), dim3(NT), lds, st, ps, so, L,
-                       out_rows);
+    RENET_LAUNCH((gru_fwd_bf_kernel<H>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(NT), lds, st, ps, ly);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
 
 template <int H>
-int launch_bwd(const BwdProbs& ps, int np, const StepOff& so, int L, int B, hipStream_t st) {
+int launch_bwd(const BwdProbs& ps, int np, const Layouts& ly, hipStream_t st) {
     using C = Cfg<H>;
     const size_t lds = (size_t)MT * (C::LDH + C::LDG) * sizeof(float);
     static bool attr_set = false;
     const int e = set_lds(gru_bwd_kernel<H>, lds, attr_set);
     if (e != RENET_OK) return e;
-    RENET_LAUNCH((gru_bwd_kernel<H>), dim3((B + MT - 1) / MT, np), dim3(NT), lds, st, ps, so, L);
+    RENET_LAUNCH((gru_bwd_kernel<H>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(NT), lds, st, ps, ly);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
 
 template <int H>
-int launch_bwd_bf(const BwdProbsB& ps, int np, const StepOff& so, int L, int B, hipStream_t st) {
+int launch_bwd_bf(const BwdProbsB& ps, int np, const Layouts& ly, hipStream_t st) {
     using C = Cfg<H>;
     const size_t lds = (size_t)MT * C::LDH * sizeof(float) + (size_t)3 * MT * BCfg<H>::LDP3 * sizeof(__bf16);
     static bool attr_set = false;
     const int e = set_lds(gru_bwd_bf_kernel<H>, lds, attr_set);
     if (e != RENET_OK) return e;
-    RENET_LAUNCH((gru_bwd_bf_kernel<H>), dim3((B + MT - 1) / MT, np), dim3(NT), lds, st, ps, so, L);
+    RENET_LAUNCH((gru_bwd_bf_kernel<H>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(NT), lds, st, ps, ly);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -615,20 +640,67 @@ size_t renet_gru_workspace(int B, int H) {
     return m;
 }
 
-int renet_gru_fwd_multi(int n, const float* const* Gi, const int32_t* step_off, int L, int H,
-                        const float* const* Whh, const float* const* bhh, float* const* h_last, int out_rows,
-                        float* const* saved, float* workspace, size_t workspace_bytes, void* stream) {
-    if (n < 1 || n > MAXP) return RENET_ERR_BADARG;
-    StepOff so;
-    int B = 0;
-    if (L == 0) {                                   // no steps at all: every row is h0
-        for (int j = 0; j <= MAXL; ++j) so.off[j] = 0;
-        L = 0;
-    } else if (!fill_offsets(step_off, L, so, B)) {
-        return RENET_ERR_BADARG;
+}  // extern "C"
+
+namespace {
+
+// Groups the n problems by packed layout (equal step_off POINTERS = same layout) and validates each layout.
+// rows_in[k]: forward = rows of h_last of problem k, backward = ignored (B of the layout is used).
+int make_layouts(int n, const int32_t* const* step_off, const int* Ls, const int* rows_in, bool fwd, Layouts& ly,
+                 int* B_of) {
+    const int32_t* seen[MAXLAY] = {nullptr, nullptr};
+    int nl = 0;
+    for (int i = 0; i < MAXLAY; ++i) {
+        ly.L[i] = 0; ly.rows[i] = 0;
+        for (int j = 0; j <= MAXL; ++j) ly.so[i].off[j] = 0;
     }
-    if (out_rows < B) return RENET_ERR_BADARG;
-    if (out_rows == 0) return RENET_OK;
+    for (int k = 0; k < MAXP; ++k) ly.lay_of[k] = 0;
+    for (int k = 0; k < n; ++k) {
+        int l = -1;
+        for (int i = 0; i < nl; ++i)
+            if (seen[i] == step_off[k] && ly.L[i] == Ls[k]) l = i;
+        if (l < 0) {
+            if (nl == MAXLAY) return RENET_ERR_BADARG;
+            l = nl++;
+            seen[l] = step_off[k];
+            ly.L[l] = Ls[k];
+            int B = 0;
+            if (Ls[k] > 0 && !fill_offsets(step_off[k], Ls[k], ly.so[l], B)) return RENET_ERR_BADARG;
+            ly.rows[l] = fwd ? 0 : B;
+        }
+        const int B = ly.L[l] > 0 ? ly.so[l].off[1] - ly.so[l].off[0] : 0;
+        if (fwd) {
+            if (rows_in[k] < B) return RENET_ERR_BADARG;
+            if (ly.rows[l] != 0 && ly.rows[l] != rows_in[k]) return RENET_ERR_BADARG;   // one h_last height per layout
+            ly.rows[l] = rows_in[k];
+        }
+        ly.lay_of[k] = l;
+        B_of[k] = B;
+    }
+    return RENET_OK;
+}
+
+// W_hh planes are split once per DISTINCT weight pointer (the subject and object passes share the encoders)
+int plane_slot(int k, const float* const* W) {
+    for (int i = 0; i < k; ++i)
+        if (W[i] == W[k]) return i;
+    return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+int renet_gru_fwd_layouts(int n, const float* const* Gi, const int32_t* const* step_off, const int* L, int H,
+                          const float* const* Whh, const float* const* bhh, float* const* h_last,
+                          const int* out_rows, float* const* saved, float* workspace, size_t workspace_bytes,
+                          void* stream) {
+    if (n < 1 || n > MAXP) return RENET_ERR_BADARG;
+    Layouts ly;
+    int B_of[MAXP];
+    const int e0 = make_layouts(n, step_off, L, out_rows, true, ly, B_of);
+    if (e0 != RENET_OK) return e0;
+    if (max_rows(ly) == 0) return RENET_OK;
     if (H != 100 && H != 200 && H != 400) return RENET_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (use_f32()) {
@@ -639,18 +711,19 @@ int renet_gru_fwd_multi(int n, const float* const* Gi, const int32_t* step_off, 
             ps.p[i].saved = saved[k];
         }
         switch (H) {
-            case 100: return launch_fwd<100>(ps, n, so, L, out_rows, st);
-            case 200: return launch_fwd<200>(ps, n, so, L, out_rows, st);
-            default: return launch_fwd<400>(ps, n, so, L, out_rows, st);
+            case 100: return launch_fwd<100>(ps, n, ly, st);
+            case 200: return launch_fwd<200>(ps, n, ly, st);
+            default: return launch_fwd<400>(ps, n, ly, st);
         }
     }
-    const size_t per = renet_gru_workspace(B, H);
+    const size_t per = renet_gru_workspace(0, H);
     if (!workspace || workspace_bytes < (size_t)n * per) return RENET_ERR_WORKSPACE;
     FwdProbsB ps;
     for (int i = 0; i < MAXP; ++i) {
         const int k = i < n ? i : 0;
-        bf16x8* planes = reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(workspace) + (size_t)k * per);
-        if (i < n) {                                // gate g of unit u, input k: W_hh[g*H + u][k]
+        const int slot = plane_slot(k, Whh);
+        bf16x8* planes = reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(workspace) + (size_t)slot * per);
+        if (i < n && slot == k) {                   // gate g of unit u, input k: W_hh[g*H + u][k]
             const int e = split_frag(Whh[k], H, H, 3, (size_t)H * H, (size_t)H, 1, planes, st);
             if (e != RENET_OK) return e;
         }
@@ -658,30 +731,23 @@ int renet_gru_fwd_multi(int n, const float* const* Gi, const int32_t* step_off, 
         ps.p[i].saved = saved[k];
     }
     switch (H) {
-        case 100: return launch_fwd_bf<100>(ps, n, so, L, out_rows, st);
-        case 200: return launch_fwd_bf<200>(ps, n, so, L, out_rows, st);
-        default: return launch_fwd_bf<400>(ps, n, so, L, out_rows, st);
+        case 100: return launch_fwd_bf<100>(ps, n, ly, st);
+        case 200: return launch_fwd_bf<200>(ps, n, ly, st);
+        default: return launch_fwd_bf<400>(ps, n, ly, st);
     }
 }
 
-int renet_gru_fwd(const float* Gi, const int32_t* step_off, int L, int H, const float* Whh,
-                  const float* bhh, float* h_last, int out_rows, float* saved, float* workspace,
-                  size_t workspace_bytes, void* stream) {
-    return renet_gru_fwd_multi(1, &Gi, step_off, L, H, &Whh, &bhh, &h_last, out_rows, &saved, workspace,
-                               workspace_bytes, stream);
-}
-
-int renet_gru_bwd_multi(int n, const float* const* dh_last, const int32_t* step_off, int L, int H,
-                        const float* const* Whh, const float* const* saved, float* const* dGi,
-                        float* const* dGh, float* workspace, size_t workspace_bytes, void* stream) {
+int renet_gru_bwd_layouts(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
+                          const float* const* Whh, const float* const* saved, float* const* dGi,
+                          float* const* dGh, float* workspace, size_t workspace_bytes, void* stream) {
     if (n < 1 || n > MAXP) return RENET_ERR_BADARG;
-    if (L == 0) return RENET_OK;
-    StepOff so;
-    int B;
-    if (!fill_offsets(step_off, L, so, B)) return RENET_ERR_BADARG;
-    if (B == 0) return RENET_OK;
+    Layouts ly;
+    int B_of[MAXP];
+    const int e0 = make_layouts(n, step_off, L, nullptr, false, ly, B_of);
+    if (e0 != RENET_OK) return e0;
+    if (max_rows(ly) == 0) return RENET_OK;
     if (H != 100 && H != 200 && H != 400) return RENET_ERR_UNSUPPORTED;
-    const size_t per = renet_gru_workspace(B, H);
+    const size_t per = renet_gru_workspace(0, H);
     if (!workspace || workspace_bytes < (size_t)n * per) return RENET_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const bool f32 = use_f32();
@@ -689,10 +755,11 @@ int renet_gru_bwd_multi(int n, const float* const* dh_last, const int32_t* step_
     BwdProbsB pb;
     for (int i = 0; i < MAXP; ++i) {
         const int k = i < n ? i : 0;
-        char* base = reinterpret_cast<char*>(workspace) + (size_t)k * per;
+        const int slot = plane_slot(k, Whh);
+        char* base = reinterpret_cast<char*>(workspace) + (size_t)slot * per;
         float* WhhT = reinterpret_cast<float*>(base);
         bf16x8* planes = reinterpret_cast<bf16x8*>(base);
-        if (i < n) {
+        if (i < n && slot == k) {
             if (f32) {
                 RENET_LAUNCH(transpose_kernel, dim3((H + 31) / 32, (3 * H + 31) / 32), dim3(256), 0, st, Whh[k],
                                    3 * H, H, WhhT);
@@ -709,16 +776,44 @@ int renet_gru_bwd_multi(int n, const float* const* dh_last, const int32_t* step_
     }
     if (f32) {
         switch (H) {
-            case 100: return launch_bwd<100>(ps, n, so, L, B, st);
-            case 200: return launch_bwd<200>(ps, n, so, L, B, st);
-            default: return launch_bwd<400>(ps, n, so, L, B, st);
+            case 100: return launch_bwd<100>(ps, n, ly, st);
+            case 200: return launch_bwd<200>(ps, n, ly, st);
+            default: return launch_bwd<400>(ps, n, ly, st);
         }
     }
     switch (H) {
-        case 100: return launch_bwd_bf<100>(pb, n, so, L, B, st);
-        case 200: return launch_bwd_bf<200>(pb, n, so, L, B, st);
-        default: return launch_bwd_bf<400>(pb, n, so, L, B, st);
+        case 100: return launch_bwd_bf<100>(pb, n, ly, st);
+        case 200: return launch_bwd_bf<200>(pb, n, ly, st);
+        default: return launch_bwd_bf<400>(pb, n, ly, st);
     }
+}
+
+// n (<= 4) GRUs over ONE packed layout
+int renet_gru_fwd_multi(int n, const float* const* Gi, const int32_t* step_off, int L, int H,
+                        const float* const* Whh, const float* const* bhh, float* const* h_last, int out_rows,
+                        float* const* saved, float* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 1 || n > MAXP) return RENET_ERR_BADARG;
+    const int32_t* so[MAXP];
+    int Ls[MAXP], rows[MAXP];
+    for (int k = 0; k < n; ++k) { so[k] = step_off; Ls[k] = L; rows[k] = out_rows; }
+    return renet_gru_fwd_layouts(n, Gi, so, Ls, H, Whh, bhh, h_last, rows, saved, workspace, workspace_bytes, stream);
+}
+
+int renet_gru_fwd(const float* Gi, const int32_t* step_off, int L, int H, const float* Whh,
+                  const float* bhh, float* h_last, int out_rows, float* saved, float* workspace,
+                  size_t workspace_bytes, void* stream) {
+    return renet_gru_fwd_multi(1, &Gi, step_off, L, H, &Whh, &bhh, &h_last, out_rows, &saved, workspace,
+                               workspace_bytes, stream);
+}
+
+int renet_gru_bwd_multi(int n, const float* const* dh_last, const int32_t* step_off, int L, int H,
+                        const float* const* Whh, const float* const* saved, float* const* dGi,
+                        float* const* dGh, float* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 1 || n > MAXP) return RENET_ERR_BADARG;
+    const int32_t* so[MAXP];
+    int Ls[MAXP];
+    for (int k = 0; k < n; ++k) { so[k] = step_off; Ls[k] = L; }
+    return renet_gru_bwd_layouts(n, dh_last, so, Ls, H, Whh, saved, dGi, dGh, workspace, workspace_bytes, stream);
 }
 
 int renet_gru_bwd(const float* dh_last, const int32_t* step_off, int L, int H, const float* Whh,

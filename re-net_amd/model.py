@@ -162,23 +162,10 @@ class RENet(nn.Module):
         processes).  hist: (histories, timestamps) in the reference's nested-list layout, or a FlatHistory."""
         return self.prepare_from_host(self.host_batch(triplets, hist, graph_dict, subject))
 
-    def loss_prepared(self, prep):
-        """Device half (model.py:82-103): RGCN x2 -> sequence assembly -> GRU x2 -> heads -> loss."""
+    def _heads(self, prep, s_h, s_q):
+        """model.py:89-103: both score heads + the weighted sum of their losses."""
         subject = prep.subject
         rel_embeds = self.rel_embeds[:self.num_rels] if subject else self.rel_embeds[self.num_rels:]
-        dev = self.ent_embeds.device
-        b, g = prep.b, prep.g
-        self.aggregator.last_batch = g
-        if g is None:
-            s_h = torch.zeros(b, self.h_dim, device=dev)
-            s_q = torch.zeros(b, self.h_dim, device=dev)
-        else:
-            x, xr = self.aggregator.encode(g, self.ent_embeds, rel_embeds, reverse=not subject)
-            e, er = self.encoder, self.encoder_r                                      # model.py:86-88, 94-96
-            s_h, s_q = ops.DualGRUFn.apply(x, xr, e.weight_ih_l0, e.weight_hh_l0, e.bias_ih_l0, e.bias_hh_l0,
-                                           er.weight_ih_l0, er.weight_hh_l0, er.bias_ih_l0, er.bias_hh_l0,
-                                           prep.step_off, b)
-            s_h, s_q = s_h[0], s_q[0]
         p = self.drop_p if self.training else 0.0
         loss_sub = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_h, rel_embeds, prep.r_idx,
                                       self.linear.weight, self.linear.bias, prep.o_idx, prep.plan_s,
@@ -187,6 +174,42 @@ class RENet(nn.Module):
                                     self.linear_r.bias, prep.r_idx, prep.plan_s, None, p,
                                     ops.next_seed() if p > 0 else 0)                      # model.py:98-100
         return loss_sub + 0.1 * loss_r                                                    # model.py:103
+
+    def _encode(self, prep):
+        rel_embeds = self.rel_embeds[:self.num_rels] if prep.subject else self.rel_embeds[self.num_rels:]
+        self.aggregator.last_batch = prep.g
+        return self.aggregator.encode(prep.g, self.ent_embeds, rel_embeds, reverse=not prep.subject)
+
+    def loss_prepared(self, prep):
+        """Device half (model.py:82-103): RGCN x2 -> sequence assembly -> GRU x2 -> heads -> loss."""
+        dev = self.ent_embeds.device
+        b, g = prep.b, prep.g
+        self.aggregator.last_batch = g
+        if g is None:
+            s_h = torch.zeros(b, self.h_dim, device=dev)
+            s_q = torch.zeros(b, self.h_dim, device=dev)
+        else:
+            x, xr = self._encode(prep)
+            s_h, s_q = ops.dual_gru(x, xr, self.encoder, self.encoder_r, prep.step_off, b)   # model.py:86-88, 94-96
+            s_h, s_q = s_h[0], s_q[0]
+        return self._heads(prep, s_h, s_q)
+
+    def loss_prepared_pair(self, prep_s, prep_o):
+        """loss_prepared(prep_s) + loss_prepared(prep_o) -- the subject and the object pass of one training step
+        (train.py:136-138) -- with the four GRU recurrences of the two passes in ONE launch per direction of time
+        (extension of the reference API: the passes are independent until their losses are added, and a pass's two
+        recurrences occupy only ~120 of the 256 CUs).  Same arithmetic, same results."""
+        if prep_s.g is None or prep_o.g is None:
+            return self.loss_prepared(prep_s) + self.loss_prepared(prep_o)
+        xs, xrs = self._encode(prep_s)
+        xo, xro = self._encode(prep_o)
+        e, er = self.encoder, self.encoder_r
+        w = (e.weight_ih_l0, e.weight_hh_l0, e.bias_ih_l0, e.bias_hh_l0)
+        wr = (er.weight_ih_l0, er.weight_hh_l0, er.bias_ih_l0, er.bias_hh_l0)
+        hs, qs, ho, qo = ops.MultiGRUFn.apply([prep_s.step_off, prep_s.step_off, prep_o.step_off, prep_o.step_off],
+                                              [prep_s.b, prep_s.b, prep_o.b, prep_o.b],
+                                              xs, *w, xrs, *wr, xo, *w, xro, *wr)
+        return self._heads(prep_s, hs[0], qs[0]) + self._heads(prep_o, ho[0], qo[0])
 
     def forward(self, triplets, s_hist, o_hist, graph_dict, subject=True):
         """Training loss of one direction (model.py:64-104): CE over objects + 0.1 * CE over relations.

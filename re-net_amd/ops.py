@@ -212,64 +212,70 @@ class GRUFn(Function):
         return dx, d_wih, d_whh, d_bih, d_bhh, None, None
 
 
-class DualGRUFn(Function):
-    """RE-Net's two history encoders (`encoder` 4D->D and `encoder_r` 3D->D, model.py:86,94) over the same
-    packed batch: input projections as two GEMMs, both recurrences in ONE persistent launch."""
+class MultiGRUFn(Function):
+    """n <= 4 of RE-Net's history encoders in ONE persistent launch per direction of time (model.py:86,94):
+    `encoder` (4D->D) and `encoder_r` (3D->D) of one pass share a packed layout; the subject and the object pass of
+    a training step are independent until their losses are added, so a step may run all four side by side
+    (RENet.loss_prepared_pair).  Input projections are one GEMM per problem.
+    apply(step_offs, total_rows, x_0, w_ih_0, w_hh_0, b_ih_0, b_hh_0, x_1, ...) -> (h_n_0 [1, rows_0, H], ...)"""
 
     @staticmethod
-    def forward(ctx, x, xr, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, step_off, total_rows):
-        ctx.src_w = (w_ih, w_hh, w_ih_r, w_hh_r)
-        ctx.src_b = (b_ih, b_hh, b_ih_r, b_hh_r)
-        ts = [_c(t) for t in (x, xr, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)]
-        x, xr, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r = ts
-        hdim = w_hh.shape[1]
-        gi = K.gemm(x, w_ih, tb=True, bias=b_ih)
-        gir = K.gemm(xr, w_ih_r, tb=True, bias=b_ih_r)
-        (h, q), (sv, svr) = K.gru_fwd_multi([gi, gir], step_off, hdim, [w_hh, w_hh_r], [b_hh, b_hh_r],
-                                            out_rows=total_rows)                 # rows past nnz are zero
-        nnz = int(step_off[1] - step_off[0]) if len(step_off) > 1 else 0
-        outs = [h.unsqueeze(0), q.unsqueeze(0)]
-        ctx.step_off, ctx.nnz, ctx.hdim = step_off, nnz, hdim
-        ctx.save_for_backward(x, xr, w_ih, w_hh, w_ih_r, w_hh_r, sv, svr)
+    def forward(ctx, step_offs, total_rows, *ts):
+        n = len(ts) // 5
+        ctx.src_w = [(ts[5 * k + 1], ts[5 * k + 2]) for k in range(n)]
+        ctx.src_b = [(ts[5 * k + 3], ts[5 * k + 4]) for k in range(n)]
+        ts = [_c(t) for t in ts]
+        xs, w_ihs, w_hhs = ts[0::5], ts[1::5], ts[2::5]
+        b_ihs, b_hhs = ts[3::5], ts[4::5]
+        hdim = w_hhs[0].shape[1]
+        gis = [K.gemm(x, w, tb=True, bias=b) for x, w, b in zip(xs, w_ihs, b_ihs)]
+        hs, svs = K.gru_fwd_layouts(gis, step_offs, hdim, w_hhs, b_hhs, total_rows)     # rows past nnz are zero
+        ctx.step_offs, ctx.hdim, ctx.n = step_offs, hdim, n
+        ctx.nnz = [int(o[1] - o[0]) if len(o) > 1 else 0 for o in step_offs]
+        ctx.save_for_backward(*(list(xs) + list(w_ihs) + list(w_hhs) + list(svs)))
         if debug_tap is not None:
-            debug_tap('h_n', h)
-            debug_tap('q_n', q)
-        return outs[0], outs[1]
+            for k, h in enumerate(hs):
+                debug_tap('h_n' if k % 2 == 0 else 'q_n', h)
+        return tuple(h.unsqueeze(0) for h in hs)
 
     @staticmethod
-    def backward(ctx, dh, dq):
-        x, xr, w_ih, w_hh, w_ih_r, w_hh_r, sv, svr = ctx.saved_tensors
-        hdim, nnz = ctx.hdim, ctx.nnz
-        tgts = [grad_target(t) for t in ctx.src_w]
-        btgts = [grad_target(t) for t in ctx.src_b]
-        (d_gi, d_gir), (d_gh, d_ghr) = K.gru_bwd_multi([_c(dh[0, :nnz]), _c(dq[0, :nnz])], ctx.step_off, hdim,
-                                                       [w_hh, w_hh_r], [sv, svr])
-        res = []
-        for k, (xx, wi, dgi, dgh, s_) in enumerate(((x, w_ih, d_gi, d_gh, sv), (xr, w_ih_r, d_gir, d_ghr, svr))):
-            t_ih, t_hh = tgts[2 * k], tgts[2 * k + 1]
+    def backward(ctx, *dhs):
+        n, hdim = ctx.n, ctx.hdim
+        sv_ = ctx.saved_tensors
+        xs, w_ihs, w_hhs, svs = sv_[:n], sv_[n:2 * n], sv_[2 * n:3 * n], sv_[3 * n:4 * n]
+        d_gis, d_ghs = K.gru_bwd_layouts([_c(dh[0, :nz]) for dh, nz in zip(dhs, ctx.nnz)], ctx.step_offs, hdim,
+                                         list(w_hhs), list(svs))
+        out = [None, None]
+        for k in range(n):
+            t_ih, t_hh = (grad_target(t) for t in ctx.src_w[k])
+            t_bi, t_bh = (grad_target(t) for t in ctx.src_b[k])
+            dgi, dgh, xx, s_ = d_gis[k], d_ghs[k], xs[k], svs[k]
+            dwi = dwh = dbi = dbh = None
             if t_ih is not None:
                 K.gemm(dgi, xx, ta=True, out=t_ih, beta=1.0)
-                dwi_ = None
             else:
-                dwi_ = K.gemm(dgi, xx, ta=True)
+                dwi = K.gemm(dgi, xx, ta=True)
             if t_hh is not None:
                 K.gemm(dgh, s_[:, 4 * hdim:], ta=True, out=t_hh, beta=1.0)
-                dwh_ = None
             else:
-                dwh_ = K.gemm(dgh, s_[:, 4 * hdim:], ta=True)
-            t_bi, t_bh = btgts[2 * k], btgts[2 * k + 1]
-            dbi_ = dbh_ = None
+                dwh = K.gemm(dgh, s_[:, 4 * hdim:], ta=True)
             if t_bi is not None:
                 K.colsum(dgi, out=t_bi, beta=1.0)
             else:
-                dbi_ = K.colsum(dgi)
+                dbi = K.colsum(dgi)
             if t_bh is not None:
                 K.colsum(dgh, out=t_bh, beta=1.0)
             else:
-                dbh_ = K.colsum(dgh)
-            res.append((K.gemm(dgi, wi), dwi_, dwh_, dbi_, dbh_))
-        (dx, dwi, dwh, dbi, dbh), (dxr, dwir, dwhr, dbir, dbhr) = res
-        return dx, dxr, dwi, dwh, dbi, dbh, dwir, dwhr, dbir, dbhr, None, None
+                dbh = K.colsum(dgh)
+            out += [K.gemm(dgi, w_ihs[k]), dwi, dwh, dbi, dbh]
+        return tuple(out)
+
+
+def dual_gru(x, xr, enc, enc_r, step_off, total_rows):
+    """Both encoders of ONE pass: -> (h_n [1, rows, H], q_n [1, rows, H])."""
+    return MultiGRUFn.apply([step_off, step_off], [total_rows, total_rows],
+                            x, enc.weight_ih_l0, enc.weight_hh_l0, enc.bias_ih_l0, enc.bias_hh_l0,
+                            xr, enc_r.weight_ih_l0, enc_r.weight_hh_l0, enc_r.bias_ih_l0, enc_r.bias_hh_l0)
 
 
 class HeadCEFn(Function):

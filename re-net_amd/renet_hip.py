@@ -57,6 +57,10 @@ _SIGNATURES = {
                                     c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_gru_bwd_multi': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
+    'renet_gru_fwd_layouts': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'renet_gru_bwd_layouts': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_concat3_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                                   c_u64, c_void_p, c_void_p]),
     'renet_concat3_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_u64, c_void_p, c_void_p,
@@ -468,6 +472,52 @@ def gru_bwd_multi(dh_lasts, step_off_host, hdim, w_hhs, saveds):
                                      _ptrs(w_hhs), _ptrs(saveds), _ptrs(d_gis), _ptrs(d_ghs), ws.data_ptr(),
                                      nbytes, _stream()), 'gru_bwd_multi')
     if t0 is not None:      # dh_{t-1} += d_gates @ W_hh per step: the same 2 * 3H * H flops per packed row
+        _timer.end('gru_recurrence', t0, flops=sum(2.0 * 3 * hdim * hdim * s_.shape[0] for s_ in saveds))
+    return d_gis, d_ghs
+
+
+def _offs(step_offs):
+    return ((ctypes.c_void_p * len(step_offs))(*[ctypes.cast(o, c_void_p).value for o in step_offs]),
+            (ctypes.c_int * len(step_offs))(*[len(o) - 1 for o in step_offs]))
+
+
+def gru_fwd_layouts(gis, step_offs, hdim, w_hhs, b_hhs, out_rows):
+    """n <= 4 GRUs of up to two packed layouts in one launch (renet_gru_fwd_layouts): step_offs[k] is the host
+    offset array of problem k (problems of one layout pass the SAME object), out_rows[k] its h_last height.
+    -> ([h_last...], [saved...])."""
+    n = len(gis)
+    dev = gis[0].device
+    rows = [max(int(r), (o[1] - o[0]) if len(o) > 1 else 0) for r, o in zip(out_rows, step_offs)]
+    hs = [torch.empty(r, hdim, device=dev, dtype=torch.float32) for r in rows]
+    svs = [torch.empty(g.shape[0], 5 * hdim, device=dev, dtype=torch.float32) for g in gis]
+    for t in list(gis) + list(w_hhs) + list(b_hhs):
+        _f32(t)
+    nbytes = n * lib().renet_gru_workspace(0, hdim)
+    ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
+    so, ls = _offs(step_offs)
+    t0 = _timer.begin() if _timer is not None else None
+    _check(lib().renet_gru_fwd_layouts(n, _ptrs(gis), so, ls, hdim, _ptrs(w_hhs), _ptrs(b_hhs), _ptrs(hs),
+                                       (ctypes.c_int * n)(*rows), _ptrs(svs), ws.data_ptr(), nbytes, _stream()),
+           'gru_fwd_layouts')
+    if t0 is not None:
+        _timer.end('gru_recurrence', t0, flops=sum(2.0 * 3 * hdim * hdim * g.shape[0] for g in gis))
+    return hs, svs
+
+
+def gru_bwd_layouts(dh_lasts, step_offs, hdim, w_hhs, saveds):
+    n = len(dh_lasts)
+    dev = saveds[0].device
+    d_gis = [torch.empty(s.shape[0], 3 * hdim, device=dev, dtype=torch.float32) for s in saveds]
+    d_ghs = [torch.empty(s.shape[0], 3 * hdim, device=dev, dtype=torch.float32) for s in saveds]
+    for t in list(dh_lasts) + list(w_hhs) + list(saveds):
+        _f32(t)
+    nbytes = n * lib().renet_gru_workspace(0, hdim)
+    ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
+    so, ls = _offs(step_offs)
+    t0 = _timer.begin() if _timer is not None else None
+    _check(lib().renet_gru_bwd_layouts(n, _ptrs(dh_lasts), so, ls, hdim, _ptrs(w_hhs), _ptrs(saveds), _ptrs(d_gis),
+                                       _ptrs(d_ghs), ws.data_ptr(), nbytes, _stream()), 'gru_bwd_layouts')
+    if t0 is not None:
         _timer.end('gru_recurrence', t0, flops=sum(2.0 * 3 * hdim * hdim * s_.shape[0] for s_ in saveds))
     return d_gis, d_ghs
 

@@ -193,6 +193,16 @@ def gru_bwd_multi(dh_lasts, step_off_host, hdim, w_hhs, saveds):
     return [r[0] for r in res], [r[1] for r in res]
 
 
+def gru_fwd_layouts(gis, step_offs, hdim, w_hhs, b_hhs, out_rows):
+    res = [_gru_fwd_one(g, _off(o), hdim, w, b, r) for g, o, w, b, r in zip(gis, step_offs, w_hhs, b_hhs, out_rows)]
+    return [r[0] for r in res], [r[1] for r in res]
+
+
+def gru_bwd_layouts(dh_lasts, step_offs, hdim, w_hhs, saveds):
+    res = [_gru_bwd_one(d, _off(o), hdim, w, s) for d, o, w, s in zip(dh_lasts, step_offs, w_hhs, saveds)]
+    return [r[0] for r in res], [r[1] for r in res]
+
+
 def concat3_fwd(a, ia, hmid, c, ic, drop_p, seed):
     _no_drop(drop_p)
     parts = [a[ia.long()], hmid] + ([c[ic.long()]] if c is not None else [])
@@ -251,7 +261,7 @@ def segment_pool_bwd(dout, seg_ptr, arg, num_graphs, is_max, n):
 
 EMULATED = ['gather_rows', 'segment_add', 'rgcn_gather_items', 'rgcn_bwd_prep', 'rgcn_bwd_w', 'gemm', 'colsum',
             'scale_by_device_scalar', 'seq_assemble_fwd', 'seq_assemble_bwd', 'gru_fwd', 'gru_bwd', 'gru_fwd_multi',
-            'gru_bwd_multi', 'concat3_fwd', 'concat3_bwd', 'dropout', 'softmax_ce', 'segment_pool_fwd',
+            'gru_bwd_multi', 'gru_fwd_layouts', 'gru_bwd_layouts', 'concat3_fwd', 'concat3_bwd', 'dropout', 'softmax_ce', 'segment_pool_fwd',
             'segment_pool_bwd']
 
 

@@ -149,3 +149,37 @@ def test_zero_grad_set_to_none_between_forward_and_backward(dev):
         assert got[k] is not None
         scale = float(ref[k].abs().max())
         assert float((got[k] - ref[k]).abs().max()) <= 1e-5 * scale + 1e-12, k
+
+
+def test_paired_step_equals_two_sequential_passes(dev):
+    """RENet.loss_prepared_pair (four GRU recurrences of the subject and object pass in one launch per direction
+    of time, two packed layouts) == loss_prepared(subject) + loss_prepared(object): same losses bit for bit,
+    gradients equal up to the order in which the shared parameters' gradients are accumulated."""
+    import model as M
+    import preprocess as P
+    import synth
+    quads, num_ent, num_rels, _ = synth.make_stream('ICEWS18', seed=11, num_t=60)
+    hs, ho = P.HistoryIndex(quads, 's'), P.HistoryIndex(quads, 'o')
+    gd = P.build_graph_dict(quads, num_rels)
+    idx = np.random.RandomState(5).permutation(len(quads))[:700]
+    torch.manual_seed(4)
+    net = M.RENet(num_ent, 200, num_rels, dropout=0.0, seq_len=10)
+    gen = torch.Generator().manual_seed(2)
+    net.global_emb = {int(t): torch.randn(1, 1, 200, generator=gen) * 0.1 for t in gd}
+    net.to(dev)
+    net.eval()
+    b = quads[idx]
+    ps = net.prepare(b, hs.take(idx), gd, subject=True)
+    po = net.prepare(b, ho.take(idx), gd, subject=False)
+    assert ps.g.host.nnz != po.g.host.nnz or not np.array_equal(ps.g.host.step_off, po.g.host.step_off)
+    res = {}
+    for mode in ('seq', 'pair'):
+        for p in net.parameters():
+            p.grad = None
+        loss = net.loss_prepared(ps) + net.loss_prepared(po) if mode == 'seq' else net.loss_prepared_pair(ps, po)
+        loss.backward()
+        res[mode] = (loss.item(), {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    assert res['seq'][0] == res['pair'][0]
+    for k, g in res['seq'][1].items():
+        scale = float(g.abs().max())
+        assert float((res['pair'][1][k] - g).abs().max()) <= 1e-5 * scale + 1e-12, k
