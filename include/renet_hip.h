@@ -140,6 +140,14 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
                          const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                          int split_k, float* workspace, size_t workspace_bytes, void* stream);
 
+/* Same contract in bf16 mixed precision (BASELINE config 5: "n_hidden=400 bf16"): every fp32 operand value is
+ * rounded to bf16 (RNE) on its way into LDS, products on v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 C.
+ * Relative error of a product ~2^-8 per operand; a K-long dot product of O(1) terms is accurate to ~2^-8/sqrt(K)
+ * relative to its magnitude scale (tolerances: tests/test_gpu_bf16.py). */
+int renet_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
+                    const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
+                    int split_k, float* workspace, size_t workspace_bytes, void* stream);
+
 /* column sums: out[n] = beta * out[n] + sum_m X[m,n]  (bias gradients; beta = 1 accumulates straight into
  * an existing .grad); two deterministic passes over row groups, `workspace` = renet_colsum_workspace(M, N)
  * bytes (0 for short matrices). */

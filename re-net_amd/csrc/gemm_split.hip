@@ -645,6 +645,95 @@ __global__ __launch_bounds__(THREADS) void gemm_split_fused_kernel(SplitArgs g) 
     store_tile(g, m0, n0, z, wm, wn, lane, acc);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// bf16 mode (renet_gemm_bf16; BASELINE config 5 "n_hidden=400 bf16"): the SAME tile, loaders and LDS image with ONE
+// bf16 plane per operand -- every fp32 operand value is rounded to bf16 (RNE) on its way into LDS and the product
+// is a single v_mfma_f32_32x32x16_bf16 with fp32 accumulation (standard bf16 mixed precision: bf16 multiplicands,
+// fp32 sums, fp32 storage of every tensor).  1/6 of the matrix-pipe work of the bf16x6 kernels; the k-loop is then
+// bound by staging, so the next tile's global loads are issued before the MFMA phase and land behind it.
+// ------------------------------------------------------------------------------------------------------
+template <bool CONTIG_K, bool EDGE>
+__device__ __forceinline__ void store_items_1(__bf16* __restrict__ S, int rows, int K, int row0, int k0, int tid,
+                                              const float4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row, k;
+        item_pos<CONTIG_K>(tid + THREADS * i, row, k);
+        float4 v = r[i];
+        if constexpr (EDGE) v = fix_item<CONTIG_K>(v, rows, K, row0, k0, row, k);
+        const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+        *reinterpret_cast<uint2*>(S + row * LDS_ROW + k) =
+            pack4(__builtin_convertvector(lo, bf16x2), __builtin_convertvector(hi, bf16x2));
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(SplitArgs g) {
+    __shared__ __attribute__((aligned(16))) __bf16 sA[2][PLANE];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[2][PLANE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx, by;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    const int m0 = by * BM, n0 = bx * BN;
+    const int z = blockIdx.z;
+    const int kt0 = z * g.k_tiles_per_split;
+    const int kt_total = (g.K + BK - 1) / BK;
+    const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
+    constexpr bool A_CK = !TA;
+    constexpr bool B_CK = TB;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[4], rb[4];
+    ItemLoader<A_CK> la;
+    ItemLoader<B_CK> lb;
+    la.init(g.A, g.lda, g.M, g.K, m0, tid);
+    lb.init(g.B, g.ldb, g.N, g.K, n0, tid);
+    if (kt0 < kt1) {
+        la.load(kt0 * BK, ra);
+        lb.load(kt0 * BK, rb);
+    }
+    const bool a_edge = m0 + BM > g.M, b_edge = n0 + BN > g.N;
+    const int arow = (wm * 64 + (lane & 31)) * LDS_ROW;
+    const int brow = (wn * 64 + (lane & 31)) * LDS_ROW;
+    const int ksel = (lane >> 5) * 8;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;                 // LDS double buffer: ONE barrier per k-tile
+        const bool k_edge = (kt + 1) * BK > g.K;
+        if (a_edge || k_edge) store_items_1<A_CK, true>(sA[buf], g.M, g.K, m0, kt * BK, tid, ra);
+        else store_items_1<A_CK, false>(sA[buf], g.M, g.K, m0, kt * BK, tid, ra);
+        if (b_edge || k_edge) store_items_1<B_CK, true>(sB[buf], g.N, g.K, n0, kt * BK, tid, rb);
+        else store_items_1<B_CK, false>(sB[buf], g.N, g.K, n0, kt * BK, tid, rb);
+        __syncthreads();
+        if (kt + 1 < kt1) {                             // in flight behind the MFMAs
+            la.load((kt + 1) * BK, ra);
+            lb.load((kt + 1) * BK, rb);
+        }
+#pragma unroll
+        for (int slab = 0; slab < 2; ++slab) {
+            const int ko = slab * 16 + ksel;
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = *reinterpret_cast<const bf16x8*>(&sA[buf][arow + t * 32 * LDS_ROW + ko]);
+                b[t] = *reinterpret_cast<const bf16x8*>(&sB[buf][brow + t * 32 * LDS_ROW + ko]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    store_tile(g, m0, n0, z, wm, wn, lane, acc);
+}
+
 __global__ __launch_bounds__(256) void split_reduce_kernel(const float* __restrict__ partial, int split_k,
                                                            int M, int N, float alpha, float beta,
                                                            const float* __restrict__ bias,
@@ -744,9 +833,9 @@ int renet_gemm_trace_set(unsigned long long* buf) {
 }
 #endif
 
-int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
-                         const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
-                         int split_k, float* workspace, size_t workspace_bytes, void* stream) {
+static int gemm_planes_launch(bool bf16_mode, int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
+                              const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
+                              int split_k, float* workspace, size_t workspace_bytes, void* stream) {
     if (M < 0 || N < 0 || K < 1 || lda <= 0 || ldb <= 0 || ldc < N) return RENET_ERR_BADARG;
     if (M == 0 || N == 0) return RENET_OK;
     if (split_k < 1) split_k = 1;
@@ -763,7 +852,7 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
     hipStream_t st = (hipStream_t)stream;
     const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
     const int ntiles = nbx * nby * split_k;
-    int choice = kernel_choice(ntiles);
+    int choice = bf16_mode ? 2 : kernel_choice(ntiles);
     // the fused kernel addresses with 32-bit element offsets and float4 loads along a contiguous K
     if (choice == 0 && (K < 4 || (size_t)(ta ? K : M) * lda >= (1u << 31) || (size_t)(tb ? N : K) * ldb >= (1u << 31)))
         choice = 1;
@@ -774,6 +863,12 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
         else if (!ta && tb) e = launch_fused<false, true>(g, grid, st);
         else if (ta && !tb) e = launch_fused<true, false>(g, grid, st);
         else e = launch_fused<true, true>(g, grid, st);
+    } else if (choice == 2) {
+        dim3 grid(nbx, nby, split_k);
+        if (!ta && !tb) RENET_LAUNCH((gemm_bf16_kernel<false, false>), grid, dim3(THREADS), 0, st, g);
+        else if (!ta && tb) RENET_LAUNCH((gemm_bf16_kernel<false, true>), grid, dim3(THREADS), 0, st, g);
+        else if (ta && !tb) RENET_LAUNCH((gemm_bf16_kernel<true, false>), grid, dim3(THREADS), 0, st, g);
+        else RENET_LAUNCH((gemm_bf16_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
     } else {
         dim3 grid(nbx, nby, split_k);
         if (!ta && !tb) RENET_LAUNCH((gemm_split_kernel<false, false>), grid, dim3(THREADS), 0, st, g);
@@ -796,6 +891,21 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
         RENET_LAUNCH_CHECK();
     }
     return RENET_OK;
+}
+
+
+int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
+                         const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
+                         int split_k, float* workspace, size_t workspace_bytes, void* stream) {
+    return gemm_planes_launch(false, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, split_k, workspace,
+                              workspace_bytes, stream);
+}
+
+int renet_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
+                    const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
+                    int split_k, float* workspace, size_t workspace_bytes, void* stream) {
+    return gemm_planes_launch(true, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, split_k, workspace,
+                              workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -40,6 +40,8 @@ _SIGNATURES = {
                                c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'renet_gemm_f32_split': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                      c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'renet_gemm_bf16': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
+                                c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'renet_colsum_workspace': (c_size_t, [c_int, c_int]),
     'renet_colsum': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     'renet_scale_by_device_scalar': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -321,6 +323,8 @@ def auto_split_k(m, n, k):
     return best
 
 
+# 'bf16'   : operands rounded to bf16 on the way into LDS, ONE v_mfma_f32_32x32x16_bf16 product, fp32 accumulate
+#            (mixed precision for BASELINE config 5; tensors stay fp32 in memory)
 # 'f32'    : v_mfma_f32_32x32x2_f32, exact fp32 products (gemm.hip)
 # 'bf16x6' : fp32 operands split into 3 bf16 terms, 6 term products on v_mfma_f32_32x32x16_bf16 with fp32
 #            accumulation (gemm_split.hip): fp32-class accuracy at 2.67x the matrix-pipe rate
@@ -348,7 +352,8 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, spl
         ws = torch.empty(ws_bytes // 4, device=a.device, dtype=torch.float32)
         ws_ptr = ws.data_ptr()
     t0 = _timer.begin() if _timer is not None else None
-    fn = lib().renet_gemm_f32_split if (mode or GEMM_MODE) == 'bf16x6' else lib().renet_gemm_f32
+    md = mode or GEMM_MODE
+    fn = lib().renet_gemm_f32_split if md == 'bf16x6' else lib().renet_gemm_bf16 if md == 'bf16' else lib().renet_gemm_f32
     _check(fn(int(ta), int(tb), m, n, k, float(alpha), a.data_ptr(), _ld(a), b.data_ptr(),
               _ld(b), float(beta), out.data_ptr(), _ld(out), _f32(bias), split_k, ws_ptr,
               ws_bytes, _stream()), 'gemm_f32')
