@@ -4,7 +4,8 @@ v_mfma_f32_32x32x16_bf16 and accumulates / stores in fp32; every other kernel of
 
 Tolerances against the fp32 reference outputs (the reference has no bf16 path: they are OURS, stated here and in
 DESIGN.md): a bf16 operand carries 8 significant bits (relative rounding error <= 2^-9), so
-  * a GEMM of K-long dot products:           |C - C_fp64| <= 2^-8 * sqrt(K) * max|a| * max|b|   (random-walk bound)
+  * a GEMM of K-long dot products:           |C - C_fp64| <= 2^-8 * (3 sqrt(K) + 1) * max|a| * max|b|  (random walk
+                                             of 2K roundings of <= 2^-9 each, 3 sigma; >= the worst case for K <= 9)
   * training step at config 5:               losses 2e-3 relative; h_n / logits 2e-2 of the tensor's max |value|;
                                              gradients 6e-2 of the tensor's max |value| and 3e-2 in Frobenius norm.
 """
@@ -45,7 +46,7 @@ def test_bf16_gemm_matches_fp64_of_the_rounded_operands(dev, m, n, k, ta, tb):
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=2e-6 * max(1, k))
     # and the distance to the unrounded product stays inside the stated bf16 bound
     full = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64) + bias
-    assert np.abs(out.cpu().numpy() - full).max() <= 2.0 ** -8 * np.sqrt(k) + 1e-6
+    assert np.abs(out.cpu().numpy() - full).max() <= 2.0 ** -8 * (3 * np.sqrt(k) + 1) + 1e-6
 
 
 def test_config5_training_step_in_bf16_mode(dev):
