@@ -47,6 +47,9 @@ def parse():
                          'the default keeps the whole run within a few minutes, SURVEY 8d asks for >= 10)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='torch threads for the CPU baseline (0 = min(32, cores))')
     ap.add_argument('--e2e-steps', type=int, default=5)
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='weak: --batch quadruples per GPU (default); strong: --batch quadruples per step in total, '
+                         'batch / N per GPU')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="f32: fp32-class GEMMs (bf16x6 split, or exact fp32 with RENET_GEMM=f32); bf16: GEMM operands "
                          "rounded to bf16, fp32 accumulate (BASELINE config 5)")
@@ -100,8 +103,10 @@ def main():
     flat = opt.grads
     perm = np.random.RandomState(999).permutation(len(quads))
 
+    rank_batch = args.batch if args.scaling == 'weak' else max(1, args.batch // world)
+
     def prepare(step):
-        idx = parallel.shard_indices(perm, step, rank, world, args.batch)
+        idx = parallel.shard_indices(perm, step, rank, world, rank_batch)
         b = quads[idx]
         return (net.prepare(b, hist_s.take(idx), graph_dict, subject=True),
                 net.prepare(b, hist_o.take(idx), graph_dict, subject=False))
@@ -144,7 +149,7 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    value = args.batch * world * args.steps / elapsed
+    value = rank_batch * world * args.steps / elapsed
 
     # ---- end-to-end rates with the host builder in the loop (extras, never `value`) ----------------
     #  e2e_inline : builder on the training thread (one batch at a time)
@@ -161,7 +166,7 @@ def main():
         import pipeline
 
         def host_step(step):
-            idx = parallel.shard_indices(perm, step, rank, world, args.batch)
+            idx = parallel.shard_indices(perm, step, rank, world, rank_batch)
             b = quads[idx]
             return (net.host_batch(b, hist_s.take(idx), graph_dict, subject=True),
                     net.host_batch(b, hist_o.take(idx), graph_dict, subject=False))
@@ -301,11 +306,11 @@ def main():
         'metric': 'RGCN+GRU encoder triples/s at bs=%d n_hidden=%d (full training step, both directions)'
                   % (args.batch, args.hidden),
         'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': args.scaling,
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'gemm_mode': K.GEMM_MODE,
         'config': {'workload': '%s-shaped synthetic stream (seed 999), n_hidden=%d, seq_len=%d, batch=%d per GPU, '
                                'dropout=%.2f, fwd+bwd both directions + clip + Adam' %
-                               (args.shape, args.hidden, args.seq_len, args.batch, args.dropout),
+                               (args.shape, args.hidden, args.seq_len, rank_batch, args.dropout),
                    'num_entities': num_ent, 'num_relations': num_rels, 'parallelism': 'dp%d' % world,
                    'batch_graph': {'nodes': int(g0.N), 'edges': int(g0.E), 'history_steps': int(g0.S),
                                    'nonempty': int(g0.nnz)}},

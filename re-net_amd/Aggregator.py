@@ -44,8 +44,14 @@ class GlobalEmbTable(object):
             ts = sorted(int(t) for t in global_emb.keys())
             self.times = np.asarray(ts, dtype=np.int64)
             if ts:
-                rows = [torch.as_tensor(global_emb[t]).detach().reshape(dim).float().cpu() for t in ts]
-                self.mat = torch.stack(rows).to(device)
+                # one stack per source device and ONE transfer (a .cpu() per row was a device sync per timestamp:
+                # thousands per rebuild at GDELT scale, and the table is rebuilt at every new test timestamp)
+                rows = [torch.as_tensor(global_emb[t]).detach().reshape(dim).float() for t in ts]
+                devs = {r.device for r in rows}
+                if len(devs) == 1:
+                    self.mat = torch.stack(rows).to(device)
+                else:
+                    self.mat = torch.stack([r.to(device) for r in rows])
             else:
                 self.mat = torch.zeros(1, dim, device=device)
             self._key = key

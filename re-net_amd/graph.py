@@ -162,6 +162,11 @@ class GraphStore(object):
         else:
             self.trip_s = self.trip_r = self.trip_o = np.zeros(0, np.int64)
         self.node_cnt = np.asarray([g.number_of_nodes() for g in gs], dtype=np.int64)
+        # the native passes index scratch tables with these ids unchecked: validate once, here
+        self.max_ent = int(max(self.trip_s.max(), self.trip_o.max())) if len(self.trip_s) else -1
+        self.max_rel = int(self.trip_r.max()) if len(self.trip_r) else -1
+        if len(self.trip_s) and (min(self.trip_s.min(), self.trip_o.min()) < 0 or self.trip_r.min() < 0):
+            raise ValueError('negative entity / relation id in graph_dict')
         order = np.argsort(self.times, kind='stable')
         self._sorted_times = self.times[order]
         self._sorted_pos = order
@@ -535,6 +540,15 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None, 
     s = np.asarray(s, dtype=np.int64).reshape(-1)
     r = np.asarray(r, dtype=np.int64).reshape(-1)
     B = len(s)
+    # ids index scratch tables / counting-sort arrays of the native passes: an id outside [0, num_ent) or
+    # [0, num_rels) (stat.txt disagreeing with the data) must be an error, not an out-of-bounds write
+    if store.max_ent >= num_ent or store.max_rel >= num_rels:
+        raise ValueError('graph_dict holds entity id %d / relation id %d but num_ent = %d, num_rels = %d'
+                         % (store.max_ent, store.max_rel, num_ent, num_rels))
+    if B and (s.min() < 0 or s.max() >= num_ent or r.min() < 0 or r.max() >= num_rels):
+        raise ValueError('batch subject / relation id out of range')
+    if len(fh.nbr_o) and (fh.nbr_o.min() < 0 or fh.nbr_o.max() >= num_ent):
+        raise ValueError('history neighbour id out of range')
     lens_all = np.diff(fh.seq_ptr)
     if sort:
         perm = np.argsort(-lens_all, kind='stable')            # ONE permutation

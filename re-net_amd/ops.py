@@ -41,6 +41,11 @@ def _c(t):
 # (4 uses per direction, 18 MB each) and linear.weight (55 MB) that removes ~45 add/fill kernels per step.
 INPLACE_GRADS = True
 
+# Set by parallel.HipAdam when gradients are exchanged between ranks: called with the parameter right after a
+# Function accumulated its contribution into param.grad in place (the score head's weight and bias), so that the
+# all-reduce of that bucket can start while the rest of the backward pass runs.
+grad_done_hook = None
+
 # Test hook (tests/test_gpu_config.py): when set to a callable(name, tensor), the training path reports its
 # internal activations (GRU final states, entity logits before the in-place CE) -- None in production.
 debug_tap = None
@@ -325,6 +330,9 @@ class HeadCEFn(Function):
             d_b = None
         else:
             d_b = K.colsum(dlogits)
+        if grad_done_hook is not None and t_w is not None and t_b is not None:
+            grad_done_hook(ctx.srcs[2])
+            grad_done_hook(ctx.srcs[3])
         da_rows, dh, dc_rows = K.concat3_bwd(dfeat, d, parts, drop_p, seed)
         d_a = d_c = None
         if t_a is not None:

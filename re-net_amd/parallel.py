@@ -5,11 +5,14 @@ reference's per-batch semantics, and the ONE exchange step is an all-reduce of t
 (80.9 MB fp32 at ICEWS18 sizes) before clip + Adam, i.e. exactly gradient accumulation over
 world_size reference batches.
 
-All gradients live in ONE flat fp32 buffer (param.grad are views into it), so the exchange is a
-single large collective: xGMI is point-to-point (7 links x ~153 GB/s per GPU), so one big ring
-all-reduce (2*(W-1)/W * 81 MB per GPU ~ 0.9 ms at W=8) beats many small ones; no bucketing/overlap
-is attempted because the whole backward is only a few ms and the last-produced gradients
-(ent_embeds, linear.weight) are also the largest.
+All gradients live in ONE flat fp32 buffer (param.grad are views into it).  xGMI is point-to-point
+(7 links x ~153 GB/s per GPU): a ring all-reduce of the 81 MB moves 2*(W-1)/W * 81 MB per GPU ~ 0.9 ms at
+W = 8, a fifth of the step, so the exchange is cut into TWO large buckets (few, large collectives suit the
+per-link bound) and the first one overlaps the backward pass: the score head's parameters (linear.weight +
+bias: 55 of the 81 MB) receive their last gradient contribution when the second entity-head backward has run
+-- the FIRST thing the backward pass does -- so their all-reduce is launched on a side stream at that point
+(ops.grad_done_hook) and runs under the GRU / RGCN backward (~1.5 ms); the rest follows in step().
+No measured multi-GPU curve exists yet (one-GPU boxes only): the logic is covered by world-size-2 gloo tests.
 """
 import torch
 import torch.distributed as dist
@@ -60,6 +63,72 @@ class FlatGrads(object):
         self.flat.mul_(scale)
         return norm
 
+    def span(self, names, module):
+        """(offset, length) of the contiguous flat region that holds the named parameters (they must be adjacent
+        in parameter order, as linear.weight / linear.bias are)."""
+        by_name = {id(p): n for n, p in module.named_parameters()}
+        idx = [i for i, p in enumerate(self.params) if by_name.get(id(p)) in names]
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            raise ValueError('parameters %r are not adjacent in the flat layout' % (names,))
+        lo = self.offsets[idx[0]]
+        hi = self.offsets[idx[-1]] + ((self.params[idx[-1]].numel() + 3) & ~3)
+        return lo, hi - lo
+
+
+class OverlapReducer(object):
+    """Two-bucket gradient all-reduce with the first bucket overlapped with the backward pass.
+
+    early = the flat region of the parameters whose gradient is complete EARLY in the backward pass (RE-Net: the
+    entity score head, model.py:38, whose backward runs first); `early_uses` in-place accumulations complete it
+    per step (the subject and the object pass: 2).  on_grad_done(param) is called by the autograd Functions right
+    after they accumulated into param.grad (ops.grad_done_hook); when the early bucket is complete its all-reduce
+    is issued asynchronously on a side stream (device tensors) / as an async gloo op (CPU tensors) and proceeds
+    while the rest of the backward pass runs.  finish() waits for it, reduces the remaining bucket and averages."""
+
+    def __init__(self, flat_grads, early_span, early_params, early_uses=2, group=None):
+        self.fg, self.group = flat_grads, group
+        self.lo, self.n = early_span
+        self.early_ids = {id(p) for p in early_params}
+        self.early_uses = early_uses * len(self.early_ids)
+        self.count, self.work = 0, None
+        f = flat_grads.flat
+        self.early = f[self.lo:self.lo + self.n]
+        self.rest = [f[:self.lo], f[self.lo + self.n:]]
+        self.stream = torch.cuda.Stream() if f.is_cuda else None
+
+    def active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def on_grad_done(self, param):
+        if id(param) not in self.early_ids or not self.active():
+            return
+        self.count += 1
+        if self.count == self.early_uses and self.work is None:
+            if self.stream is not None:
+                self.stream.wait_stream(torch.cuda.current_stream())      # the accumulating kernels are queued
+                with torch.cuda.stream(self.stream):
+                    self.work = dist.all_reduce(self.early, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                self.work = dist.all_reduce(self.early, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Call after backward(): completes the exchange; the flat buffer then holds the rank-averaged gradient."""
+        if not self.active():
+            self.count, self.work = 0, None
+            return
+        world = dist.get_world_size(self.group)
+        for t in self.rest:
+            if t.numel():
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if self.work is None:                     # the early bucket never completed early (e.g. empty batches)
+            dist.all_reduce(self.early, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self.work.wait()                      # device: makes the current stream wait for the side stream
+            if self.stream is not None:
+                torch.cuda.current_stream().wait_stream(self.stream)
+        self.fg.flat.div_(world)
+        self.count, self.work = 0, None
+
 
 def shard_indices(perm, step, rank, world, batch_size):
     """Rank `rank`'s quadruple indices for global step `step`: consecutive batch_size slices of the
@@ -101,10 +170,21 @@ class HipAdam(object):
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
         self.t = 0
         self.norm = torch.zeros(1, device=self.m.device, dtype=torch.float32)
+        self.reducer = None
+        names = [n for n, _ in module.named_parameters()]
+        if 'linear.weight' in names and 'linear.bias' in names:       # RENet: overlap the score head's bucket
+            import ops
+            early = [p for n, p in module.named_parameters() if n in ('linear.weight', 'linear.bias')]
+            self.reducer = OverlapReducer(self.grads, self.grads.span(('linear.weight', 'linear.bias'), module), early)
+            ops.grad_done_hook = self.reducer.on_grad_done
 
     def step(self):
-        """all-reduce (if distributed) -> clip -> Adam -> zero_grad."""
-        self.grads.allreduce_mean()
+        """all-reduce (if distributed; the score head's bucket was started during backward) -> clip -> Adam ->
+        zero_grad."""
+        if self.reducer is not None:
+            self.reducer.finish()
+        else:
+            self.grads.allreduce_mean()
         self.t += 1
         self.K.adam_step(self.params.flat, self.grads.flat, self.m, self.v, self.lr, self.betas[0], self.betas[1],
                          self.eps, self.wd, self.max_norm, self.t, True, self.norm)

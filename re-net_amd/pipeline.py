@@ -61,7 +61,15 @@ class Uploader(object):
             prep = self.net.prepare_from_host(hbatch)
         main.wait_stream(self.stream)
         g = prep.g
-        for t in ([g._buf, g.norm] if g is not None else []) + [prep.o_idx, prep.s_idx, prep.r_idx]:
-            if t is not None and t.is_cuda:
-                t.record_stream(main)             # allocator: memory is in use on the compute stream
+        # allocator: every tensor allocated under the copy stream is used on the compute stream -- including the
+        # scatter plans of an all-empty-history batch and a global-embedding matrix built inside this context
+        ts = [prep.o_idx, prep.s_idx, prep.r_idx]
+        if g is not None:
+            ts += [g._buf, g.norm, getattr(g, 'glob', None)]
+        for pl in (prep.plan_s, prep.plan_r):
+            if pl is not None:
+                ts += [pl.order, pl.seg_ptr, pl.target]
+        for t in ts:
+            if t is not None and torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(main)
         return prep

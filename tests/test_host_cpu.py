@@ -570,3 +570,24 @@ def test_gather_item_plan_covers_every_light_row_once(heavy, budget):
         assert (gi < hb.n_groups_out) == (v < n_out)
     with pytest.raises(ValueError):
         G.plan_gather_items(hb.row_ptr, hb.col, hb.etype, n_out, 40, 24)
+
+
+def test_builder_rejects_ids_outside_the_declared_ranges():
+    """the native host passes index scratch tables with entity / relation ids unchecked -- ids outside
+    [0, num_ent) / [0, num_rels) (stat.txt disagreeing with the data) must raise before any native call."""
+    import preprocess as P
+    import synth
+    quads, ne, nr, _ = synth.make_stream('YAGO', seed=3, num_t=12)
+    gd = P.build_graph_dict(quads, nr)
+    hs = P.HistoryIndex(quads, 's', 10)
+    idx = np.arange(len(quads) - 50, len(quads))
+    store = G.store_for(gd)
+    G.build_batch(store, ne, nr, quads[idx, 0], quads[idx, 1], hs.take(idx))               # fine
+    with pytest.raises(ValueError):
+        G.build_batch(store, int(quads[:, [0, 2]].max()), nr, quads[idx, 0], quads[idx, 1], hs.take(idx))
+    with pytest.raises(ValueError):
+        G.build_batch(store, ne, int(quads[:, 1].max()), quads[idx, 0], quads[idx, 1], hs.take(idx))
+    bad = quads[idx, 0].copy()
+    bad[0] = -1
+    with pytest.raises(ValueError):
+        G.build_batch(store, ne, nr, bad, quads[idx, 1], hs.take(idx))

@@ -94,3 +94,99 @@ def test_single_process_paths_are_noops():
     flat.allreduce_mean()                      # no process group: must not touch the gradient
     assert torch.equal(before, flat.flat) and flat.check_views()
     assert torch.equal(_flat(net), flat.flat)
+
+
+# ---------------------------------------------------------------------------------------------
+# RENet-level: two ranks, each with its own batch, real model + real flat-gradient layout + the overlapped
+# two-bucket exchange == one process accumulating the same two batches.  The container has no GPU: the device
+# wrappers are emulated in torch-CPU (tests/cpu_abi_emulation.py); the exchange logic under test is the product's.
+# ---------------------------------------------------------------------------------------------
+def _renet_setup():
+    import model as M
+    import preprocess as P
+    import synth
+    quads, num_ent, num_rels, _ = synth.make_stream('YAGO', seed=7, num_t=30)
+    quads = quads[quads[:, 0] < 400]
+    quads = quads[quads[:, 2] < 400]
+    num_ent = 400
+    gd = P.build_graph_dict(quads, num_rels)
+    hs, ho = P.HistoryIndex(quads, 's'), P.HistoryIndex(quads, 'o')
+    torch.manual_seed(21)
+    net = M.RENet(num_ent, 100, num_rels, dropout=0.0, seq_len=10)
+    gen = torch.Generator().manual_seed(2)
+    net.global_emb = {int(t): torch.randn(1, 1, 100, generator=gen) * 0.1 for t in gd}
+    net.eval()
+    perm = np.random.RandomState(4).permutation(len(quads))
+    return net, quads, gd, hs, ho, perm
+
+
+def _renet_grads(net, quads, gd, hs, ho, idx, pair):
+    b = quads[idx]
+    ps = net.prepare(b, hs.take(idx), gd, subject=True)
+    po = net.prepare(b, ho.take(idx), gd, subject=False)
+    loss = net.loss_prepared_pair(ps, po) if pair else net.loss_prepared(ps) + net.loss_prepared(po)
+    loss.backward()
+    return float(loss)
+
+
+def _renet_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cpu_abi_emulation
+    cpu_abi_emulation.install()
+    import ops
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    net, quads, gd, hs, ho, perm = _renet_setup()
+    flat = parallel.FlatGrads(net)
+    early = [p for n, p in net.named_parameters() if n in ('linear.weight', 'linear.bias')]
+    red = parallel.OverlapReducer(flat, flat.span(('linear.weight', 'linear.bias'), net), early)
+    ops.grad_done_hook = red.on_grad_done
+    started = []
+    orig = red.on_grad_done
+
+    def spy(p):
+        orig(p)
+        started.append(red.work is not None)
+    ops.grad_done_hook = spy
+    res = []
+    for step in range(2):
+        idx = parallel.shard_indices(perm, step, rank, world, 96)
+        _renet_grads(net, quads, gd, hs, ho, idx, pair=(step == 1))
+        assert flat.check_views()
+        assert started[-1] and not any(started[:-1][-3:]), started      # launched by the LAST of the 4 notifications
+        red.finish()
+        res.append(flat.flat.clone())
+        flat.zero()
+        del started[:]
+    seeds = [ops.next_seed() for _ in range(3)]
+    torch.save({'flat': res, 'seeds': seeds}, out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_renet_two_ranks_equal_accumulation_over_the_same_batches(tmp_path):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    world, port, out = 2, _free_port(), str(tmp_path / 'r%d.pt')
+    mp.spawn(_renet_worker, args=(world, port, out), nprocs=world, join=True)
+    got = [torch.load(out % r) for r in range(world)]
+    assert torch.equal(got[0]['flat'][0], got[1]['flat'][0])          # both ranks hold the same averaged gradient
+    assert set(got[0]['seeds']).isdisjoint(got[1]['seeds'])           # dropout seeds differ per rank
+    import cpu_abi_emulation
+    undo = cpu_abi_emulation.install()
+    try:
+        net, quads, gd, hs, ho, perm = _renet_setup()
+        flat = parallel.FlatGrads(net)
+        for step in range(2):
+            acc = torch.zeros_like(flat.flat)
+            for rank in range(world):
+                flat.zero()
+                _renet_grads(net, quads, gd, hs, ho, parallel.shard_indices(perm, step, rank, world, 96), pair=False)
+                acc += flat.flat
+            ref = acc / world
+            scale = float(ref.abs().max())
+            assert float((got[0]['flat'][step] - ref).abs().max()) <= 1e-5 * scale
+    finally:
+        undo()
