@@ -14,6 +14,8 @@ bias: 55 of the 81 MB) receive their last gradient contribution when the second 
 (ops.grad_done_hook) and runs under the GRU / RGCN backward (~1.5 ms); the rest follows in step().
 No measured multi-GPU curve exists yet (one-GPU boxes only): the logic is covered by world-size-2 gloo tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -97,7 +99,11 @@ class OverlapReducer(object):
         self.stream = torch.cuda.Stream() if f.is_cuda else None
 
     def active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        # RENET_FORCE_REDUCER=1 runs the collectives even in a one-rank group (a no-op exchange): lets a one-GPU box
+        # exercise the side-stream / RCCL call sequence
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(self.group) > 1 or os.environ.get('RENET_FORCE_REDUCER') == '1'
 
     def on_grad_done(self, param):
         if id(param) not in self.early_ids or not self.active():
