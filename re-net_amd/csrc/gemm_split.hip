@@ -734,6 +734,199 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(SplitArgs g) {
     store_tile(g, m0, n0, z, wm, wn, lane, acc);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// PLANES GEMM (renet_gemm_planes): both operands arrive as three bf16 planes in HBM (renet_pack_planes, or a
+// producer kernel that writes planes directly), so the k-loop holds no fp32 -> bf16 split at all -- the split above
+// costs as much as the 48 MFMAs it feeds (its VALU work cannot hide behind the same SIMD's matrix pipe and its LDS
+// stores saturate the 85 B/clk store path; profiles/r01_g_gemm_probes.md).  Here a k-tile is
+//     12 global_load_lds_dwordx4 per wave (LDS-DMA: no VGPRs, no VALU, no ds_write)
+//     24 fragment reads + 48 v_mfma_f32_32x32x16_bf16 per wave            (same bf16x6 arithmetic, same results)
+// with a 3-deep LDS ring (3 x 48 KB, one workgroup per CU) and ONE raw s_barrier per k-tile: the DMA of tile
+// kt + 2 is issued right behind barrier(kt) into the buffer that every wave finished reading before that barrier,
+// and `s_waitcnt vmcnt(12)` -- the 12 newest DMAs may stay in flight -- is the only wait on global memory.
+//
+// A plane tensor is a row-major bf16 matrix [rows][cols] x 3 planes, both dims padded with zeros to multiples of
+// 128 (so no edge handling exists in the loop).  An operand is consumed in one of two roles:
+//   K-CONTIGUOUS (tr = 0): rows = the operand's M (N) index, cols = K.  Tile image in LDS: [128 rows][32 k], 64-byte
+//       rows, the four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3 -- applied on the SOURCE address of
+//       the DMA (the LDS side of global_load_lds is lane-linear) -- which makes every ds_read_b128 fragment read
+//       conflict free.
+//   K-STRIDED (tr = 1): rows = K, cols = the operand's M (N) index (the tensor as stored when the contraction runs
+//       over its rows: dW = dlogits^T feat, dfeat = dlogits W).  Tile image [32 k][128 cols], 256-byte rows, the
+//       sixteen 16-byte chunks XOR-swizzled by 4 * (k & 3); fragments come from two ds_read_b64_tr_b16 each (gfx950's
+//       transposing LDS read: in a 16-lane group, lane i receives element i & 3 of the 8-byte chunks addressed by
+//       lanes (i >> 2) + 4 j, j = 0..3 -- measured with tools/probes/tr_probe.hip).
+// One plane set therefore serves BOTH roles: the weight of the score head feeds logits (K-contiguous) and dfeat
+// (K-strided), dlogits feeds dfeat (K-contiguous) and dW (K-strided).
+// ------------------------------------------------------------------------------------------------------
+struct PlanesArgs {
+    const __bf16* A;            // plane 0 of A; planes are a_plane elements apart
+    const __bf16* B;
+    size_t a_plane, b_plane;
+    int lda, ldb;               // row stride of a plane (elements)
+    SplitArgs out;              // M, N, K, C, ldc, alpha, beta, bias, split-K fields (A/B/lda/ldb unused)
+};
+
+constexpr int P3_STAGE = 6 * 8192;                       // bytes per ring slot: 3 A planes + 3 B planes, 8 KB each
+constexpr int P3_SLOTS = 3;
+constexpr size_t P3_LDS = (size_t)P3_STAGE * P3_SLOTS;
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <bool TR>
+__device__ __forceinline__ bf16x8 p3_fragment(const char* tile, int lane, int t, int slab) {
+    // fragment of MFMA tile t (rows 32 t .. 32 t + 31 of this wave's 64-row slice; `tile` already points at it)
+    if constexpr (!TR) {
+        const int row = 32 * t + (lane & 31);
+        const int chunk = (2 * slab + (lane >> 5)) ^ ((row >> 2) & 3);
+        return *reinterpret_cast<const bf16x8*>(tile + row * 64 + chunk * 16);
+    } else {
+        const int s = lane & 15;
+        const int col = 32 * t + 16 * ((lane >> 4) & 1) + 4 * (s & 3);       // first of the 4 columns of the chunk
+        bf16x8 r;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int kk = slab * 16 + 8 * (lane >> 5) + 4 * q + (s >> 2);
+            const int phys16 = (col >> 3) ^ (4 * (kk & 3));
+            const char* p = tile + kk * 256 + phys16 * 16 + ((col >> 2) & 1) * 8;
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[4 * q + j] = __builtin_bit_cast(__bf16, (short)v[j]);
+        }
+        return r;
+    }
+}
+
+template <bool A_TR, bool B_TR>
+__global__ __launch_bounds__(THREADS) void gemm_planes_kernel(PlanesArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) char ring[];          // the ONLY LDS object (see the header comment)
+    const SplitArgs& g = pa.out;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx, by;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    const int m0 = by * BM, n0 = bx * BN;
+    const int z = blockIdx.z;
+    const int kt0 = z * g.k_tiles_per_split;
+    const int kt_total = (g.K + BK - 1) / BK;
+    const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
+    const int nk = kt1 - kt0;
+
+    // the 12 DMA pieces of this wave: piece id = wave + 4 i  ->  operand (id / 24), plane ((id / 8) % 3), 1 KB
+    // piece (id % 8) of the plane's 8 KB tile.  Source pointers advance by a uniform stride per k-tile.
+    const __bf16* src[12];
+    int dst[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int id = wave + 4 * i;
+        const int opnd = id / 24, plane = (id / 8) % 3, piece = id % 8;
+        const bool tr = opnd ? B_TR : A_TR;
+        const __bf16* base = (opnd ? pa.B + plane * pa.b_plane : pa.A + plane * pa.a_plane);
+        const int ld = opnd ? pa.ldb : pa.lda;
+        const int r0 = opnd ? n0 : m0;
+        size_t off;
+        if (!tr) {                                   // rows r0 + 16 piece + (lane >> 2), 64 B of k per row
+            const int row = 16 * piece + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+            off = (size_t)(r0 + row) * ld + (size_t)kt0 * BK + chunk * 8;
+        } else {                                     // k rows 4 piece + (lane >> 4), 256 B of columns per row
+            const int kk = 4 * piece + (lane >> 4);
+            const int log16 = (lane & 15) ^ (4 * (kk & 3));
+            off = (size_t)(kt0 * BK + kk) * ld + r0 + log16 * 8;
+        }
+        src[i] = base + off;
+        dst[i] = (opnd * 3 + plane) * 8192 + piece * 1024;
+    }
+    const size_t a_step = A_TR ? (size_t)BK * pa.lda : (size_t)BK;
+    const size_t b_step = B_TR ? (size_t)BK * pa.ldb : (size_t)BK;
+
+    auto issue = [&](int slot) {
+        char* base = ring + slot * P3_STAGE;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                             (__attribute__((address_space(3))) void*)(base + dst[i]), 16, 0, 0);
+            src[i] += ((wave + 4 * i) / 24) ? b_step : a_step;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // tile kt landed (this wave's pieces)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                            // ... and everybody else's
+        if (kt + 2 < nk) issue((kt + 2) % P3_SLOTS);                             // buffer of tile kt - 1: free now
+        const char* st = ring + (kt % P3_SLOTS) * P3_STAGE;
+        const char* ta = st + (A_TR ? wm * 128 : wm * 64 * 64);                 // this wave's 64 rows (cols) of A
+        const char* tb = st + 3 * 8192 + (B_TR ? wn * 128 : wn * 64 * 64);
+#pragma unroll
+        for (int slab = 0; slab < 2; ++slab) {
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[t][p] = p3_fragment<A_TR>(ta + p * 8192, lane, t, slab);
+                    b[t][p] = p3_fragment<B_TR>(tb + p * 8192, lane, t, slab);
+                }
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+        }
+    }
+    store_tile(g, m0, n0, z, wm, wn, lane, acc);
+}
+
+// fp32 [R, C] (row stride ldx) -> three bf16 planes [Rp][Cp] each (Rp, Cp = R, C rounded up to 128; the padding is
+// written as zeros here, so the destination needs no initialisation).  x = p0 + p1 + p2 as in store_items.
+__global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restrict__ X, int R, int C, int ldx, int Rp,
+                                                          int Cp, __bf16* __restrict__ P) {
+    const size_t plane = (size_t)Rp * Cp;
+    const size_t total = plane / 4;                       // items of 4 consecutive columns
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / (Cp / 4)), c = (int)(i % (Cp / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < R) {
+            const float* x = X + (size_t)row * ldx + c;
+            if (c + 3 < C && ((ldx & 3) == 0)) v = *reinterpret_cast<const float4*>(x);
+            else {
+                if (c < C) v.x = x[0];
+                if (c + 1 < C) v.y = x[1];
+                if (c + 2 < C) v.z = x[2];
+                if (c + 3 < C) v.w = x[3];
+            }
+        }
+        f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const bf16x2 blo = __builtin_convertvector(lo, bf16x2);
+            const bf16x2 bhi = __builtin_convertvector(hi, bf16x2);
+            *reinterpret_cast<uint2*>(P + p * plane + (size_t)row * Cp + c) = pack4(blo, bhi);
+            if (p < 2) {
+                lo -= __builtin_convertvector(blo, f32x2);
+                hi -= __builtin_convertvector(bhi, f32x2);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void split_reduce_kernel(const float* __restrict__ partial, int split_k,
                                                            int M, int N, float alpha, float beta,
                                                            const float* __restrict__ bias,
@@ -825,6 +1018,23 @@ int kernel_choice(int ntiles) {
 
 }  // namespace
 
+namespace {
+template <bool A_TR, bool B_TR>
+int launch_planes(const PlanesArgs& pa, dim3 grid, hipStream_t st) {
+    static bool attr_set = false;      // benign race: the attribute is idempotent
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_planes_kernel<A_TR, B_TR>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P3_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    RENET_LAUNCH((gemm_planes_kernel<A_TR, B_TR>), grid, dim3(THREADS), P3_LDS, st, pa);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 #ifdef RENET_GEMM_TRACE
@@ -906,6 +1116,71 @@ int renet_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const floa
                     int split_k, float* workspace, size_t workspace_bytes, void* stream) {
     return gemm_planes_launch(true, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, split_k, workspace,
                               workspace_bytes, stream);
+}
+
+size_t renet_planes_bytes(int R, int C) {
+    const size_t rp = ((size_t)R + 127) & ~(size_t)127, cp = ((size_t)C + 127) & ~(size_t)127;
+    return 3 * rp * cp * sizeof(__bf16);
+}
+
+int renet_pack_planes(const float* X, int R, int C, int ldx, void* planes, void* stream) {
+    if (R < 0 || C < 0 || ldx < C || !planes) return RENET_ERR_BADARG;
+    const int Rp = (R + 127) & ~127, Cp = (C + 127) & ~127;
+    if (Rp == 0 || Cp == 0) return RENET_OK;
+    const size_t total = (size_t)Rp * Cp / 4;
+    const int blocks = (int)min((size_t)4096, (total + 255) / 256);
+    RENET_LAUNCH(pack_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, R, C, ldx, Rp, Cp,
+                 (__bf16*)planes);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_gemm_planes(int a_tr, int b_tr, int M, int N, int K, float alpha, const void* Ap, int lda, const void* Bp,
+                      int ldb, float beta, float* C, int ldc, const float* bias, int split_k, float* workspace,
+                      size_t workspace_bytes, void* stream) {
+    if (M < 0 || N < 0 || K < 1 || ldc < N || !Ap || !Bp) return RENET_ERR_BADARG;
+    if (M == 0 || N == 0) return RENET_OK;
+    const int Mp = (M + 127) & ~127, Np = (N + 127) & ~127, Kp = (K + 127) & ~127;
+    // plane shapes: K-contiguous [Mp][Kp] (ld >= Kp), K-strided [Kp][Mp] (ld >= Mp)
+    if (lda < (a_tr ? Mp : Kp) || ldb < (b_tr ? Np : Kp) || (lda & 7) || (ldb & 7)) return RENET_ERR_BADARG;
+    if (split_k < 1) split_k = 1;
+    const int kt_total = (K + BK - 1) / BK;
+    if (split_k > kt_total) split_k = max(kt_total, 1);
+    if (split_k > 1 && workspace_bytes < renet_gemm_workspace(M, N, split_k)) return RENET_ERR_WORKSPACE;
+    PlanesArgs pa;
+    pa.A = (const __bf16*)Ap; pa.B = (const __bf16*)Bp;
+    pa.lda = lda; pa.ldb = ldb;
+    pa.a_plane = (size_t)(a_tr ? Kp : Mp) * lda;
+    pa.b_plane = (size_t)(b_tr ? Kp : Np) * ldb;
+    SplitArgs& g = pa.out;
+    g.A = nullptr; g.B = nullptr; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
+    g.lda = 0; g.ldb = 0; g.ldc = ldc; g.alpha = alpha; g.beta = beta;
+    g.split_k = split_k;
+    g.k_tiles_per_split = max(1, (kt_total + split_k - 1) / split_k);
+    g.partial = workspace;
+    g.xcd_order = tile_order();
+    hipStream_t st = (hipStream_t)stream;
+    const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
+    dim3 grid(nbx, nby, split_k);
+    int e;
+    if (!a_tr && !b_tr) e = launch_planes<false, false>(pa, grid, st);
+    else if (!a_tr && b_tr) e = launch_planes<false, true>(pa, grid, st);
+    else if (a_tr && !b_tr) e = launch_planes<true, false>(pa, grid, st);
+    else e = launch_planes<true, true>(pa, grid, st);
+    if (e != RENET_OK) return e;
+    if (split_k > 1) {
+        const size_t total = (size_t)M * N;
+        if (total <= (size_t)256 * 1024 && split_k >= 8) {
+            RENET_LAUNCH(split_reduce4_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, workspace,
+                               split_k, M, N, alpha, beta, bias, C, ldc);
+        } else {
+            int blocks = (int)min((size_t)2048, (total + 255) / 256);
+            RENET_LAUNCH(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, split_k, M, N, alpha,
+                               beta, bias, C, ldc);
+        }
+        RENET_LAUNCH_CHECK();
+    }
+    return RENET_OK;
 }
 
 }  // extern "C"

@@ -42,6 +42,10 @@ _SIGNATURES = {
                                      c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'renet_gemm_bf16': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                 c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'renet_planes_bytes': (c_size_t, [c_int, c_int]),
+    'renet_pack_planes': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'renet_gemm_planes': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
+                                  c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'renet_colsum_workspace': (c_size_t, [c_int, c_int]),
     'renet_colsum': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     'renet_scale_by_device_scalar': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -357,6 +361,57 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, spl
     _check(fn(int(ta), int(tb), m, n, k, float(alpha), a.data_ptr(), _ld(a), b.data_ptr(),
               _ld(b), float(beta), out.data_ptr(), _ld(out), _f32(bias), split_k, ws_ptr,
               ws_bytes, _stream()), 'gemm_f32')
+    if t0 is not None:
+        _timer.end('gemm_f32', t0, flops=2.0 * m * n * k)
+    return out
+
+
+class Planes(object):
+    """Three bf16 planes of an fp32 matrix [R, C] (x = p0 + p1 + p2), each [Rp, Cp] with Rp, Cp multiples of 128 and
+    zero padding: the operand format of gemm_planes (renet_pack_planes)."""
+    __slots__ = ('p', 'R', 'C')
+
+    def __init__(self, p, R, C):
+        self.p, self.R, self.C = p, R, C
+
+
+def pack_planes(x, out=None):
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
+        raise RenetHipError('pack_planes needs a 2-D float32 device tensor with unit inner stride')
+    r, c = x.shape
+    rp, cp = (r + 127) & ~127, (c + 127) & ~127
+    p = out.p if out is not None else torch.empty(3, rp, cp, device=x.device, dtype=torch.bfloat16)
+    if tuple(p.shape) != (3, rp, cp):
+        raise RenetHipError('pack_planes: destination has the wrong shape')
+    t0 = _timer.begin() if _timer is not None else None
+    _check(lib().renet_pack_planes(x.data_ptr(), r, c, x.stride(0), p.data_ptr(), _stream()), 'pack_planes')
+    if t0 is not None:
+        _timer.end('pack_planes', t0, nbytes=float(r * c * 4 + 3 * rp * cp * 2))
+    return Planes(p, r, c)
+
+
+def gemm_planes(pa, a_tr, pb, b_tr, out=None, bias=None, alpha=1.0, beta=0.0, split_k=None):
+    """out = alpha * op(A) @ op(B) + bias + beta * out on pre-split operands (include/renet_hip.h):
+    a_tr False: pa holds A [M, K];  True: pa holds A^T [K, M].   b_tr False: pb holds B^T [N, K];  True: B [K, N]."""
+    m, k = (pa.C, pa.R) if a_tr else (pa.R, pa.C)
+    n, k2 = (pb.C, pb.R) if b_tr else (pb.R, pb.C)
+    if k != k2:
+        raise RenetHipError('gemm_planes inner dimensions differ: %d vs %d' % (k, k2))
+    if out is None:
+        if beta != 0.0:
+            raise RenetHipError('beta != 0 needs an output tensor')
+        out = torch.empty(m, n, device=pa.p.device, dtype=torch.float32)
+    if split_k is None:
+        split_k = auto_split_k(m, n, k)
+    ws_ptr, ws_bytes = None, 0
+    if split_k > 1:
+        ws_bytes = lib().renet_gemm_workspace(m, n, split_k)
+        ws = torch.empty(ws_bytes // 4, device=out.device, dtype=torch.float32)
+        ws_ptr = ws.data_ptr()
+    t0 = _timer.begin() if _timer is not None else None
+    _check(lib().renet_gemm_planes(int(a_tr), int(b_tr), m, n, k, float(alpha), pa.p.data_ptr(), pa.p.shape[2],
+                                   pb.p.data_ptr(), pb.p.shape[2], float(beta), out.data_ptr(), _ld(out), _f32(bias),
+                                   split_k, ws_ptr, ws_bytes, _stream()), 'gemm_planes')
     if t0 is not None:
         _timer.end('gemm_f32', t0, flops=2.0 * m * n * k)
     return out
