@@ -773,16 +773,17 @@ constexpr size_t P3_LDS = (size_t)P3_STAGE * P3_SLOTS;
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// Fragment of MFMA tile t of a wave whose 64 rows (K-contiguous image) / 64 columns (K-strided image) start at `w0`
+// inside the operand's 128-wide tile; `tile` = start of the plane's 8 KB image.
 template <bool TR>
-__device__ __forceinline__ bf16x8 p3_fragment(const char* tile, int lane, int t, int slab) {
-    // fragment of MFMA tile t (rows 32 t .. 32 t + 31 of this wave's 64-row slice; `tile` already points at it)
+__device__ __forceinline__ bf16x8 p3_fragment(const char* tile, int lane, int w0, int t, int slab) {
     if constexpr (!TR) {
-        const int row = 32 * t + (lane & 31);
+        const int row = w0 + 32 * t + (lane & 31);
         const int chunk = (2 * slab + (lane >> 5)) ^ ((row >> 2) & 3);
         return *reinterpret_cast<const bf16x8*>(tile + row * 64 + chunk * 16);
     } else {
         const int s = lane & 15;
-        const int col = 32 * t + 16 * ((lane >> 4) & 1) + 4 * (s & 3);       // first of the 4 columns of the chunk
+        const int col = w0 + 32 * t + 16 * ((lane >> 4) & 1) + 4 * (s & 3);  // first of the 4 columns of the chunk
         bf16x8 r;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -797,6 +798,14 @@ __device__ __forceinline__ bf16x8 p3_fragment(const char* tile, int lane, int t,
     }
 }
 
+// The k-loop is ROTATED by half a tile so that no MFMA waits for LDS behind the barrier and the DMA issue slots sit
+// between MFMAs (one wave per SIMD: nothing else can cover them):
+//     state on entry of round kt: F0 = slab 0 of tile kt (registers); tile kt + 1 in flight (issued in round kt - 1)
+//       MFMAs  0..23 on F0 | behind them: the 12 reads of F1 (slab 1 of tile kt) and the 12 DMA pieces of tile kt + 2
+//                           (its ring slot held tile kt - 1, whose last reads every wave finished before the barrier
+//                           of round kt - 1)
+//       s_waitcnt vmcnt(12) [tile kt + 1 landed; tile kt + 2 may stay in flight], s_barrier
+//       MFMAs 24..47 on F1 | behind the first 12: reads of F0 <- slab 0 of tile kt + 1
 template <bool A_TR, bool B_TR>
 __global__ __launch_bounds__(THREADS) void gemm_planes_kernel(PlanesArgs pa) {
     extern __shared__ __attribute__((aligned(16))) char ring[];          // the ONLY LDS object (see the header comment)
@@ -842,14 +851,21 @@ __global__ __launch_bounds__(THREADS) void gemm_planes_kernel(PlanesArgs pa) {
     const size_t a_step = A_TR ? (size_t)BK * pa.lda : (size_t)BK;
     const size_t b_step = B_TR ? (size_t)BK * pa.ldb : (size_t)BK;
 
-    auto issue = [&](int slot) {
+    auto issue_piece = [&](auto ic, char* slot) {
+        constexpr int i = ic.value;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                         (__attribute__((address_space(3))) void*)(slot + dst[i]), 16, 0, 0);
+        src[i] += ((wave + 4 * i) / 24) ? b_step : a_step;
+    };
+    auto issue_all = [&](int slot) {
         char* base = ring + slot * P3_STAGE;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
-                                             (__attribute__((address_space(3))) void*)(base + dst[i]), 16, 0, 0);
-            src[i] += ((wave + 4 * i) / 24) ? b_step : a_step;
-        }
+        static_for<0, 12>([&](auto ic) { issue_piece(ic, base); });
+    };
+    // fragment index = operand + 2 * t + 4 * plane (as in mfma_tile_ld)
+    auto read_frag = [&](auto frc, bf16x8 (&F)[12], const char* st, int slab) {
+        constexpr int fr = frc.value, op = fr & 1, t = (fr >> 1) & 1, p = fr >> 2;
+        if constexpr (op == 0) F[fr] = p3_fragment<A_TR>(st + p * 8192, lane, wm * 64, t, slab);
+        else F[fr] = p3_fragment<B_TR>(st + (3 + p) * 8192, lane, wn * 64, t, slab);
     };
 
     f32x16 acc[2][2];
@@ -860,36 +876,52 @@ __global__ __launch_bounds__(THREADS) void gemm_planes_kernel(PlanesArgs pa) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (nk > 0) issue(0);
-    if (nk > 1) issue(1);
+    constexpr int ORDER[12] = {8, 1, 3, 10, 4, 5, 7, 6, 0, 9, 11, 2};     // order in which the term pairs consume them
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
     constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // tile kt landed (this wave's pieces)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                            // ... and everybody else's
-        if (kt + 2 < nk) issue((kt + 2) % P3_SLOTS);                             // buffer of tile kt - 1: free now
-        const char* st = ring + (kt % P3_SLOTS) * P3_STAGE;
-        const char* ta = st + (A_TR ? wm * 128 : wm * 64 * 64);                 // this wave's 64 rows (cols) of A
-        const char* tb = st + 3 * 8192 + (B_TR ? wn * 128 : wn * 64 * 64);
-#pragma unroll
-        for (int slab = 0; slab < 2; ++slab) {
-            bf16x8 a[2][3], b[2][3];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    a[t][p] = p3_fragment<A_TR>(ta + p * 8192, lane, t, slab);
-                    b[t][p] = p3_fragment<B_TR>(tb + p * 8192, lane, t, slab);
-                }
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+    bf16x8 F0[12], F1[12];
+    if (nk > 0) {
+        issue_all(0);
+        if (nk > 1) {
+            issue_all(1);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        __builtin_amdgcn_s_barrier();
+        static_for<0, 12>([&](auto n) { read_frag(std::integral_constant<int, ORDER[n.value]>{}, F0, ring, 0); });
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* st = ring + (kt % P3_SLOTS) * P3_STAGE;
+        const char* stn = ring + ((kt + 1) % P3_SLOTS) * P3_STAGE;
+        char* slot2 = ring + ((kt + 2) % P3_SLOTS) * P3_STAGE;
+        const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+        static_for<0, 24>([&](auto gc) {
+            constexpr int w = gc.value, q = w >> 2, i = (w >> 1) & 1, j = w & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F0[2 * i + 4 * PA[q]], F0[1 + 2 * j + 4 * PB[q]], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (w < 12) read_frag(std::integral_constant<int, ORDER[w]>{}, F1, st, 1);
+            if constexpr (w % 2 == 1) {
+                if (more2) issue_piece(std::integral_constant<int, w / 2>{}, slot2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (more1) {
+            // lgkmcnt(0): this wave's reads of tile kt (F1, issued >= 12 MFMAs ago) have returned, so the DMA that
+            // other waves aim at this slot after the barrier cannot overtake them
+            if (more2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        static_for<0, 24>([&](auto gc) {
+            constexpr int w = gc.value, q = w >> 2, i = (w >> 1) & 1, j = w & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F1[2 * i + 4 * PA[q]], F1[1 + 2 * j + 4 * PB[q]], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (w < 12) {
+                if (more1) read_frag(std::integral_constant<int, ORDER[w]>{}, F0, stn, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
     }
     store_tile(g, m0, n0, z, wm, wn, lane, acc);
 }
