@@ -798,22 +798,24 @@ __device__ __forceinline__ bf16x8 p3_fragment(const char* tile, int lane, int w0
     }
 }
 
-// The k-loop is ROTATED by half a tile so that no MFMA waits for LDS behind the barrier and the DMA issue slots sit
-// between MFMAs (one wave per SIMD: nothing else can cover them):
-//     state on entry of round kt: F0 = slab 0 of tile kt (registers); tile kt + 1 in flight (issued in round kt - 1)
-//       MFMAs  0..23 on F0 | behind them: the 12 reads of F1 (slab 1 of tile kt) and the 12 DMA pieces of tile kt + 2
-//                           (its ring slot held tile kt - 1, whose last reads every wave finished before the barrier
-//                           of round kt - 1)
-//       s_waitcnt vmcnt(12) [tile kt + 1 landed; tile kt + 2 may stay in flight], s_barrier
-//       MFMAs 24..47 on F1 | behind the first 12: reads of F0 <- slab 0 of tile kt + 1
+// Wave specialisation: a workgroup is 8 waves -- waves 0..3 (one per SIMD) only read fragments and issue MFMAs, waves
+// 4..7 (their SIMD partners) only issue the LDS-DMA.  A global_load_lds costs the issuing wave ~60-100 cycles of issue
+// time (12 per k-tile and wave: as much as half the tile's MFMA time when the MFMA wave has to issue them itself,
+// measured: 3200 cycles per k-tile against 1536 of matrix-pipe time); from a partner wave it overlaps the MFMAs.
+//   ring of 3 slots, ONE s_barrier per round, all 8 waves:
+//     loader, round k : issue tile k + 2 into slot (k + 2) % 3   [held tile k - 1: every MFMA wave finished reading it
+//                                                                 before barrier k - 1]
+//                       s_waitcnt vmcnt(12)                       [tile k + 1 landed; tile k + 2 stays in flight]
+//                       barrier k
+//     MFMA wave, round k : fragments of tile k (slot k % 3), 48 MFMAs with the slab-1 reads behind the first 12,
+//                          s_waitcnt lgkmcnt(0), barrier k
 template <bool A_TR, bool B_TR>
-__global__ __launch_bounds__(THREADS) void gemm_planes_kernel(PlanesArgs pa) {
+__global__ __launch_bounds__(2 * THREADS) void gemm_planes_kernel(PlanesArgs pa) {
     extern __shared__ __attribute__((aligned(16))) char ring[];          // the ONLY LDS object (see the header comment)
     const SplitArgs& g = pa.out;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
     int bx, by;
     tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
     const int m0 = by * BM, n0 = bx * BN;
@@ -822,50 +824,116 @@ __global__ __launch_bounds__(THREADS) void gemm_planes_kernel(PlanesArgs pa) {
     const int kt_total = (g.K + BK - 1) / BK;
     const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
     const int nk = kt1 - kt0;
+    if (nk <= 0) return;                                  // (workgroup-uniform)
 
-    // the 12 DMA pieces of this wave: piece id = wave + 4 i  ->  operand (id / 24), plane ((id / 8) % 3), 1 KB
-    // piece (id % 8) of the plane's 8 KB tile.  Source pointers advance by a uniform stride per k-tile.
-    const __bf16* src[12];
-    int dst[12];
+    if (wave >= 4) {
+        // ---------------- loader waves ----------------
+        // the 12 DMA pieces of this wave: piece id = lw + 4 i  ->  operand (id / 24), plane ((id / 8) % 3), 1 KB
+        // piece (id % 8) of the plane's 8 KB tile.  Source pointers advance by a uniform stride per k-tile.
+        const int lw = wave - 4;
+        const __bf16* src[12];
+        int dst[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int id = wave + 4 * i;
-        const int opnd = id / 24, plane = (id / 8) % 3, piece = id % 8;
-        const bool tr = opnd ? B_TR : A_TR;
-        const __bf16* base = (opnd ? pa.B + plane * pa.b_plane : pa.A + plane * pa.a_plane);
-        const int ld = opnd ? pa.ldb : pa.lda;
-        const int r0 = opnd ? n0 : m0;
-        size_t off;
-        if (!tr) {                                   // rows r0 + 16 piece + (lane >> 2), 64 B of k per row
-            const int row = 16 * piece + (lane >> 2);
-            const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-            off = (size_t)(r0 + row) * ld + (size_t)kt0 * BK + chunk * 8;
-        } else {                                     // k rows 4 piece + (lane >> 4), 256 B of columns per row
-            const int kk = 4 * piece + (lane >> 4);
-            const int log16 = (lane & 15) ^ (4 * (kk & 3));
-            off = (size_t)(kt0 * BK + kk) * ld + r0 + log16 * 8;
+        for (int i = 0; i < 12; ++i) {
+            const int id = lw + 4 * i;
+            const int opnd = id / 24, plane = (id / 8) % 3, piece = id % 8;
+            const bool tr = opnd ? B_TR : A_TR;
+            const __bf16* base = (opnd ? pa.B + plane * pa.b_plane : pa.A + plane * pa.a_plane);
+            const int ld = opnd ? pa.ldb : pa.lda;
+            const int r0 = opnd ? n0 : m0;
+            size_t off;
+            if (!tr) {                                   // rows r0 + 16 piece + (lane >> 2), 64 B of k per row
+                const int row = 16 * piece + (lane >> 2);
+                const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+                off = (size_t)(r0 + row) * ld + (size_t)kt0 * BK + chunk * 8;
+            } else {                                     // k rows 4 piece + (lane >> 4), 256 B of columns per row
+                const int kk = 4 * piece + (lane >> 4);
+                const int log16 = (lane & 15) ^ (4 * (kk & 3));
+                off = (size_t)(kt0 * BK + kk) * ld + r0 + log16 * 8;
+            }
+            src[i] = base + off;
+            dst[i] = (opnd * 3 + plane) * 8192 + piece * 1024;
         }
-        src[i] = base + off;
-        dst[i] = (opnd * 3 + plane) * 8192 + piece * 1024;
+        const size_t a_step = A_TR ? (size_t)BK * pa.lda : (size_t)BK;
+        const size_t b_step = B_TR ? (size_t)BK * pa.ldb : (size_t)BK;
+        auto issue_all = [&](int slot) {
+            char* base = ring + slot * P3_STAGE;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                                 (__attribute__((address_space(3))) void*)(base + dst[i]), 16, 0, 0);
+                src[i] += ((lw + 4 * i) / 24) ? b_step : a_step;
+            }
+        };
+        issue_all(0);
+        if (nk > 1) {
+            issue_all(1);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                                     // barrier -1: tile 0 visible
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 2 < nk) {
+                issue_all((kt + 2) % P3_SLOTS);
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                                 // barrier kt: tile kt + 1 visible
+        }
+        return;
     }
-    const size_t a_step = A_TR ? (size_t)BK * pa.lda : (size_t)BK;
-    const size_t b_step = B_TR ? (size_t)BK * pa.ldb : (size_t)BK;
 
-    auto issue_piece = [&](auto ic, char* slot) {
-        constexpr int i = ic.value;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
-                                         (__attribute__((address_space(3))) void*)(slot + dst[i]), 16, 0, 0);
-        src[i] += ((wave + 4 * i) / 24) ? b_step : a_step;
-    };
-    auto issue_all = [&](int slot) {
-        char* base = ring + slot * P3_STAGE;
-        static_for<0, 12>([&](auto ic) { issue_piece(ic, base); });
+    // ---------------- MFMA waves ----------------
+    const int wm = wave >> 1, wn = wave & 1;
+    // byte offsets of this lane's fragment reads inside a plane's 8 KB image: K-contiguous [t][slab], K-strided [t][q]
+    // (slab 1 of a K-strided image is 16 k rows = 4096 bytes further)
+    int offA[2][2], offB[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if constexpr (!A_TR) {
+                const int row = wm * 64 + 32 * t + (lane & 31);
+                offA[t][u] = row * 64 + (((2 * u + (lane >> 5)) ^ ((row >> 2) & 3)) * 16);
+            } else {
+                const int sl = lane & 15;
+                const int col = wm * 64 + 32 * t + 16 * ((lane >> 4) & 1) + 4 * (sl & 3);
+                const int kk = 8 * (lane >> 5) + 4 * u + (sl >> 2);
+                offA[t][u] = kk * 256 + (((col >> 3) ^ (4 * (kk & 3))) * 16) + ((col >> 2) & 1) * 8;
+            }
+            if constexpr (!B_TR) {
+                const int row = wn * 64 + 32 * t + (lane & 31);
+                offB[t][u] = row * 64 + (((2 * u + (lane >> 5)) ^ ((row >> 2) & 3)) * 16);
+            } else {
+                const int sl = lane & 15;
+                const int col = wn * 64 + 32 * t + 16 * ((lane >> 4) & 1) + 4 * (sl & 3);
+                const int kk = 8 * (lane >> 5) + 4 * u + (sl >> 2);
+                offB[t][u] = kk * 256 + (((col >> 3) ^ (4 * (kk & 3))) * 16) + ((col >> 2) & 1) * 8;
+            }
+        }
+    auto frag_tr = [&](const char* img, const int (&off)[2], int slab) {
+        bf16x8 r;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(img + off[q] + slab * 4096));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[4 * q + j] = __builtin_bit_cast(__bf16, (short)v[j]);
+        }
+        return r;
     };
     // fragment index = operand + 2 * t + 4 * plane (as in mfma_tile_ld)
-    auto read_frag = [&](auto frc, bf16x8 (&F)[12], const char* st, int slab) {
-        constexpr int fr = frc.value, op = fr & 1, t = (fr >> 1) & 1, p = fr >> 2;
-        if constexpr (op == 0) F[fr] = p3_fragment<A_TR>(st + p * 8192, lane, wm * 64, t, slab);
-        else F[fr] = p3_fragment<B_TR>(st + (3 + p) * 8192, lane, wn * 64, t, slab);
+    auto read_frag = [&](auto frc, bf16x8 (&F)[12], const char* st, auto slabc) {
+        constexpr int fr = frc.value, op = fr & 1, t = (fr >> 1) & 1, p = fr >> 2, slab = slabc.value;
+        if constexpr (op == 0) {
+            if constexpr (!A_TR) F[fr] = *reinterpret_cast<const bf16x8*>(st + p * 8192 + offA[t][slab]);
+            else F[fr] = frag_tr(st + p * 8192, offA[t], slab);
+        } else {
+            if constexpr (!B_TR) F[fr] = *reinterpret_cast<const bf16x8*>(st + (3 + p) * 8192 + offB[t][slab]);
+            else F[fr] = frag_tr(st + (3 + p) * 8192, offB[t], slab);
+        }
     };
 
     f32x16 acc[2][2];
@@ -879,49 +947,27 @@ __global__ __launch_bounds__(THREADS) void gemm_planes_kernel(PlanesArgs pa) {
     constexpr int ORDER[12] = {8, 1, 3, 10, 4, 5, 7, 6, 0, 9, 11, 2};     // order in which the term pairs consume them
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
     constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
     bf16x8 F0[12], F1[12];
-    if (nk > 0) {
-        issue_all(0);
-        if (nk > 1) {
-            issue_all(1);
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        static_for<0, 12>([&](auto n) { read_frag(std::integral_constant<int, ORDER[n.value]>{}, F0, ring, 0); });
-    }
+    __builtin_amdgcn_s_barrier();                                         // barrier -1: tile 0 visible
     for (int kt = 0; kt < nk; ++kt) {
         const char* st = ring + (kt % P3_SLOTS) * P3_STAGE;
-        const char* stn = ring + ((kt + 1) % P3_SLOTS) * P3_STAGE;
-        char* slot2 = ring + ((kt + 2) % P3_SLOTS) * P3_STAGE;
-        const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
-        static_for<0, 24>([&](auto gc) {
-            constexpr int w = gc.value, q = w >> 2, i = (w >> 1) & 1, j = w & 1;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F0[2 * i + 4 * PA[q]], F0[1 + 2 * j + 4 * PB[q]], acc[i][j], 0, 0, 0);
+        static_for<0, 12>([&](auto n) { read_frag(std::integral_constant<int, ORDER[n.value]>{}, F0, st, I0{}); });
+        static_for<0, 48>([&](auto gc) {
+            constexpr int gI = gc.value, w = gI % 24, q = w >> 2, i = (w >> 1) & 1, j = w & 1;
+            if constexpr (gI < 24)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F0[2 * i + 4 * PA[q]], F0[1 + 2 * j + 4 * PB[q]], acc[i][j], 0, 0, 0);
+            else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F1[2 * i + 4 * PA[q]], F1[1 + 2 * j + 4 * PB[q]], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (w < 12) read_frag(std::integral_constant<int, ORDER[w]>{}, F1, st, 1);
-            if constexpr (w % 2 == 1) {
-                if (more2) issue_piece(std::integral_constant<int, w / 2>{}, slot2);
-            }
+            if constexpr (gI < 12) read_frag(std::integral_constant<int, ORDER[gI]>{}, F1, st, I1{});
             __builtin_amdgcn_sched_barrier(0);
         });
-        if (more1) {
-            // lgkmcnt(0): this wave's reads of tile kt (F1, issued >= 12 MFMAs ago) have returned, so the DMA that
-            // other waves aim at this slot after the barrier cannot overtake them
-            if (more2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        static_for<0, 24>([&](auto gc) {
-            constexpr int w = gc.value, q = w >> 2, i = (w >> 1) & 1, j = w & 1;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F1[2 * i + 4 * PA[q]], F1[1 + 2 * j + 4 * PB[q]], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (w < 12) {
-                if (more1) read_frag(std::integral_constant<int, ORDER[w]>{}, F0, stn, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
+        // every LDS read of tile kt has returned (they were issued >= 36 MFMAs ago): the DMA that the loaders aim
+        // at this slot after the barrier cannot overtake them
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                     // barrier kt
     }
     store_tile(g, m0, n0, z, wm, wn, lane, acc);
 }
@@ -1060,7 +1106,7 @@ int launch_planes(const PlanesArgs& pa, dim3 grid, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    RENET_LAUNCH((gemm_planes_kernel<A_TR, B_TR>), grid, dim3(THREADS), P3_LDS, st, pa);
+    RENET_LAUNCH((gemm_planes_kernel<A_TR, B_TR>), grid, dim3(2 * THREADS), P3_LDS, st, pa);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
