@@ -769,6 +769,9 @@ struct PlanesArgs {
 
 constexpr int P3_STAGE = 6 * 8192;                       // bytes per ring slot: 3 A planes + 3 B planes, 8 KB each
 constexpr int P3_SLOTS = 3;
+constexpr int P3_LOADERS = 4;                           // loader waves per workgroup (48 DMA pieces per k-tile)
+constexpr int P3_PER = 48 / P3_LOADERS;
+constexpr int P3_THREADS = 64 * (4 + P3_LOADERS);
 constexpr size_t P3_LDS = (size_t)P3_STAGE * P3_SLOTS;
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -810,7 +813,7 @@ __device__ __forceinline__ bf16x8 p3_fragment(const char* tile, int lane, int w0
 //     MFMA wave, round k : fragments of tile k (slot k % 3), 48 MFMAs with the slab-1 reads behind the first 12,
 //                          s_waitcnt lgkmcnt(0), barrier k
 template <bool A_TR, bool B_TR>
-__global__ __launch_bounds__(2 * THREADS) void gemm_planes_kernel(PlanesArgs pa) {
+__global__ __launch_bounds__(P3_THREADS) void gemm_planes_kernel(PlanesArgs pa) {
     extern __shared__ __attribute__((aligned(16))) char ring[];          // the ONLY LDS object (see the header comment)
     const SplitArgs& g = pa.out;
     const int tid = threadIdx.x;
@@ -823,19 +826,19 @@ __global__ __launch_bounds__(2 * THREADS) void gemm_planes_kernel(PlanesArgs pa)
     const int kt0 = z * g.k_tiles_per_split;
     const int kt_total = (g.K + BK - 1) / BK;
     const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
-    const int nk = kt1 - kt0;
-    if (nk <= 0) return;                                  // (workgroup-uniform)
+    const int nk = max(kt1 - kt0, 0);                     // (an empty split-K slice still stores its zero tile)
 
     if (wave >= 4) {
+        if (nk == 0) return;
         // ---------------- loader waves ----------------
         // the 12 DMA pieces of this wave: piece id = lw + 4 i  ->  operand (id / 24), plane ((id / 8) % 3), 1 KB
         // piece (id % 8) of the plane's 8 KB tile.  Source pointers advance by a uniform stride per k-tile.
         const int lw = wave - 4;
-        const __bf16* src[12];
-        int dst[12];
+        const __bf16* src[P3_PER];
+        int dst[P3_PER];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int id = lw + 4 * i;
+        for (int i = 0; i < P3_PER; ++i) {
+            const int id = lw + P3_LOADERS * i;
             const int opnd = id / 24, plane = (id / 8) % 3, piece = id % 8;
             const bool tr = opnd ? B_TR : A_TR;
             const __bf16* base = (opnd ? pa.B + plane * pa.b_plane : pa.A + plane * pa.a_plane);
@@ -859,16 +862,16 @@ __global__ __launch_bounds__(2 * THREADS) void gemm_planes_kernel(PlanesArgs pa)
         auto issue_all = [&](int slot) {
             char* base = ring + slot * P3_STAGE;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {
+            for (int i = 0; i < P3_PER; ++i) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
                                                  (__attribute__((address_space(3))) void*)(base + dst[i]), 16, 0, 0);
-                src[i] += ((lw + 4 * i) / 24) ? b_step : a_step;
+                src[i] += ((lw + P3_LOADERS * i) / 24) ? b_step : a_step;
             }
         };
         issue_all(0);
         if (nk > 1) {
             issue_all(1);
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            if constexpr (P3_PER == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -876,7 +879,7 @@ __global__ __launch_bounds__(2 * THREADS) void gemm_planes_kernel(PlanesArgs pa)
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 2 < nk) {
                 issue_all((kt + 2) % P3_SLOTS);
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                if constexpr (P3_PER == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -950,7 +953,7 @@ __global__ __launch_bounds__(2 * THREADS) void gemm_planes_kernel(PlanesArgs pa)
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     bf16x8 F0[12], F1[12];
-    __builtin_amdgcn_s_barrier();                                         // barrier -1: tile 0 visible
+    if (nk > 0) __builtin_amdgcn_s_barrier();                             // barrier -1: tile 0 visible
     for (int kt = 0; kt < nk; ++kt) {
         const char* st = ring + (kt % P3_SLOTS) * P3_STAGE;
         static_for<0, 12>([&](auto n) { read_frag(std::integral_constant<int, ORDER[n.value]>{}, F0, st, I0{}); });
@@ -1106,7 +1109,7 @@ int launch_planes(const PlanesArgs& pa, dim3 grid, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    RENET_LAUNCH((gemm_planes_kernel<A_TR, B_TR>), grid, dim3(2 * THREADS), P3_LDS, st, pa);
+    RENET_LAUNCH((gemm_planes_kernel<A_TR, B_TR>), grid, dim3(P3_THREADS), P3_LDS, st, pa);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
