@@ -223,6 +223,17 @@ def main():
         if st['bytes']:
             ent['gbs'] = st['bytes'] / (st['ms'] * 1e-3) / 1e9
         kernels[name] = ent
+    # per-shape view of the GEMM class (row counts that vary with the batch graph are rounded to thousands)
+    merged = {}
+    for tag, o in timer.by_tag('gemm_f32').items():
+        key = tuple(tag[:2]) + tuple(v if v <= 2048 or v == num_ent else int(round(v, -3)) for v in tag[2:5]) + (tag[5],)
+        mo = merged.setdefault(key, {'calls': 0, 'ms': 0.0, 'flops': 0.0})
+        for f in mo:
+            mo[f] += o[f]
+    gemm_shapes = [{'ta_tb_m_n_k_split': list(key), 'calls_per_step': round(o['calls'] / args.steps, 2),
+                    'avg_us': round(o['ms'] * 1e3 / o['calls'], 2),
+                    'tflops': round(o['flops'] / (o['ms'] * 1e-3) / 1e12, 1)}
+                   for key, o in sorted(merged.items(), key=lambda kv: -kv[1]['ms'])]
     dom = max(stats, key=lambda n: stats[n]['ms']) if stats else None
     roofline = None
     if dom:
@@ -315,7 +326,7 @@ def main():
                    'batch_graph': {'nodes': int(g0.N), 'edges': int(g0.E), 'history_steps': int(g0.S),
                                    'nonempty': int(g0.nnz)}},
         'roofline': roofline, 'roofline_rgcn_gather': gather, 'roofline_gru': gru, 'parity': parity,
-        'value_exact_f32': exact, 'pmc_source': pmc_file, 'kernels': kernels, 'cpu_baseline': cpu,
+        'value_exact_f32': exact, 'pmc_source': pmc_file, 'kernels': kernels, 'gemm_shapes': gemm_shapes, 'cpu_baseline': cpu,
         'host_build_ms': host_build_ms, 'e2e_value': e2e, 'e2e_workers': e2e_workers, 'e2e_inline': e2e_inline,
         'last_loss': last_loss,
     }

@@ -177,17 +177,28 @@ class KernelTimer(object):
         e.record()
         return e
 
-    def end(self, name, e0, flops=0.0, nbytes=0.0):
+    def end(self, name, e0, flops=0.0, nbytes=0.0, tag=None):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.recs.setdefault(name, []).append((e0, e1, flops, nbytes))
+        self.recs.setdefault(name, []).append((e0, e1, flops, nbytes, tag))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for name, rs in self.recs.items():
-            out[name] = {'calls': len(rs), 'ms': sum(a.elapsed_time(b) for a, b, _, _ in rs),
+            out[name] = {'calls': len(rs), 'ms': sum(r[0].elapsed_time(r[1]) for r in rs),
                          'flops': sum(r[2] for r in rs), 'bytes': sum(r[3] for r in rs)}
+        return out
+
+    def by_tag(self, name):
+        """per-tag breakdown of one class (GEMMs: tag = (ta, tb, m, n, k, split_k))"""
+        torch.cuda.synchronize()
+        out = {}
+        for r in self.recs.get(name, []):
+            o = out.setdefault(r[4], {'calls': 0, 'ms': 0.0, 'flops': 0.0})
+            o['calls'] += 1
+            o['ms'] += r[0].elapsed_time(r[1])
+            o['flops'] += r[2]
         return out
 
 
@@ -362,7 +373,7 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, spl
               _ld(b), float(beta), out.data_ptr(), _ld(out), _f32(bias), split_k, ws_ptr,
               ws_bytes, _stream()), 'gemm_f32')
     if t0 is not None:
-        _timer.end('gemm_f32', t0, flops=2.0 * m * n * k)
+        _timer.end('gemm_f32', t0, flops=2.0 * m * n * k, tag=(int(ta), int(tb), m, n, k, split_k))
     return out
 
 
