@@ -53,6 +53,10 @@ def parse():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="f32: fp32-class GEMMs (bf16x6 split, or exact fp32 with RENET_GEMM=f32); bf16: GEMM operands "
                          "rounded to bf16, fp32 accumulate (BASELINE config 5)")
+    ap.add_argument('--passes', choices=('merged', 'pair', 'serial'), default='merged',
+                    help='how a step runs the subject and the object pass of its batch (train.py:136-138): merged = '
+                         'one pass over the 2B sequences (RENet.loss_prepared_both), pair = two passes with their four '
+                         'GRU recurrences sharing launches (loss_prepared_pair), serial = RENet.loss_prepared twice')
     ap.add_argument('--no-pair', action='store_true',
                     help='run the subject and object passes strictly one after the other (RENet.loss_prepared twice) '
                          'instead of RENet.loss_prepared_pair')
@@ -105,17 +109,30 @@ def main():
 
     rank_batch = args.batch if args.scaling == 'weak' else max(1, args.batch // world)
 
+    if args.no_pair:
+        args.passes = 'serial'
+    if args.passes == 'merged' and opt.reducer is not None:
+        opt.reducer.set_uses(1)          # the score head's gradient is complete after ONE head backward
+
     def prepare(step):
         idx = parallel.shard_indices(perm, step, rank, world, rank_batch)
         b = quads[idx]
+        if args.passes == 'merged':
+            both = net.prepare_both(b, hist_s.take(idx), hist_o.take(idx), graph_dict)
+            if both is not None:
+                return (both,)
         return (net.prepare(b, hist_s.take(idx), graph_dict, subject=True),
                 net.prepare(b, hist_o.take(idx), graph_dict, subject=False))
 
-    def train_step(ps, po):
-        if args.no_pair:
-            loss = net.loss_prepared(ps) + net.loss_prepared(po)
-        else:           # same arithmetic; the four GRU recurrences of the two passes share one launch
-            loss = net.loss_prepared_pair(ps, po)
+    def step_loss(*preps):
+        if len(preps) == 1:              # same arithmetic per row; every kernel sees the rows of both passes
+            return net.loss_prepared_both(preps[0])
+        if args.passes == 'serial':
+            return net.loss_prepared(preps[0]) + net.loss_prepared(preps[1])
+        return net.loss_prepared_pair(*preps)       # the four GRU recurrences of the two passes share one launch
+
+    def train_step(*preps):
+        loss = step_loss(*preps)
         loss.backward()
         opt.step()                       # gradient all-reduce (N>1) -> clip -> Adam -> zero_grad
         return loss
@@ -168,6 +185,10 @@ def main():
         def host_step(step):
             idx = parallel.shard_indices(perm, step, rank, world, rank_batch)
             b = quads[idx]
+            if args.passes == 'merged':
+                both = net.host_batch_both(b, hist_s.take(idx), hist_o.take(idx), graph_dict)
+                if both is not None:
+                    return (both,)
             return (net.host_batch(b, hist_s.take(idx), graph_dict, subject=True),
                     net.host_batch(b, hist_o.take(idx), graph_dict, subject=False))
         n_pipe = max(40, 8 * args.e2e_steps)
@@ -176,13 +197,13 @@ def main():
         up = pipeline.Uploader(net)                              # H2D on a copy stream, off the compute queue
         it = iter(pf)
         first = [next(it) for _ in range(4)]                    # let the workers fill the pipe
-        for hs_, ho_ in first:
-            train_step(up(hs_), up(ho_))
+        for hbs in first:
+            train_step(*[up(h) for h in hbs])
         sync_all()
         t0 = time.perf_counter()
         done = 0
-        for hs_, ho_ in it:
-            train_step(up(hs_), up(ho_))
+        for hbs in it:
+            train_step(*[up(h) for h in hbs])
             done += 1
         sync_all()
         e2e = args.batch * world * done / (time.perf_counter() - t0)
@@ -286,11 +307,7 @@ def main():
         hip_losses = []
         with torch.no_grad():
             for k in cpu_steps_idx:
-                idx = parallel.shard_indices(perm, k, 0, 1, args.batch)
-                b = quads[idx]
-                ls = net.loss_prepared(net.prepare(b, hist_s.take(idx), graph_dict, subject=True)) + \
-                    net.loss_prepared(net.prepare(b, hist_o.take(idx), graph_dict, subject=False))
-                hip_losses.append(float(ls.item()))
+                hip_losses.append(float(step_loss(*prepare(k)).item()))      # the path that was timed
         net.train()
         rel = [abs(a - b_) / abs(b_) for a, b_ in zip(hip_losses, oracle_losses)]
         parity = {'hip_loss': hip_losses[0], 'oracle_loss': oracle_losses[0], 'rel_err': max(rel),
@@ -304,7 +321,7 @@ def main():
         cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.f32_steps), '--warmup', str(args.warmup),
                '--shape', args.shape, '--batch', str(args.batch), '--hidden', str(args.hidden), '--seq-len',
                str(args.seq_len), '--dropout', str(args.dropout), '--cpu-steps', '0', '--e2e-steps', '0',
-               '--f32-steps', '0']
+               '--f32-steps', '0', '--passes', args.passes]
         r = subprocess.run(cmd, env=dict(os.environ, RENET_GEMM='f32'), capture_output=True, text=True)
         try:
             j = json.loads(r.stdout.strip().splitlines()[-1])
@@ -318,7 +335,7 @@ def main():
                   % (args.batch, args.hidden),
         'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': args.scaling,
-        'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'gemm_mode': K.GEMM_MODE,
+        'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'gemm_mode': K.GEMM_MODE, 'passes': args.passes,
         'config': {'workload': '%s-shaped synthetic stream (seed 999), n_hidden=%d, seq_len=%d, batch=%d per GPU, '
                                'dropout=%.2f, fwd+bwd both directions + clip + Adam' %
                                (args.shape, args.hidden, args.seq_len, rank_batch, args.dropout),

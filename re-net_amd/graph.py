@@ -327,7 +327,7 @@ class HostBatch(object):
     INT_FIELDS = ('node_ent', 'row_ptr', 'col', 'etype', 'e_src', 'e_dst', 'chunk_ptr', 'chunk_type',
                   'type_chunk_ptr', 'subj_row', 'row_ent', 'row_rel', 'glob_row', 's_sorted', 'r_sorted',
                   'step_off', 'heavy_rows', 'heavy_rows_out', 'e_src2', 'e_dst2', 'chunk_ptr2', 'chunk_type2',
-                  'type_chunk_ptr2', 'it_src', 'it_type', 'grp_ptr')
+                  'type_chunk_ptr2', 'it_src', 'it_type', 'grp_ptr', 'rel_label', 'ent_label')
     PLANS = ('plan_node_ent', 'plan_subj_row', 'plan_s', 'plan_r')
 
     def set_edges(self, n, src, dst, et, num_types, heavy=None):
@@ -525,7 +525,8 @@ def _induced_edges(store, ti, num_ent, keys, new_id, sparse=False):
     return np.concatenate(out_s), np.concatenate(out_o), np.concatenate(out_r)
 
 
-def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None, group=None):
+def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None, group=None, reverse_group=None,
+                sparse=None):
     """Vectorised restatement of utils.py:209-283 (+115-131,149-181).
 
     store: GraphStore;  s, r: int arrays [B];  fh: FlatHistory of the B sequences;
@@ -535,6 +536,10 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None, 
       model.py:329-352, one call per test quadruple) in one batch;
     Edge types are stored as type_s; the object-side pass (reverse, model.py:78) uses
     type_o = (type_s + R) mod 2R, which the kernels apply as `type_shift`;
+    reverse_group: optional bool array indexed by group id: member graphs of those groups store the OBJECT-side
+      edge types (type_s + R) mod 2R, so one launch with type_shift = 0 serves both directions (build_batch_both);
+    sparse: edge filter for grouped batches -- True (default with groups) walks the store's subject index per node
+      (many small member graphs), False uses the per-timestamp table pass of the training batches;
     glob_index: callable mapping an int64 array of timestamps to rows of the global-embedding matrix.
     Returns a HostBatch (numpy)."""
     s = np.asarray(s, dtype=np.int64).reshape(-1)
@@ -577,10 +582,12 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None, 
     step_j = np.arange(S, dtype=np.int64) - np.repeat(np.cumsum(ln) - ln, ln)
     t_k = fh.step_t[step_idx]
     uniq_t, slot_k = np.unique(t_k, return_inverse=True)
+    slot_group = None
     if group is not None:
         g_k = np.asarray(group, dtype=np.int64).reshape(-1)[perm][step_seq]
         pair, slot_k = np.unique(g_k * max(len(uniq_t), 1) + slot_k, return_inverse=True)
-        uniq_t = uniq_t[pair % max(len(uniq_t), 1)]               # the timestamp of every (group, t) slot
+        slot_group = pair // max(len(uniq_t), 1)                  # the group of every (group, t) slot
+        uniq_t = uniq_t[pair % max(len(uniq_t), 1)]               # ... and its timestamp
     Tb = len(uniq_t)
     hb.graph_t = uniq_t
 
@@ -627,12 +634,16 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None, 
 
     # node-induced edges of every member graph (utils.py:115-131)
     if Tb:
-        ls, lo, rr = _induced_edges(store, store.index_of(uniq_t), num_ent, keys, new_id, sparse=group is not None)
+        ls, lo, rr = _induced_edges(store, store.index_of(uniq_t), num_ent, keys, new_id,
+                                    sparse=(group is not None) if sparse is None else sparse)
     else:
         ls = lo = rr = np.zeros(0, np.int64)
     src = np.concatenate((ls, lo))
     dst = np.concatenate((lo, ls))
     et = np.concatenate((rr, rr + num_rels))                          # type_s (utils.py:76)
+    if reverse_group is not None and slot_group is not None and len(et):
+        rev = np.asarray(reverse_group, dtype=bool)[slot_group][np.asarray(hb.node_slot)[src]]
+        et = np.where(rev, (et + num_rels) % (2 * num_rels), et)      # type_o (utils.py:75), model.py:78
     E = len(src)
     hb.E = E
 
@@ -661,6 +672,42 @@ def build_batch(store, num_ent, num_rels, s, r, fh, sort=True, glob_index=None, 
     hb.plan_node_ent = SegPlan.host(hb.node_ent)
     hb.plan_subj_row = SegPlan.host(hb.subj_row)
     hb.plan_s = SegPlan.host(hb.s_sorted)
+    hb.plan_r = SegPlan.host(hb.r_sorted)
+    return hb
+
+
+def concat_histories(a, b):
+    """FlatHistory of the sequences of `a` followed by those of `b`."""
+    return FlatHistory(np.concatenate((a.seq_ptr, a.seq_ptr[-1] + b.seq_ptr[1:])),
+                       np.concatenate((a.step_t, b.step_t)),
+                       np.concatenate((a.nbr_ptr, a.nbr_ptr[-1] + b.nbr_ptr[1:])),
+                       np.concatenate((a.nbr_o, b.nbr_o)))
+
+
+def build_batch_both(store, num_ent, num_rels, s, r, o, fh_s, fh_o, glob_index=None):
+    """The subject pass and the object pass of ONE training step (train.py:136-138: model(..., subject=True) +
+    model(..., subject=False) over the same quadruples) as a single batch of 2B sequences: rows [0, B) are the
+    subject-side sequences (entity s, history s_hist, relation embedding r), rows [B, 2B) the object-side ones
+    (entity o, history o_hist, relation embedding R + r, model.py:70-78).  The two passes keep SEPARATE member
+    graphs per timestamp (group 0 / group 1: the node sets of utils.py:149-156 are per call), the object-side graphs
+    with type_o baked into their edge types, so every row of the merged batch sees exactly what its own pass would.
+    Extra fields: rel_label (the relation id without the R offset, for the relation head's labels, model.py:98)
+    and ent_label (o for subject-side rows, s for object-side rows), both in sorted order; is_obj per sorted row."""
+    s = np.asarray(s, dtype=np.int64).reshape(-1)
+    r = np.asarray(r, dtype=np.int64).reshape(-1)
+    o = np.asarray(o, dtype=np.int64).reshape(-1)
+    B = len(s)
+    group = np.concatenate((np.zeros(B, np.int64), np.ones(B, np.int64)))
+    hb = build_batch(store, num_ent, num_rels, np.concatenate((s, o)), np.concatenate((r, r)),
+                     concat_histories(fh_s, fh_o), sort=True, glob_index=glob_index, group=group,
+                     reverse_group=np.array([False, True]), sparse=False)
+    is_obj = group[hb.perm] == 1
+    hb.rel_label = hb.r_sorted.copy()
+    hb.ent_label = np.concatenate((o, s))[hb.perm].astype(np.int32)
+    hb.is_obj = is_obj
+    shift = np.where(is_obj, num_rels, 0).astype(np.int32)
+    hb.r_sorted = hb.r_sorted + shift                                 # rows of the FULL rel_embeds table [2R, H]
+    hb.row_rel = hb.row_rel + shift[hb.row_seq]
     hb.plan_r = SegPlan.host(hb.r_sorted)
     return hb
 

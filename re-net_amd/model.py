@@ -136,6 +136,8 @@ class RENet(nn.Module):
 
     def prepare_from_host(self, hbatch):
         """Device half of prepare(): one upload of the packed batch + the label vector."""
+        if hbatch.get('both'):
+            return self.prepare_both_from_host(hbatch)
         dev = self.ent_embeds.device
         prep = PreparedBatch()
         prep.subject, prep.b = hbatch['subject'], hbatch['b']
@@ -154,6 +156,60 @@ class RENet(nn.Module):
             prep.step_off = ops.host_offsets(g.host.step_off)
         prep.o_idx = torch.from_numpy(hbatch['o']).to(dev)
         return prep
+
+    def host_batch_both(self, triplets, s_hist, o_hist, graph_dict):
+        """Host half of BOTH passes of a training step as one merged batch (graph.build_batch_both); None when
+        either direction has no history at all (callers then fall back to the two separate passes)."""
+        trip = triplets.detach().cpu().numpy() if isinstance(triplets, torch.Tensor) else np.asarray(triplets)
+        fs = s_hist if isinstance(s_hist, G.FlatHistory) else G.FlatHistory.from_lists(s_hist[0], s_hist[1])
+        fo = o_hist if isinstance(o_hist, G.FlatHistory) else G.FlatHistory.from_lists(o_hist[0], o_hist[1])
+        if fs.seq_ptr[-1] == 0 or fo.seq_ptr[-1] == 0:
+            return None
+        table = self.aggregator.glob_table.get_host(self.global_emb)
+        hb = G.build_batch_both(G.store_for(graph_dict), self.in_dim, self.num_rels, trip[:, 0], trip[:, 1],
+                                trip[:, 2], fs, fo, glob_index=table.index)
+        if hb.L > self.seq_len:
+            raise ValueError('history longer than seq_len (%d > %d)' % (hb.L, self.seq_len))
+        return {'both': True, 'b': 2 * len(trip), 'pb': G.PackedBatch(hb)}
+
+    def prepare_both_from_host(self, hbatch):
+        dev = self.ent_embeds.device
+        prep = PreparedBatch()
+        prep.subject, prep.b = None, hbatch['b']
+        g = G.DeviceGraph(hbatch['pb'], dev)
+        g.glob = self.aggregator.glob_table.get(self.global_emb, self.h_dim, dev).mat
+        prep.g, prep.perm = g, g.host.perm
+        prep.s_idx, prep.r_idx, prep.plan_s, prep.plan_r = g.s_sorted, g.r_sorted, g.plan_s, g.plan_r
+        prep.o_idx, prep.r_label = g.ent_label, g.rel_label
+        prep.batch_sizes = torch.from_numpy(g.host.batch_sizes)
+        prep.step_off = ops.host_offsets(g.host.step_off)
+        return prep
+
+    def prepare_both(self, triplets, s_hist, o_hist, graph_dict):
+        """prepare() for the merged batch of both passes; None -> use prepare() twice."""
+        hbatch = self.host_batch_both(triplets, s_hist, o_hist, graph_dict)
+        return None if hbatch is None else self.prepare_both_from_host(hbatch)
+
+    def loss_prepared_both(self, prep):
+        """loss_prepared(prep_s) + loss_prepared(prep_o) evaluated as ONE pass over the 2B sequences of the merged
+        batch (extension of the reference API; train.py:136-138 adds the two losses of the same quadruples).  The
+        aggregator, both encoders and both heads are shared between the directions (model.py:26-40), the directions
+        differ only in which half of rel_embeds and which edge-type view they read (model.py:70-78) -- both baked
+        into the merged batch's indices -- so every kernel simply sees twice the rows: half the launches, GEMMs
+        with M (or K) doubled.  Each CE is a mean over its B rows: the sum of the two is 2 x the mean over 2B."""
+        g = prep.g
+        self.aggregator.last_batch = g
+        x, xr = self.aggregator.encode(g, self.ent_embeds, self.rel_embeds, reverse=False)
+        s_h, s_q = ops.dual_gru(x, xr, self.encoder, self.encoder_r, prep.step_off, prep.b)
+        s_h, s_q = s_h[0], s_q[0]
+        p = self.drop_p if self.training else 0.0
+        loss_sub = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_h, self.rel_embeds, prep.r_idx,
+                                      self.linear.weight, self.linear.bias, prep.o_idx, prep.plan_s,
+                                      prep.plan_r, p, ops.next_seed() if p > 0 else 0)
+        loss_r = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_q, None, None, self.linear_r.weight,
+                                    self.linear_r.bias, prep.r_label, prep.plan_s, None, p,
+                                    ops.next_seed() if p > 0 else 0)
+        return 2.0 * (loss_sub + 0.1 * loss_r)
 
     def prepare(self, triplets, hist, graph_dict, subject=True):
         """Host + upload half of one direction of a training step: batch graph, packed layout and plans,
@@ -221,7 +277,7 @@ class RENet(nn.Module):
 class PreparedBatch(object):
     """Device-resident inputs of one direction of one step (see RENet.prepare)."""
     __slots__ = ('g', 'subject', 'b', 'perm', 's_idx', 'r_idx', 'o_idx', 'plan_s', 'plan_r', 'batch_sizes',
-                 'step_off')
+                 'step_off', 'r_label')
 
 
 def _device_plan(idx, device):

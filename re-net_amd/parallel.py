@@ -98,6 +98,11 @@ class OverlapReducer(object):
         self.rest = [f[:self.lo], f[self.lo + self.n:]]
         self.stream = torch.cuda.Stream() if f.is_cuda else None
 
+    def set_uses(self, n):
+        """in-place accumulations that complete the early bucket per step: 2 for the subject + object passes,
+        1 when a step runs them as one merged pass (RENet.loss_prepared_both)"""
+        self.early_uses = n * len(self.early_ids)
+
     def active(self):
         # RENET_FORCE_REDUCER=1 runs the collectives even in a one-rank group (a no-op exchange): lets a one-GPU box
         # exercise the side-stream / RCCL call sequence

@@ -1,0 +1,100 @@
+"""The merged batch of both passes of a training step (graph.build_batch_both / RENet.loss_prepared_both) on CPU:
+host-side structure against two separate build_batch calls, and -- with the device wrappers emulated in torch-CPU
+(tests/cpu_abi_emulation.py) -- loss and every gradient against loss_prepared(subject) + loss_prepared(object)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import graph as G
+import preprocess as P
+import synth
+
+
+def _data(num_t=40, cap=600):
+    quads, num_ent, num_rels, _ = synth.make_stream('YAGO', seed=7, num_t=num_t)
+    quads = quads[(quads[:, 0] < cap) & (quads[:, 2] < cap)]
+    return quads, cap, num_rels
+
+
+def test_merged_batch_is_the_two_batches_side_by_side():
+    quads, num_ent, R = _data()
+    gd = P.build_graph_dict(quads, R)
+    store = G.store_for(gd)
+    hs, ho = P.HistoryIndex(quads, 's'), P.HistoryIndex(quads, 'o')
+    idx = np.random.RandomState(1).permutation(len(quads))[:200]
+    b = quads[idx]
+    s, r, o = b[:, 0], b[:, 1], b[:, 2]
+    hb_s = G.build_batch(store, num_ent, R, s, r, hs.take(idx))
+    hb_o = G.build_batch(store, num_ent, R, o, r, ho.take(idx))
+    hb = G.build_batch_both(store, num_ent, R, s, r, o, hs.take(idx), ho.take(idx))
+    B = len(b)
+    assert hb.B == 2 * B and hb.N == hb_s.N + hb_o.N and hb.E == hb_s.E + hb_o.E
+    assert hb.nA == hb_s.nA + hb_o.nA and hb.S == hb_s.S + hb_o.S and hb.nnz == hb_s.nnz + hb_o.nnz
+    is_obj = hb.perm >= B
+    assert np.array_equal(hb.is_obj, is_obj)
+    # sorted rows: entity, relation-embedding row, labels
+    assert np.array_equal(hb.s_sorted, np.concatenate((s, o))[hb.perm])
+    assert np.array_equal(hb.rel_label, np.concatenate((r, r))[hb.perm])
+    assert np.array_equal(hb.r_sorted, hb.rel_label + R * is_obj)
+    assert np.array_equal(hb.ent_label, np.concatenate((o, s))[hb.perm])
+    assert np.array_equal(hb.row_rel, hb.r_sorted[hb.row_seq])
+    # the stable length sort keeps each direction's own order: the merged permutation restricted to one
+    # direction is that direction's permutation
+    assert np.array_equal(hb.perm[~is_obj], hb_s.perm) and np.array_equal(hb.perm[is_obj] - B, hb_o.perm)
+
+    # edges as (entity of src, entity of dst, timestamp, type) multisets per direction: the object side holds
+    # type_o = (type_s + R) mod 2R of its own pass's edges (model.py:78), the subject side type_s
+    col, rp, et = np.asarray(hb.col), np.asarray(hb.row_ptr), np.asarray(hb.etype)
+    dst = np.repeat(np.arange(hb.N), np.diff(rp))
+    t_of = np.asarray(hb.graph_t)[np.asarray(hb.node_slot)]
+    grp = (np.asarray(hb.node_slot) >= len(hb_s.graph_t)).astype(np.int64)      # slots are group-major
+    assert np.all(grp[col] == grp[dst])
+    for gsel, ref, shift in ((0, hb_s, 0), (1, hb_o, R)):
+        m = grp[dst] == gsel
+        got = np.stack((hb.node_ent[col[m]], hb.node_ent[dst[m]], t_of[dst[m]], et[m]), axis=1)
+        rcol, rrp, ret = np.asarray(ref.col), np.asarray(ref.row_ptr), np.asarray(ref.etype)
+        rdst = np.repeat(np.arange(ref.N), np.diff(rrp))
+        rt = np.asarray(ref.graph_t)[np.asarray(ref.node_slot)]
+        want = np.stack((ref.node_ent[rcol], ref.node_ent[rdst], rt[rdst], (ret + shift) % (2 * R)), axis=1)
+        assert np.array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])
+
+
+def test_merged_pass_equals_the_two_passes():
+    import cpu_abi_emulation
+    undo = cpu_abi_emulation.install()
+    try:
+        import model as M
+        import parallel
+        quads, num_ent, R = _data()
+        gd = P.build_graph_dict(quads, R)
+        hs, ho = P.HistoryIndex(quads, 's'), P.HistoryIndex(quads, 'o')
+        torch.manual_seed(21)
+        net = M.RENet(num_ent, 100, R, dropout=0.0, seq_len=10)
+        gen = torch.Generator().manual_seed(2)
+        net.global_emb = {int(t): torch.randn(1, 1, 100, generator=gen) * 0.1 for t in gd}
+        net.eval()
+        idx = np.random.RandomState(4).permutation(len(quads))[:160]
+        b = quads[idx]
+        flat = parallel.FlatGrads(net)
+        ps = net.prepare(b, hs.take(idx), gd, subject=True)
+        po = net.prepare(b, ho.take(idx), gd, subject=False)
+        l1 = net.loss_prepared(ps) + net.loss_prepared(po)
+        l1.backward()
+        g1 = flat.flat.clone()
+        flat.zero()
+        pb = net.prepare_both(b, hs.take(idx), ho.take(idx), gd)
+        assert pb.b == 2 * len(b) and pb.g.N == ps.g.N + po.g.N
+        l2 = net.loss_prepared_both(pb)
+        l2.backward()
+        assert abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l1))
+        scale = float(g1.abs().max())
+        assert float((g1 - flat.flat).abs().max()) <= 2e-6 * scale
+        # a direction without any history: callers fall back to the two separate passes
+        first = np.arange(len(quads))[quads[:, 3] == quads[:, 3].min()][:8]
+        assert net.prepare_both(quads[first], hs.take(first), ho.take(first), gd) is None
+    finally:
+        undo()

@@ -109,6 +109,54 @@ def test_training_step_at_config_scale_matches_reference_and_oracle(dev, name):
         assert err <= 2e-3 * scale + 1e-9, ('oracle', k, err, scale)
 
 
+@pytest.mark.parametrize('name', CASE_NAMES)
+def test_merged_pass_at_config_scale_matches_reference(dev, name):
+    """RENet.loss_prepared_both (both passes of the step as ONE batch of 2B sequences, the path bench.py times)
+    against the unmodified reference's loss_s + loss_o, its h_n / q_n / entity logits per direction and every
+    parameter gradient."""
+    import model as M
+    import ops
+    import preprocess as P
+    gold = load_golden('config_%s.npz' % name)
+    case = C.build_case(name, gold=gold)
+    spec, quads, idx = case['spec'], case['quads'], case['idx']
+    B, L = spec['batch'], spec['seq_len']
+    fs = P.HistoryIndex(quads, 's', history_len=L).take(idx)
+    fo = P.HistoryIndex(quads, 'o', history_len=L).take(idx)
+    net = M.RENet(case['num_ent'], spec['hidden'], case['num_rels'], dropout=0.0, seq_len=L)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in case['params'].items()})
+    net.global_emb = {t: torch.from_numpy(v).view(1, 1, -1) for t, v in case['global_emb'].items()}
+    net.to(dev)
+    net.eval()
+    gd = P.build_graph_dict(quads, case['num_rels'])
+    prep = net.prepare_both(case['batch'], fs, fo, gd)
+    assert prep is not None and prep.b == 2 * B
+    taps = []
+    ops.debug_tap = lambda n, t: taps.append((n, t.detach().clone()))
+    try:
+        loss = net.loss_prepared_both(prep)
+    finally:
+        ops.debug_tap = None
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = float(gold['loss_s']) + float(gold['loss_o'])
+    assert abs(loss.item() - ref) < 1e-4 * abs(ref), (loss.item(), ref)
+    names = [n for n, _ in taps]
+    assert names == ['h_n', 'q_n', 'logits', 'logits'], names
+    perm = np.asarray(prep.perm)                                # sorted row -> position in [subject rows | object rows]
+    for key, t in (('h_n', taps[0][1]), ('q_n', taps[1][1]), ('logits', taps[2][1])):
+        a = t.cpu().numpy()
+        full = np.zeros_like(a)
+        full[perm] = a
+        for tag, half in (('s', full[:B]), ('o', full[B:])):
+            ok, err, scale = C.compare_packed(gold, '%s_%s' % (tag, key), half, rel=5e-4)
+            assert ok, (tag, key, err, scale)
+    for k, p in net.named_parameters():
+        g = p.grad.cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+        ok, err, scale = C.compare_packed(gold, 'grad.' + k, g, rel=2e-3)
+        assert ok, ('reference', k, err, scale)
+
+
 def test_zero_grad_set_to_none_between_forward_and_backward(dev):
     """`loss = model(..); opt.zero_grad(set_to_none=True); loss.backward()` (the torch >= 2 default
     order of many loops) must produce the same gradients as the reference order -- the kernels resolve their
