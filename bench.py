@@ -275,15 +275,15 @@ def main():
             roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': ach / HBM_PEAK_GBS, 'traffic': traffic_of(dom)}
     # the north-star kernel: one entry per launch class of the step (distinct kernel names in a rocprof trace).
-    # `achieved` uses SURVEY 8d's bytes incl. the fused self-loop addend row; `frac_strict` drops that re-read.
+    # `achieved` uses SURVEY 8d's bytes incl. the fused self-loop addend row where the launch has one (the forward
+    # launches; the backward launches run without an addend); `frac_strict` never counts it.
     gather = {}
     d = args.hidden
     for name in ('rgcn_gather_fwd_full', 'rgcn_gather_bwdh_full', 'rgcn_gather_fwd_pruned', 'rgcn_gather_bwdh_pruned'):
         if name in stats:
             st = stats[name]
             ach = st['bytes'] / (st['ms'] * 1e-3) / 1e9
-            rows = g0.N if (name.endswith('full') or 'bwdh' in name) else g0.nA
-            strict = (st['bytes'] - st['calls'] * rows * d * 4) / (st['ms'] * 1e-3) / 1e9
+            strict = sum(t * o['calls'] for t, o in timer.by_tag(name).items()) / (st['ms'] * 1e-3) / 1e9
             gather[name] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                             'frac': ach / HBM_PEAK_GBS, 'frac_strict': strict / HBM_PEAK_GBS,
                             'traffic': traffic_of(name), 'avg_us': st['ms'] * 1e3 / st['calls'],

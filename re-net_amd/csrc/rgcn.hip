@@ -579,6 +579,16 @@ int gather_unr() {
 }
 
 // ---- backward prologue ----------------------------------------------------------------------
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float4* p, float4 v) {
+    nt_f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(p));
+}
+
 __global__ __launch_bounds__(256) void rgcn_bwd_prep_kernel(const float4* __restrict__ g_out,
                                                             const float4* __restrict__ out,
                                                             const float* __restrict__ norm, int relu,
@@ -589,14 +599,16 @@ __global__ __launch_bounds__(256) void rgcn_bwd_prep_kernel(const float4* __rest
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const int v = (int)(i / CH);
-        float4 g = g_out[i];
+        // streaming operands (read once / consumed by matrix-bound GEMMs) bypass the caches: what should still be
+        // cache resident when this kernel ends is gn, which the bandwidth-bound gather reads next
+        float4 g = nt_load4(g_out + i);
         if (relu) {
-            const float4 o = out[i];
+            const float4 o = nt_load4(out + i);
             g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f;
             g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
         }
         gn[i] = f4_scale(g, norm[v]);
-        g_loop[i] = f4_mul(g, renet_drop4(drop, i));
+        nt_store4(g_loop + i, f4_mul(g, renet_drop4(drop, i)));
     }
 }
 

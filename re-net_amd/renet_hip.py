@@ -283,7 +283,8 @@ def rgcn_gather_items(x, g, weight, type_shift, transpose_w, addend, drop_p, see
     if t0 is not None:
         e = g.E_out if pruned else g.E
         name = 'rgcn_gather_%s_%s' % ('bwdh' if transpose_w else 'fwd', 'pruned' if pruned else 'full')
-        _timer.end(name, t0, nbytes=float(gather_bytes(e, n_rows, d, weight.numel(), addend is not None)))
+        _timer.end(name, t0, nbytes=float(gather_bytes(e, n_rows, d, weight.numel(), addend is not None)),
+                   tag=float(gather_bytes(e, n_rows, d, weight.numel(), False)))       # tag: the strict bytes
     return out
 
 

@@ -2,7 +2,7 @@
 """Micro-benchmark of the RGCN gather-SpMM (RGCN.py:79-94) on the bench workload's batch graph (ICEWS18-shaped,
 seed 999, B = 1024, D = 200) and at the global model's scale (all 240 full graphs), GPU only.
 
-    python tools/gather_bench.py [batch|global|sweep] [--json out.json]
+    python tools/gather_bench.py [batch|both|global|sweep|sweep_both] [--json out.json]
 
 For every variant: forward over the full graph (fused norm + self-loop addend + ReLU), backward-wrt-h (transposed
 blocks, in-place addend), the pruned forward (subject-row prefix) and the pruned backward -- the four launch classes
@@ -39,6 +39,10 @@ def workload(kind):
     hs = P.HistoryIndex(quads, 's', 10)
     idx = np.random.RandomState(999).permutation(len(quads))[3 * 1024:4 * 1024]      # bench.py's first timed batch
     store = G.store_for(gd)
+    if kind == 'both':       # the merged batch of both passes (bench.py --passes merged, the default)
+        ho = P.HistoryIndex(quads, 'o', 10)
+        return lambda: G.build_batch_both(store, ne, nr, quads[idx, 0], quads[idx, 1], quads[idx, 2], hs.take(idx),
+                                          ho.take(idx)), nr
     return lambda: G.build_batch(store, ne, nr, quads[idx, 0], quads[idx, 1], hs.take(idx), sort=True), nr
 
 
@@ -120,18 +124,19 @@ def main():
     out_json = sys.argv[sys.argv.index('--json') + 1] if '--json' in sys.argv else None
     dev = torch.device('cuda:0')
     results = []
-    if mode in ('batch', 'global'):
+    if mode in ('batch', 'global', 'both'):
         build, nr = workload(mode)
         results.append(bench_graph(build(), nr, dev, label=mode))
-    elif mode == 'sweep':
-        build, nr = workload('batch')
+    elif mode in ('sweep', 'sweep_both'):
+        kind = 'both' if mode == 'sweep_both' else 'batch'
+        build, nr = workload(kind)
         for heavy, budget in ((4, 8), (6, 12), (8, 8), (8, 12), (8, 16), (8, 24), (12, 16), (16, 24), (24, 32)):
             G.HEAVY, G.GROUP_ITEMS = heavy, budget
             results.append(bench_graph(build(), nr, dev, legacy=(heavy == 8 and budget == 16),
                                        label='h%d_b%d' % (heavy, budget)))
         if 'RENET_GATHER_UNR' not in os.environ:
             for unr in ('2', '3', '4', '6', '8'):
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), 'unr_child'],
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), 'unr_child_' + kind],
                                    env=dict(os.environ, RENET_GATHER_UNR=unr), capture_output=True, text=True)
                 sys.stdout.write(r.stdout)
                 if r.returncode != 0:
@@ -139,8 +144,8 @@ def main():
                 for line in r.stdout.splitlines():
                     if line.startswith('JSON '):
                         results.append(json.loads(line[5:]))
-    elif mode == 'unr_child':
-        build, nr = workload('batch')
+    elif mode.startswith('unr_child'):
+        build, nr = workload(mode.split('_')[-1] if mode.count('_') > 1 else 'batch')
         r = bench_graph(build(), nr, dev, legacy=False, label='unr' + os.environ.get('RENET_GATHER_UNR', '?'))
         print('JSON ' + json.dumps(r))
         return
