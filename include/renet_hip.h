@@ -215,9 +215,11 @@ int renet_seq_assemble_bwd(const float* dX, const float* dXr, const int32_t* ste
  *   saved   [S, 5H]  per packed row: r, z, n, (W_hn h + b_hn), h_prev   (consumed by backward)
  * Backward: given dh_last[B,H] produces dGi[S,3H], dGh[S,3H] (caller forms dW_ih, dW_hh, biases,
  * dX with renet_gemm_f32 / renet_colsum).
- * `workspace` = renet_gru_workspace(B, H) bytes per GRU, for both directions: the bf16 planes of W_hh
- * (forward) / W_hh^T and its planes (backward) -- the recurrent products run as "bf16x6" like
- * renet_gemm_f32_split unless RENET_GEMM=f32 selects the exact-fp32 MFMA kernels.
+ * `workspace` = renet_gru_workspace(B, H) bytes per GRU (B = the largest first-step batch size of the
+ * GRUs of the call), for both directions: the bf16 planes of W_hh (forward) / W_hh^T and its planes
+ * (backward), then the state that travels between the per-step launches (bf16 planes of h / dGh, ping-pong,
+ * and the fp32 dh) -- the recurrent products run as "bf16x6" like renet_gemm_f32_split unless RENET_GEMM=f32
+ * selects the exact-fp32 MFMA kernels (one persistent launch, no per-step state: B may then be 0).
  * ---------------------------------------------------------------------------------------------- */
 size_t renet_gru_workspace(int B, int H);
 int renet_gru_fwd(const float* Gi, const int32_t* step_off, int L, int H, const float* Whh,

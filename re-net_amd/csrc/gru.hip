@@ -525,6 +525,313 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Step kernels (the default bf16x6 path): ONE launch per time step, GEMM-shaped tiles.
+//
+// The persistent kernels above give a workgroup 16 sequences and ALL hidden units, so every workgroup re-streams
+// the whole of W_hh (0.8 MB of planes at H = 200, 3 MB at H = 400) from L2 every step: 213 MB of L2 -> L1 traffic per
+// step at H = 200 with 256 workgroups, and the 64 B/clk L1 fill rate of a CU -- not the matrix pipe -- bounds the step
+// (PMC: r02 DESIGN 4).  Here a workgroup owns 64 sequences x 64 hidden units (4 waves, one block of 16 units each,
+// 4 MFMA row tiles per wave): a W fragment is used for 4 row tiles, the A operand (bf16 planes of h, or of dGh in the
+// backward pass) is staged through LDS in double-buffered chunks of 128 k and shared by the 4 waves, and the state
+// travels between steps through L2 (fp32 h / dh in place, bf16 planes ping-pong) -- the kernel boundary is the
+// grid-wide barrier the step needs.  W traffic per step drops 4x (16x per sequence tile), the step becomes
+// matrix-pipe / epilogue-traffic bound, and later steps launch only the row tiles that are still alive.
+// The epilogue is the gate math on the MFMA C layout exactly as above; backward launch j forms dh(j-1) and, in the
+// same epilogue, the gate gradients of step j-1 (they need dh(j-1) at the lane's own (sequence, unit) pairs only).
+// ---------------------------------------------------------------------------------------------
+constexpr int SR = 64;                          // sequences per workgroup: 4 MFMA row tiles
+constexpr int SRT = SR / 16;
+constexpr int SW = 4;                           // waves per workgroup, one block of 16 hidden units each
+constexpr int SNT = SW * 64;
+constexpr int CKG = 4;                          // k groups (32 k each) per LDS chunk
+constexpr int CK = CKG * 32;
+constexpr int LDC = CK + 8;                     // bf16 row stride of a chunk in LDS (ds_read_b128 conflict free)
+constexpr int CHUNK_ELEMS = 3 * SR * LDC;       // one chunk buffer: three planes
+constexpr int STAGE_V = 3 * SR * (CK / 8) / SNT;        // 16-byte vectors per thread and chunk (12)
+constexpr size_t STEP_LDS = (size_t)2 * CHUNK_ELEMS * sizeof(__bf16);
+
+struct StageRegs { uint4 v[STAGE_V]; };
+
+// A operand in global memory: [3][rows_pad][KPg] bf16 planes, rows_pad a multiple of SR, k padding zero
+template <int KPg>
+__device__ __forceinline__ void stage_load(const __bf16* __restrict__ A, size_t plane_stride, int r0, int kbase, int tid,
+                                           StageRegs& s) {
+#pragma unroll
+    for (int q = 0; q < STAGE_V; ++q) {
+        const int idx = tid + SNT * q;
+        const int plane = idx / (SR * (CK / 8));
+        const int rem = idx - plane * (SR * (CK / 8));
+        const int row = rem / (CK / 8), seg = rem - row * (CK / 8);
+        const int k = kbase + seg * 8;
+        const uint4 v = *reinterpret_cast<const uint4*>(A + plane * plane_stride + (size_t)(r0 + row) * KPg + (k < KPg ? k : 0));
+        s.v[q] = k < KPg ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+__device__ __forceinline__ void stage_store(__bf16* __restrict__ buf, int tid, const StageRegs& s) {
+#pragma unroll
+    for (int q = 0; q < STAGE_V; ++q) {
+        const int idx = tid + SNT * q;
+        const int plane = idx / (SR * (CK / 8));
+        const int rem = idx - plane * (SR * (CK / 8));
+        const int row = rem / (CK / 8), seg = rem - row * (CK / 8);
+        *reinterpret_cast<uint4*>(buf + plane * (SR * LDC) + row * LDC + seg * 8) = s.v[q];
+    }
+}
+
+// LDS-only barrier: the global loads that prefetch the next chunk / the next W fragments stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+struct StepF {
+    const float* Gi; const bf16x8* Wp; const float* bhh; float* h; float* saved;
+    const __bf16* Ain; __bf16* Aout;
+    int p0, bs;                         // packed row of sequence 0 at this step, sequences alive at this step
+    size_t plane_stride;
+};
+struct StepsF { StepF p[MAXP]; };
+
+template <int H, bool GEMM>
+__global__ __launch_bounds__(SNT) void gru_step_fwd_kernel(StepsF ps) {
+    using C = Cfg<H>;
+    using Bc = BCfg<H>;
+    const StepF& P = ps.p[blockIdx.z];
+    const int r0 = blockIdx.x * SR;
+    if (r0 >= P.bs) return;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* bufs = reinterpret_cast<__bf16*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ub = blockIdx.y * SW + wave;
+    const bool wave_on = ub < C::NUB;                                   // wave-uniform
+    const int jj = lane & 15, kq = lane >> 4, ai = lane & 15;
+    const int u = ub * 16 + jj;
+    const bool uok = wave_on && u < H;
+    const int uc = uok ? u : 0;
+    const int bs = P.bs;
+
+    // operands of the epilogue, requested before the matrix work (unconditional loads from clamped rows)
+    float gr[SRT][4], gz[SRT][4], gn[SRT][4], hp[SRT][4];
+#pragma unroll
+    for (int t = 0; t < SRT; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = min(r0 + 16 * t + 4 * kq + reg, bs - 1);
+            const float* gi = P.Gi + (size_t)(P.p0 + row) * C::K3 + uc;
+            gr[t][reg] = gi[0]; gz[t][reg] = gi[H]; gn[t][reg] = gi[2 * H];
+            hp[t][reg] = GEMM ? P.h[(size_t)row * H + uc] : 0.f;
+        }
+    const float b_r = P.bhh[uc], b_z = P.bhh[H + uc], b_n = P.bhh[2 * H + uc];
+
+    f32x4 ar[SRT], az[SRT], an[SRT];
+#pragma unroll
+    for (int t = 0; t < SRT; ++t) { ar[t] = {0.f, 0.f, 0.f, 0.f}; az[t] = ar[t]; an[t] = ar[t]; }
+
+    if constexpr (GEMM) {
+        constexpr int NC = (Bc::KG + CKG - 1) / CKG;
+        const bf16x8* wf = P.Wp + (size_t)(wave_on ? ub : 0) * Bc::KG * 9 * 64 + lane;      // fragment order
+        bf16x8 wcur[3][3], wnext[3][3];                                   // [gate][plane]
+#pragma unroll
+        for (int f = 0; f < 9; ++f) wcur[f / 3][f % 3] = wf[f * 64];
+        StageRegs sr;
+        stage_load<Bc::KP>(P.Ain, P.plane_stride, r0, 0, tid, sr);
+        stage_store(bufs, tid, sr);
+        if (NC > 1) stage_load<Bc::KP>(P.Ain, P.plane_stride, r0, CK, tid, sr);
+        lds_barrier();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const __bf16* cur = bufs + (c & 1) * CHUNK_ELEMS;
+            if (c + 1 < NC) {
+                stage_store(bufs + ((c + 1) & 1) * CHUNK_ELEMS, tid, sr);
+                if (c + 2 < NC) stage_load<Bc::KP>(P.Ain, P.plane_stride, r0, (c + 2) * CK, tid, sr);
+            }
+            if (wave_on) {
+                const __bf16* ha = cur + ai * LDC + kq * 8;
+#pragma unroll
+                for (int kk = 0; kk < CKG; ++kk) {
+                    const int kg = c * CKG + kk;
+                    if (kg < Bc::KG) {
+                        if (kg + 1 < Bc::KG) {
+#pragma unroll
+                            for (int f = 0; f < 9; ++f) wnext[f / 3][f % 3] = wf[((kg + 1) * 9 + f) * 64];
+                        }
+#pragma unroll
+                        for (int t = 0; t < SRT; ++t) {
+                            bf16x8 a[3];
+#pragma unroll
+                            for (int p = 0; p < 3; ++p)
+                                a[p] = *reinterpret_cast<const bf16x8*>(ha + p * (SR * LDC) + t * 16 * LDC + kk * 32);
+                            ar[t] = mfma6(a, wcur[0], ar[t]);
+                            az[t] = mfma6(a, wcur[1], az[t]);
+                            an[t] = mfma6(a, wcur[2], an[t]);
+                        }
+                        if (kg + 1 < Bc::KG) {
+#pragma unroll
+                            for (int f = 0; f < 9; ++f) wcur[f / 3][f % 3] = wnext[f / 3][f % 3];
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+        }
+    }
+
+    if (uok) {
+        // C layout: column = lane & 15 (unit u), row = 4 * (lane >> 4) + reg (sequence of the row tile)
+#pragma unroll
+        for (int t = 0; t < SRT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = r0 + 16 * t + 4 * kq + reg;
+                if (row < bs) {
+                    const size_t p = (size_t)(P.p0 + row);
+                    const float hn = an[t][reg] + b_n;
+                    const float r = sigmoidf_(gr[t][reg] + ar[t][reg] + b_r);
+                    const float z = sigmoidf_(gz[t][reg] + az[t][reg] + b_z);
+                    const float n = tanhf(gn[t][reg] + r * hn);
+                    const float hpv = hp[t][reg];
+                    const float hv = (1.f - z) * n + z * hpv;
+                    float* sv = P.saved + p * 5 * H;
+                    sv[u] = r; sv[H + u] = z; sv[2 * H + u] = n; sv[3 * H + u] = hn; sv[4 * H + u] = hpv;
+                    P.h[(size_t)row * H + u] = hv;
+                    const Planes3 sp = split3(hv);
+                    __bf16* dst = P.Aout + (size_t)row * Bc::KP + u;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) dst[pl * P.plane_stride] = sp.p[pl];
+                }
+            }
+    }
+}
+
+struct StepB {
+    const float* saved; const bf16x8* WTp; float* dh; float* dGi; float* dGh;
+    const __bf16* Ain; __bf16* Aout;
+    int bs_cur;                         // sequences alive at the step whose dGh is contracted (0: none)
+    int p0_prev, bs_prev;               // packed row 0 / sequences alive at the step whose gate gradients are formed
+    size_t plane_stride;
+};
+struct StepsB { StepB p[MAXP]; };
+
+// launch for step j:  dh(j-1) = dh(j) z(j) [already in dh] + dGh(j) W_hh  for the sequences alive at step j, then the
+// gate gradients of step j-1 for the sequences alive at step j-1 (a superset: sequences whose last step is j-1 enter
+// with dh = dh_last).  GEMM = false is the first launch (step L-1's gate gradients from dh_last alone).
+template <int H, bool GEMM>
+__global__ __launch_bounds__(SNT) void gru_step_bwd_kernel(StepsB ps) {
+    using C = Cfg<H>;
+    using Bc = BCfg<H>;
+    const StepB& P = ps.p[blockIdx.z];
+    const int r0 = blockIdx.x * SR;
+    if (r0 >= P.bs_prev) return;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* bufs = reinterpret_cast<__bf16*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ub = blockIdx.y * SW + wave;
+    const bool wave_on = ub < C::NUB;
+    const int jj = lane & 15, kq = lane >> 4, ai = lane & 15;
+    const int u = ub * 16 + jj;
+    const bool uok = wave_on && u < H;
+    const int uc = uok ? u : 0;
+    const int bsp = P.bs_prev;
+
+    float sv_r[SRT][4], sv_z[SRT][4], sv_n[SRT][4], sv_hn[SRT][4], sv_hp[SRT][4], gin[SRT][4];
+#pragma unroll
+    for (int t = 0; t < SRT; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = min(r0 + 16 * t + 4 * kq + reg, bsp - 1);
+            const float* sv = P.saved + (size_t)(P.p0_prev + row) * 5 * H + uc;
+            sv_r[t][reg] = sv[0]; sv_z[t][reg] = sv[H]; sv_n[t][reg] = sv[2 * H]; sv_hn[t][reg] = sv[3 * H];
+            sv_hp[t][reg] = sv[4 * H];
+            gin[t][reg] = P.dh[(size_t)row * H + uc];
+        }
+
+    f32x4 acc[SRT];
+#pragma unroll
+    for (int t = 0; t < SRT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+
+    if (GEMM && r0 < P.bs_cur) {                                        // workgroup-uniform
+        constexpr int NC = (Bc::KG3 + CKG - 1) / CKG;
+        const bf16x8* wf = P.WTp + (size_t)(wave_on ? ub : 0) * Bc::KG3 * 3 * 64 + lane;
+        bf16x8 wcur[3], wnext[3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) wcur[f] = wf[f * 64];
+        StageRegs sr;
+        stage_load<Bc::KP3>(P.Ain, P.plane_stride, r0, 0, tid, sr);
+        stage_store(bufs, tid, sr);
+        if (NC > 1) stage_load<Bc::KP3>(P.Ain, P.plane_stride, r0, CK, tid, sr);
+        lds_barrier();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const __bf16* cur = bufs + (c & 1) * CHUNK_ELEMS;
+            if (c + 1 < NC) {
+                stage_store(bufs + ((c + 1) & 1) * CHUNK_ELEMS, tid, sr);
+                if (c + 2 < NC) stage_load<Bc::KP3>(P.Ain, P.plane_stride, r0, (c + 2) * CK, tid, sr);
+            }
+            if (wave_on) {
+                const __bf16* ga = cur + ai * LDC + kq * 8;
+#pragma unroll
+                for (int kk = 0; kk < CKG; ++kk) {
+                    const int kg = c * CKG + kk;
+                    if (kg < Bc::KG3) {
+                        if (kg + 1 < Bc::KG3) {
+#pragma unroll
+                            for (int f = 0; f < 3; ++f) wnext[f] = wf[((kg + 1) * 3 + f) * 64];
+                        }
+#pragma unroll
+                        for (int t = 0; t < SRT; ++t) {
+                            bf16x8 a[3];
+#pragma unroll
+                            for (int p = 0; p < 3; ++p)
+                                a[p] = *reinterpret_cast<const bf16x8*>(ga + p * (SR * LDC) + t * 16 * LDC + kk * 32);
+                            acc[t] = mfma6(a, wcur, acc[t]);
+                        }
+                        if (kg + 1 < Bc::KG3) {
+#pragma unroll
+                            for (int f = 0; f < 3; ++f) wcur[f] = wnext[f];
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+        }
+    }
+
+    if (uok) {
+#pragma unroll
+        for (int t = 0; t < SRT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = r0 + 16 * t + 4 * kq + reg;
+                if (row < bsp) {
+                    const size_t p = (size_t)(P.p0_prev + row);
+                    const float r = sv_r[t][reg], z = sv_z[t][reg], n = sv_n[t][reg], hn = sv_hn[t][reg];
+                    const float hpv = sv_hp[t][reg];
+                    const float g = gin[t][reg] + ((GEMM && row < P.bs_cur) ? acc[t][reg] : 0.f);
+                    const float dan = g * (1.f - z) * (1.f - n * n);
+                    const float daz = g * (hpv - n) * z * (1.f - z);
+                    const float dar = dan * hn * r * (1.f - r);
+                    float* gi = P.dGi + p * C::K3;
+                    float* gh = P.dGh + p * C::K3;
+                    gi[u] = dar; gi[H + u] = daz; gi[2 * H + u] = dan;
+                    gh[u] = dar; gh[H + u] = daz; gh[2 * H + u] = dan * r;
+                    P.dh[(size_t)row * H + u] = g * z;                  // direct path h_prev -> h
+                    const Planes3 s0 = split3(dar), s1 = split3(daz), s2 = split3(dan * r);
+                    __bf16* dst = P.Aout + (size_t)row * Bc::KP3 + u;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        dst[pl * P.plane_stride] = s0.p[pl];
+                        dst[pl * P.plane_stride + H] = s1.p[pl];
+                        dst[pl * P.plane_stride + 2 * H] = s2.p[pl];
+                    }
+                }
+            }
+    }
+}
+
 // W_hh [3H, H] -> W_hh^T [H, 3H]  (tiny; once per backward call)
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int rows, int cols,
                                                         float* __restrict__ out) {
@@ -602,6 +909,107 @@ int launch_bwd_bf(const BwdProbsB& ps, int np, const Layouts& ly, hipStream_t st
     return RENET_OK;
 }
 
+// ---- step-kernel launch sequences ---------------------------------------------------------------
+inline int rows_pad_of(int rows) { return (rows + SR - 1) / SR * SR; }
+inline size_t kp_of(int K) { return (size_t)((K + 31) / 32) * 32; }
+
+// Which bf16x6 recurrence runs.  Measured on MI355X (merged step, 2 x 2048 sequences; profiles/r02_gru_steps.md):
+//   H = 200: persistent 189 / 167 us (fwd / bwd) per launch;  step kernels 10 x 20.8 / 10 x 28.3 us
+//   H = 400, L = 15: persistent 858 us average;                step kernels 814 us
+// The step kernels cut the W_hh stream 4x, but a launch whose workgroups all load, multiply and store in lockstep
+// leaves the memory system idle during the MFMA phase and the matrix pipe idle during the epilogue (the epilogue
+// alone -- Gi in, saved / h / planes out, 46 B per element and step -- is 12.6 us of a 20.8 us forward step),
+// while the persistent workgroups drift apart and overlap the two.  Default: persistent at H <= 200, step kernels at
+// H = 400 (where the 3 MB W_hh stream per workgroup and step dominates); RENET_GRU=steps|persistent forces one.
+bool use_persistent(int H) {
+    const char* e = getenv("RENET_GRU");
+    if (e && strcmp(e, "persistent") == 0) return true;
+    if (e && strcmp(e, "steps") == 0) return false;
+    return H < 400;
+}
+
+struct StepState {                      // per problem: bf16 plane ping-pong of the A operand + fp32 dh
+    __bf16* A[2];
+    float* dh;
+    size_t plane_stride;                // elements between two planes of one buffer
+};
+
+template <int H>
+int run_steps_fwd(int n, const Layouts& ly, const StepF* base, const StepState* stt, hipStream_t st) {
+    using C = Cfg<H>;
+    static bool a0 = false, a1 = false;
+    int e = set_lds(gru_step_fwd_kernel<H, false>, STEP_LDS, a0);
+    if (e != RENET_OK) return e;
+    e = set_lds(gru_step_fwd_kernel<H, true>, STEP_LDS, a1);
+    if (e != RENET_OK) return e;
+    int maxL = 0;
+    for (int k = 0; k < n; ++k) maxL = ly.L[ly.lay_of[k]] > maxL ? ly.L[ly.lay_of[k]] : maxL;
+    for (int j = 0; j < maxL; ++j) {
+        StepsF ps;
+        int maxbs = 0;
+        for (int i = 0; i < MAXP; ++i) {
+            const int k = i < n ? i : 0;
+            const int lay = ly.lay_of[k];
+            ps.p[i] = base[k];
+            ps.p[i].p0 = 0; ps.p[i].bs = 0;
+            if (i < n && j < ly.L[lay]) {
+                ps.p[i].p0 = ly.so[lay].off[j];
+                ps.p[i].bs = ly.so[lay].off[j + 1] - ly.so[lay].off[j];
+            }
+            ps.p[i].Aout = stt[k].A[j & 1];
+            ps.p[i].Ain = stt[k].A[(j + 1) & 1];
+            ps.p[i].plane_stride = stt[k].plane_stride;
+            maxbs = ps.p[i].bs > maxbs ? ps.p[i].bs : maxbs;
+        }
+        if (maxbs == 0) continue;
+        const dim3 grid((maxbs + SR - 1) / SR, (C::NUB + SW - 1) / SW, n);
+        if (j == 0) RENET_LAUNCH((gru_step_fwd_kernel<H, false>), grid, dim3(SNT), STEP_LDS, st, ps);
+        else RENET_LAUNCH((gru_step_fwd_kernel<H, true>), grid, dim3(SNT), STEP_LDS, st, ps);
+        RENET_LAUNCH_CHECK();
+    }
+    return RENET_OK;
+}
+
+template <int H>
+int run_steps_bwd(int n, const Layouts& ly, const StepB* base, const StepState* stt, hipStream_t st) {
+    using C = Cfg<H>;
+    static bool a0 = false, a1 = false;
+    int e = set_lds(gru_step_bwd_kernel<H, false>, STEP_LDS, a0);
+    if (e != RENET_OK) return e;
+    e = set_lds(gru_step_bwd_kernel<H, true>, STEP_LDS, a1);
+    if (e != RENET_OK) return e;
+    int maxL = 0;
+    for (int k = 0; k < n; ++k) maxL = ly.L[ly.lay_of[k]] > maxL ? ly.L[ly.lay_of[k]] : maxL;
+    for (int s = 0; s < maxL; ++s) {                 // launch s handles step L-1-s of every problem that has one
+        StepsB ps;
+        int maxbs = 0;
+        for (int i = 0; i < MAXP; ++i) {
+            const int k = i < n ? i : 0;
+            const int lay = ly.lay_of[k];
+            const int Lk = ly.L[lay];
+            ps.p[i] = base[k];
+            ps.p[i].bs_cur = 0; ps.p[i].p0_prev = 0; ps.p[i].bs_prev = 0;
+            if (i < n && s < Lk) {
+                const int jp = Lk - 1 - s;
+                ps.p[i].p0_prev = ly.so[lay].off[jp];
+                ps.p[i].bs_prev = ly.so[lay].off[jp + 1] - ly.so[lay].off[jp];
+                if (s > 0) ps.p[i].bs_cur = ly.so[lay].off[jp + 2] - ly.so[lay].off[jp + 1];
+            }
+            ps.p[i].Aout = stt[k].A[s & 1];
+            ps.p[i].Ain = stt[k].A[(s + 1) & 1];
+            ps.p[i].dh = stt[k].dh;
+            ps.p[i].plane_stride = stt[k].plane_stride;
+            maxbs = ps.p[i].bs_prev > maxbs ? ps.p[i].bs_prev : maxbs;
+        }
+        if (maxbs == 0) continue;
+        const dim3 grid((maxbs + SR - 1) / SR, (C::NUB + SW - 1) / SW, n);
+        if (s == 0) RENET_LAUNCH((gru_step_bwd_kernel<H, false>), grid, dim3(SNT), STEP_LDS, st, ps);
+        else RENET_LAUNCH((gru_step_bwd_kernel<H, true>), grid, dim3(SNT), STEP_LDS, st, ps);
+        RENET_LAUNCH_CHECK();
+    }
+    return RENET_OK;
+}
+
 bool fill_offsets(const int32_t* step_off, int L, StepOff& so, int& B) {
     if (L < 1 || L > MAXL || !step_off) return false;
     for (int j = 0; j <= L; ++j) so.off[j] = step_off[j];
@@ -633,10 +1041,14 @@ extern "C" {
 
 // per GRU: forward = the bf16 planes of W_hh; backward = those of W_hh^T (bf16x6) or W_hh^T in fp32 (RENET_GEMM=f32)
 size_t renet_gru_workspace(int B, int H) {
-    (void)B;
     size_t m = fwd_plane_bytes(H);
     if (bwd_t_bytes(H) > m) m = bwd_t_bytes(H);
     if (bwd_plane_bytes(H) > m) m = bwd_plane_bytes(H);
+    m = align256(m);
+    if (B > 0) {                        // step kernels: A-operand planes (ping-pong, sized for K = 3H) + dh
+        const size_t rp = (size_t)rows_pad_of(B);
+        m += align256((size_t)2 * 3 * rp * kp_of(3 * H) * sizeof(__bf16)) + align256(rp * H * sizeof(float));
+    }
     return m;
 }
 
@@ -680,6 +1092,18 @@ int make_layouts(int n, const int32_t* const* step_off, const int* Ls, const int
     return RENET_OK;
 }
 
+// state region of problem k inside its workspace slice (behind the weight planes)
+StepState carve_state(char* slice, int H, int Bmax, size_t kp) {
+    StepState t;
+    const size_t rp = (size_t)rows_pad_of(Bmax);
+    char* base = slice + align256(renet_gru_workspace(0, H));
+    t.plane_stride = rp * kp;
+    t.A[0] = reinterpret_cast<__bf16*>(base);
+    t.A[1] = t.A[0] + 3 * t.plane_stride;
+    t.dh = reinterpret_cast<float*>(base + align256((size_t)2 * 3 * rp * kp_of(3 * H) * sizeof(__bf16)));
+    return t;
+}
+
 // W_hh planes are split once per DISTINCT weight pointer (the subject and object passes share the encoders)
 int plane_slot(int k, const float* const* W) {
     for (int i = 0; i < k; ++i)
@@ -716,9 +1140,14 @@ int renet_gru_fwd_layouts(int n, const float* const* Gi, const int32_t* const* s
             default: return launch_fwd<400>(ps, n, ly, st);
         }
     }
-    const size_t per = renet_gru_workspace(0, H);
+    const bool steps = !use_persistent(H);
+    int Bmax = 0;
+    for (int k = 0; k < n; ++k) Bmax = B_of[k] > Bmax ? B_of[k] : Bmax;
+    const size_t per = renet_gru_workspace(steps ? Bmax : 0, H);
     if (!workspace || workspace_bytes < (size_t)n * per) return RENET_ERR_WORKSPACE;
     FwdProbsB ps;
+    StepF sf[MAXP];
+    StepState stt[MAXP];
     for (int i = 0; i < MAXP; ++i) {
         const int k = i < n ? i : 0;
         const int slot = plane_slot(k, Whh);
@@ -729,6 +1158,28 @@ int renet_gru_fwd_layouts(int n, const float* const* Gi, const int32_t* const* s
         }
         ps.p[i].Gi = Gi[k]; ps.p[i].Wp = planes; ps.p[i].bhh = bhh[k]; ps.p[i].h_last = h_last[k];
         ps.p[i].saved = saved[k];
+        if (steps && i < n) {
+            const size_t kp = kp_of(H);
+            stt[i] = carve_state(reinterpret_cast<char*>(workspace) + (size_t)i * per, H, Bmax, kp);
+            sf[i].Gi = Gi[i]; sf[i].Wp = planes; sf[i].bhh = bhh[i]; sf[i].h = h_last[i]; sf[i].saved = saved[i];
+            sf[i].Ain = sf[i].Aout = nullptr; sf[i].p0 = sf[i].bs = 0; sf[i].plane_stride = stt[i].plane_stride;
+            // h0 = 0 (also the rows of the empty histories past B); k padding of the A planes = 0
+            const int lay = ly.lay_of[i];
+            hipError_t he = hipMemsetAsync(h_last[i], 0, (size_t)ly.rows[lay] * H * sizeof(float), st);
+            if (he != hipSuccess) return (int)he;
+            if (kp > (size_t)H) {
+                he = hipMemset2DAsync(stt[i].A[0] + H, kp * sizeof(__bf16), 0, (kp - H) * sizeof(__bf16),
+                                      (size_t)2 * 3 * rows_pad_of(Bmax), st);
+                if (he != hipSuccess) return (int)he;
+            }
+        }
+    }
+    if (steps) {
+        switch (H) {
+            case 100: return run_steps_fwd<100>(n, ly, sf, stt, st);
+            case 200: return run_steps_fwd<200>(n, ly, sf, stt, st);
+            default: return run_steps_fwd<400>(n, ly, sf, stt, st);
+        }
     }
     switch (H) {
         case 100: return launch_fwd_bf<100>(ps, n, ly, st);
@@ -747,12 +1198,17 @@ int renet_gru_bwd_layouts(int n, const float* const* dh_last, const int32_t* con
     if (e0 != RENET_OK) return e0;
     if (max_rows(ly) == 0) return RENET_OK;
     if (H != 100 && H != 200 && H != 400) return RENET_ERR_UNSUPPORTED;
-    const size_t per = renet_gru_workspace(0, H);
-    if (!workspace || workspace_bytes < (size_t)n * per) return RENET_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const bool f32 = use_f32();
+    const bool steps = !f32 && !use_persistent(H);
+    int Bmax = 0;
+    for (int k = 0; k < n; ++k) Bmax = B_of[k] > Bmax ? B_of[k] : Bmax;
+    const size_t per = renet_gru_workspace(steps ? Bmax : 0, H);
+    if (!workspace || workspace_bytes < (size_t)n * per) return RENET_ERR_WORKSPACE;
     BwdProbs ps;
     BwdProbsB pb;
+    StepB sb[MAXP];
+    StepState stt[MAXP];
     for (int i = 0; i < MAXP; ++i) {
         const int k = i < n ? i : 0;
         const int slot = plane_slot(k, Whh);
@@ -773,6 +1229,30 @@ int renet_gru_bwd_layouts(int n, const float* const* dh_last, const int32_t* con
         ps.p[i].dGh = dGh[k];
         pb.p[i].dh_last = dh_last[k]; pb.p[i].WTp = planes; pb.p[i].saved = saved[k]; pb.p[i].dGi = dGi[k];
         pb.p[i].dGh = dGh[k];
+        if (steps && i < n) {
+            const size_t kp = kp_of(3 * H);
+            stt[i] = carve_state(reinterpret_cast<char*>(workspace) + (size_t)i * per, H, Bmax, kp);
+            sb[i].saved = saved[i]; sb[i].WTp = planes; sb[i].dh = stt[i].dh; sb[i].dGi = dGi[i]; sb[i].dGh = dGh[i];
+            sb[i].Ain = sb[i].Aout = nullptr; sb[i].bs_cur = sb[i].p0_prev = sb[i].bs_prev = 0;
+            sb[i].plane_stride = stt[i].plane_stride;
+            if (B_of[i] > 0) {
+                hipError_t he = hipMemcpyAsync(stt[i].dh, dh_last[i], (size_t)B_of[i] * H * sizeof(float),
+                                               hipMemcpyDeviceToDevice, st);
+                if (he != hipSuccess) return (int)he;
+                if (kp > (size_t)3 * H) {
+                    he = hipMemset2DAsync(stt[i].A[0] + 3 * H, kp * sizeof(__bf16), 0, (kp - 3 * H) * sizeof(__bf16),
+                                          (size_t)2 * 3 * rows_pad_of(Bmax), st);
+                    if (he != hipSuccess) return (int)he;
+                }
+            }
+        }
+    }
+    if (steps) {
+        switch (H) {
+            case 100: return run_steps_bwd<100>(n, ly, sb, stt, st);
+            case 200: return run_steps_bwd<200>(n, ly, sb, stt, st);
+            default: return run_steps_bwd<400>(n, ly, sb, stt, st);
+        }
     }
     if (f32) {
         switch (H) {

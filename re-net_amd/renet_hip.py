@@ -564,7 +564,8 @@ def gru_fwd_layouts(gis, step_offs, hdim, w_hhs, b_hhs, out_rows):
     svs = [torch.empty(g.shape[0], 5 * hdim, device=dev, dtype=torch.float32) for g in gis]
     for t in list(gis) + list(w_hhs) + list(b_hhs):
         _f32(t)
-    nbytes = n * lib().renet_gru_workspace(0, hdim)
+    bmax = max([(o[1] - o[0]) if len(o) > 1 else 0 for o in step_offs] + [0])
+    nbytes = n * lib().renet_gru_workspace(int(bmax), hdim)
     ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
     so, ls = _offs(step_offs)
     t0 = _timer.begin() if _timer is not None else None
@@ -583,7 +584,8 @@ def gru_bwd_layouts(dh_lasts, step_offs, hdim, w_hhs, saveds):
     d_ghs = [torch.empty(s.shape[0], 3 * hdim, device=dev, dtype=torch.float32) for s in saveds]
     for t in list(dh_lasts) + list(w_hhs) + list(saveds):
         _f32(t)
-    nbytes = n * lib().renet_gru_workspace(0, hdim)
+    bmax = max([(o[1] - o[0]) if len(o) > 1 else 0 for o in step_offs] + [0])
+    nbytes = n * lib().renet_gru_workspace(int(bmax), hdim)
     ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
     so, ls = _offs(step_offs)
     t0 = _timer.begin() if _timer is not None else None

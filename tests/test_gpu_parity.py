@@ -251,9 +251,13 @@ def test_training_step_matches_oracle_on_fresh_inputs(dev):
 # ---------------------------------------------------------------------------------------------
 # GRU vs torch.nn.GRU on CPU (the third-party op being replaced)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('i,h,nseq', [(800, 200, 31), (300, 100, 31), (400, 400, 31), (200, 200, 77), (100, 400, 45)])
-def test_gru_matches_torch_cpu(dev, i, h, nseq):
+@pytest.mark.parametrize('kernels', ['persistent', 'steps'])
+@pytest.mark.parametrize('i,h,nseq', [(800, 200, 31), (300, 100, 31), (400, 400, 31), (200, 200, 77), (100, 400, 45),
+                                      (64, 200, 150)])
+def test_gru_matches_torch_cpu(dev, i, h, nseq, kernels, monkeypatch):
+    """both bf16x6 recurrences: the one-launch persistent kernels and the per-step launches (RENET_GRU)"""
     import model as M
+    monkeypatch.setenv('RENET_GRU', kernels)
     torch.manual_seed(7)
     lens = [10] * (nseq - 11) + [9, 9, 7, 5, 5, 5, 3, 2, 1, 1, 1]
     b, l = len(lens), 10
