@@ -205,11 +205,11 @@ class RENet(nn.Module):
         p = self.drop_p if self.training else 0.0
         loss_sub = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_h, self.rel_embeds, prep.r_idx,
                                       self.linear.weight, self.linear.bias, prep.o_idx, prep.plan_s,
-                                      prep.plan_r, p, ops.next_seed() if p > 0 else 0)
+                                      prep.plan_r, p, ops.next_seed() if p > 0 else 0, 2.0)
         loss_r = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_q, None, None, self.linear_r.weight,
                                     self.linear_r.bias, prep.r_label, prep.plan_s, None, p,
-                                    ops.next_seed() if p > 0 else 0)
-        return 2.0 * (loss_sub + 0.1 * loss_r)
+                                    ops.next_seed() if p > 0 else 0, 2.0)
+        return loss_sub + 0.1 * loss_r
 
     def prepare(self, triplets, hist, graph_dict, subject=True):
         """Host + upload half of one direction of a training step: batch graph, packed layout and plans,

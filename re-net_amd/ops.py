@@ -290,7 +290,7 @@ class HeadCEFn(Function):
     into (softmax - onehot)/B in place, which the backward GEMMs then consume."""
 
     @staticmethod
-    def forward(ctx, a, ia, hmid, c, ic, weight, bias, target, plan_a, plan_c, drop_p, seed):
+    def forward(ctx, a, ia, hmid, c, ic, weight, bias, target, plan_a, plan_c, drop_p, seed, loss_scale=1.0):
         ctx.srcs = (a, c, weight, bias)
         a, hmid, weight, bias = _c(a), _c(hmid), _c(weight), _c(bias)
         c = _c(c) if c is not None else None
@@ -300,13 +300,15 @@ class HeadCEFn(Function):
         if debug_tap is not None:
             debug_tap('logits', logits)
         need_grad = any(ctx.needs_input_grad)
-        row_loss = K.softmax_ce(logits, target, 1.0 / b, need_grad)
+        # loss_scale (2 for the merged batch of both passes: sum of two B-row means = 2 x the 2B-row mean) goes into
+        # the gradient the CE kernel writes, so that the upstream scalar stays 1 and the 188 MB are not rescaled
+        row_loss = K.softmax_ce(logits, target, float(loss_scale) / b, need_grad)
         ctx.meta = (d, 3 if c is not None else 2, drop_p, seed, plan_a, plan_c, a.shape,
                     c.shape if c is not None else None)
         if need_grad:
             ctx.save_for_backward(feat, logits, weight)
             ctx.consumed = False
-        return row_loss.mean()
+        return row_loss.mean() if loss_scale == 1.0 else row_loss.mean() * float(loss_scale)
 
     @staticmethod
     def backward(ctx, g):
@@ -347,7 +349,7 @@ class HeadCEFn(Function):
             else:
                 d_c = torch.zeros(c_shape, device=g.device, dtype=torch.float32)
                 K.segment_add(dc_rows, plan_c, d_c)
-        return d_a, None, dh, d_c, None, d_w, d_b, None, None, None, None, None
+        return d_a, None, dh, d_c, None, d_w, d_b, None, None, None, None, None, None
 
 
 class SegmentPoolFn(Function):
