@@ -150,7 +150,11 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* logits,
     __syncthreads();
     s = (red[0] + red[1]) + (red[2] + red[3]);
     const int t = target[b];
-    const float xt = x[t];                      // read before dlogits may overwrite (alias allowed)
+    float xt = x[t];                            // read before dlogits may overwrite (alias allowed)
+    // pin the read HERE: hipcc turns the block-uniform x[t] into a scalar load and sinks it into the thread-0 branch
+    // below the barrier (checked in the ISA), i.e. behind other waves' in-place stores to the row -- seen as a rare
+    // wrong LOSS with correct gradients
+    asm volatile("" : "+v"(xt) :: "memory");
     __syncthreads();
     if (threadIdx.x == 0) row_loss[b] = logf(s) + m - xt;
     if (dlogits) {

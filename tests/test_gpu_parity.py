@@ -447,11 +447,12 @@ def test_full_size_dw_matches_fp64_sampled(dev):
 def test_softmax_ce_in_place_is_race_free(dev):
     """renet_softmax_ce with dlogits aliasing logits (the training path): the row loss must not depend on when other
     waves overwrite the row.  (Round 2 found thread 0's read of x[target] sunk below the barrier by the compiler
-    because both pointers were declared __restrict__: a rare wrong LOSS with correct gradients.)  Repeated launches
+    because both pointers were declared __restrict__ and, in the streamed kernel, again as a scalar load sunk into the
+    thread-0 branch: a rare wrong LOSS with correct gradients.)  Repeated launches
     on recycled allocations, against torch's cross entropy; both kernels (row in LDS / streamed)."""
     import renet_hip as K
     torch.manual_seed(3)
-    for b, c in ((96, 150), (64, 23033), (33, 40000)):
+    for b, c in ((96, 150), (4096, 150), (2048, 700), (64, 23033), (33, 40000)):
         logits0 = torch.randn(b, c, device=dev) * 3
         tgt = torch.randint(0, c, (b,), device=dev)
         ref = torch.nn.functional.cross_entropy(logits0, tgt, reduction='none')

@@ -14,6 +14,7 @@ done
 F=$(find gpurun_out/prof/pmc_FETCH_SIZE -name "*results.db" | head -1); W=$(find gpurun_out/prof/pmc_WRITE_SIZE -name "*results.db" | head -1)
 python tools/pmc_traffic.py "$F" "$W" gpurun_out/prof/pmc_traffic.json
 (timeout 600 python tools/gather_bench.py batch --json gpurun_out/prof/gather_batch.json) > gpurun_out/prof/gather_batch.log 2>&1; cat gpurun_out/prof/gather_batch.log | grep -v JSON
+(timeout 600 python tools/gather_bench.py both --json gpurun_out/prof/gather_both.json) > gpurun_out/prof/gather_both.log 2>&1; cat gpurun_out/prof/gather_both.log | grep -v JSON
 (timeout 600 python tools/gather_bench.py global --json gpurun_out/prof/gather_global.json) > gpurun_out/prof/gather_global.log 2>&1; cat gpurun_out/prof/gather_global.log | grep -v JSON
 # keep the merge small: drop the raw databases, keep summaries
 find gpurun_out/prof -name "*.db" -size +20M -delete
