@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 8 --warmup 2 --cpu-steps 0 --e2e-steps 0 --f32-steps 0"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof/kt -o kt -- $BENCH > $R/gpurun_out/prof/kt.log 2>&1)
 DB=$(find gpurun_out/prof/kt -name "*results.db" | head -1); echo "db: $DB"
-python tools/prof_summary.py "$DB" gpurun_out/prof/kernel_stats.md 8 && head -30 gpurun_out/prof/kernel_stats.md
+python tools/prof_summary.py "$DB" gpurun_out/prof/kernel_stats.md 10 && head -30 gpurun_out/prof/kernel_stats.md
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d $R/gpurun_out/prof/pmc_$C -o pmc -- python $R/bench.py --steps 3 --warmup 1 --cpu-steps 0 --e2e-steps 0 --f32-steps 0 > $R/gpurun_out/prof/pmc_$C.log 2>&1)
 done
