@@ -262,8 +262,10 @@ class RENet(nn.Module):
         e, er = self.encoder, self.encoder_r
         w = (e.weight_ih_l0, e.weight_hh_l0, e.bias_ih_l0, e.bias_hh_l0)
         wr = (er.weight_ih_l0, er.weight_hh_l0, er.bias_ih_l0, er.bias_hh_l0)
+        hd = self.h_dim
         hs, qs, ho, qo = ops.MultiGRUFn.apply([prep_s.step_off, prep_s.step_off, prep_o.step_off, prep_o.step_off],
                                               [prep_s.b, prep_s.b, prep_o.b, prep_o.b],
+                                              [xs.shape[1] - hd, xrs.shape[1] - hd, xo.shape[1] - hd, xro.shape[1] - hd],
                                               xs, *w, xrs, *wr, xo, *w, xro, *wr)
         return self._heads(prep_s, hs[0], qs[0]) + self._heads(prep_o, ho[0], qo[0])
 

@@ -223,11 +223,13 @@ class MultiGRUFn(Function):
     `encoder` (4D->D) and `encoder_r` (3D->D) of one pass share a packed layout; the subject and the object pass of
     a training step are independent until their losses are added, so a step may run all four side by side
     (RENet.loss_prepared_pair).  Input projections are one GEMM per problem.
-    apply(step_offs, total_rows, x_0, w_ih_0, w_hh_0, b_ih_0, b_hh_0, x_1, ...) -> (h_n_0 [1, rows_0, H], ...)"""
+    apply(step_offs, total_rows, live_cols, x_0, w_ih_0, w_hh_0, b_ih_0, b_hh_0, x_1, ...) -> (h_n_0 [1, rows_0, H], ...)
+    live_cols: None, or per problem the number of leading columns of dX the caller reads (None = all)."""
 
     @staticmethod
-    def forward(ctx, step_offs, total_rows, *ts):
+    def forward(ctx, step_offs, total_rows, live_cols, *ts):
         n = len(ts) // 5
+        ctx.live_cols = live_cols
         ctx.src_w = [(ts[5 * k + 1], ts[5 * k + 2]) for k in range(n)]
         ctx.src_b = [(ts[5 * k + 3], ts[5 * k + 4]) for k in range(n)]
         ts = [_c(t) for t in ts]
@@ -251,7 +253,7 @@ class MultiGRUFn(Function):
         xs, w_ihs, w_hhs, svs = sv_[:n], sv_[n:2 * n], sv_[2 * n:3 * n], sv_[3 * n:4 * n]
         d_gis, d_ghs = K.gru_bwd_layouts([_c(dh[0, :nz]) for dh, nz in zip(dhs, ctx.nnz)], ctx.step_offs, hdim,
                                          list(w_hhs), list(svs))
-        out = [None, None]
+        out = [None, None, None]
         for k in range(n):
             t_ih, t_hh = (grad_target(t) for t in ctx.src_w[k])
             t_bi, t_bh = (grad_target(t) for t in ctx.src_b[k])
@@ -273,13 +275,24 @@ class MultiGRUFn(Function):
                 K.colsum(dgh, out=t_bh, beta=1.0)
             else:
                 dbh = K.colsum(dgh)
-            out += [K.gemm(dgi, w_ihs[k]), dwi, dwh, dbi, dbh]
+            live = ctx.live_cols[k] if ctx.live_cols is not None else None
+            if live is not None and live < xx.shape[1]:
+                # the caller never reads dX beyond column `live` (RE-Net: the last D input columns are the global
+                # embedding, a constant, Aggregator.py:150-155): contract only the live columns of W_ih; the rest
+                # of dX stays unwritten
+                dxx = torch.empty_like(xx)
+                K.gemm(dgi, w_ihs[k][:, :live], out=dxx[:, :live])
+            else:
+                dxx = K.gemm(dgi, w_ihs[k])
+            out += [dxx, dwi, dwh, dbi, dbh]
         return tuple(out)
 
 
 def dual_gru(x, xr, enc, enc_r, step_off, total_rows):
-    """Both encoders of ONE pass: -> (h_n [1, rows, H], q_n [1, rows, H])."""
-    return MultiGRUFn.apply([step_off, step_off], [total_rows, total_rows],
+    """Both encoders of ONE pass: -> (h_n [1, rows, H], q_n [1, rows, H]).  x = [h2 | ent | rel | glob] and
+    xr = [h2 | ent | glob] come from SeqAssembleFn, whose backward reads every column but the trailing glob block."""
+    h = enc.weight_hh_l0.shape[1]
+    return MultiGRUFn.apply([step_off, step_off], [total_rows, total_rows], [x.shape[1] - h, xr.shape[1] - h],
                             x, enc.weight_ih_l0, enc.weight_hh_l0, enc.bias_ih_l0, enc.bias_hh_l0,
                             xr, enc_r.weight_ih_l0, enc_r.weight_hh_l0, enc_r.bias_ih_l0, enc_r.bias_hh_l0)
 
