@@ -111,8 +111,6 @@ def main():
 
     if args.no_pair:
         args.passes = 'serial'
-    if args.passes == 'merged' and opt.reducer is not None:
-        opt.reducer.set_uses(1)          # the score head's gradient is complete after ONE head backward
 
     def prepare(step):
         idx = parallel.shard_indices(perm, step, rank, world, rank_batch)
@@ -132,6 +130,8 @@ def main():
         return net.loss_prepared_pair(*preps)       # the four GRU recurrences of the two passes share one launch
 
     def train_step(*preps):
+        if opt.reducer is not None:      # head backward passes that complete the early gradient bucket this step
+            opt.reducer.set_uses(1 if len(preps) == 1 else 2)
         loss = step_loss(*preps)
         loss.backward()
         opt.step()                       # gradient all-reduce (N>1) -> clip -> Adam -> zero_grad
