@@ -93,6 +93,24 @@ def test_merged_pass_equals_the_two_passes():
         assert abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l1))
         scale = float(g1.abs().max())
         assert float((g1 - flat.flat).abs().max()) <= 2e-6 * scale
+        # ragged / degenerate batches: rows with empty histories on one or both sides mixed in, a single quadruple
+        tmin = quads[:, 3].min()
+        early = np.arange(len(quads))[quads[:, 3] <= tmin + 2][:24]
+        late = np.arange(len(quads))[quads[:, 3] >= quads[:, 3].max() - 1][:9]
+        for sel in (np.concatenate((early, late)), late[:1]):
+            bb = quads[sel]
+            flat.zero()
+            la = net.loss_prepared(net.prepare(bb, hs.take(sel), gd, subject=True)) + \
+                net.loss_prepared(net.prepare(bb, ho.take(sel), gd, subject=False))
+            la.backward()
+            ga = flat.flat.clone()
+            flat.zero()
+            pm = net.prepare_both(bb, hs.take(sel), ho.take(sel), gd)
+            assert pm is not None and pm.b == 2 * len(bb)
+            lm = net.loss_prepared_both(pm)
+            lm.backward()
+            assert abs(float(la) - float(lm)) <= 2e-6 * abs(float(la)), (len(sel), float(la), float(lm))
+            assert float((ga - flat.flat).abs().max()) <= 4e-6 * float(ga.abs().max())
         # a direction without any history: callers fall back to the two separate passes
         first = np.arange(len(quads))[quads[:, 3] == quads[:, 3].min()][:8]
         assert net.prepare_both(quads[first], hs.take(first), ho.take(first), gd) is None

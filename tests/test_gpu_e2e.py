@@ -13,8 +13,11 @@ from helpers import O, GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('tag', ['', '_big'])
-def test_yago_prefix_training_and_filtered_mrr_match_reference(tag):
+@pytest.mark.parametrize('tag,loop', [('', 'reference'), ('_big', 'reference'), ('', 'product')])
+def test_yago_prefix_training_and_filtered_mrr_match_reference(tag, loop):
+    """loop = 'reference': train.py's own step (two model() calls, clip_grad_norm_, torch Adam, zero_grad);
+    loop = 'product': the path bench.py times -- merged pass of both directions (RENet.loss_prepared_both) and the
+    fused clip + Adam + zero_grad on flat buffers (parallel.HipAdam) -- against the same reference trajectory."""
     from sklearn.utils import shuffle
     if not os.path.isfile(os.path.join(GOLDEN, 'e2e_yago%s.npz' % tag)):
         pytest.skip('fixture e2e_yago%s.npz not generated' % tag)
@@ -43,7 +46,12 @@ def test_yago_prefix_training_and_filtered_mrr_match_reference(tag):
                            num_k=num_k, maxpool=int(gold['maxpool']))
     net.to(dev)
     gnet.to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=float(gold['lr']), weight_decay=float(gold['wd']))
+    if loop == 'product':
+        import parallel
+        opt = parallel.HipAdam(net, lr=float(gold['lr']), weight_decay=float(gold['wd']),
+                               max_norm=float(gold['grad_norm']))
+    else:
+        opt = torch.optim.Adam(net.parameters(), lr=float(gold['lr']), weight_decay=float(gold['wd']))
     with torch.no_grad():
         net.global_emb = gnet.get_global_emb(np.unique(tr[:, 3]), graph_dict)
     net.graph_dict = graph_dict
@@ -53,13 +61,20 @@ def test_yago_prefix_training_and_filtered_mrr_match_reference(tag):
         d_, a, b, c, d2 = shuffle(tr, sh, sht, oh, oht)        # train.py:127 (same RNG stream as the reference run)
         tot = 0.0
         for bd, bs, bst, bo, bot in U.make_batch2(d_, a, b, c, d2, batch):
+            prep = net.prepare_both(bd, (bs, bst), (bo, bot), graph_dict) if loop == 'product' else None
             bd = torch.from_numpy(bd).long().to(dev)
-            loss = net(bd, (bs, bst), (bo, bot), graph_dict, subject=True) + \
-                net(bd, (bs, bst), (bo, bot), graph_dict, subject=False)
+            if prep is not None:
+                loss = net.loss_prepared_both(prep)
+            else:
+                loss = net(bd, (bs, bst), (bo, bot), graph_dict, subject=True) + \
+                    net(bd, (bs, bst), (bo, bot), graph_dict, subject=False)
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(net.parameters(), float(gold['grad_norm']))
-            opt.step()
-            opt.zero_grad()
+            if loop == 'product':
+                opt.step()                                        # clip -> Adam -> zero_grad, one fused pass
+            else:
+                torch.nn.utils.clip_grad_norm_(net.parameters(), float(gold['grad_norm']))
+                opt.step()
+                opt.zero_grad()
             step_losses.append(loss.item())
             tot += step_losses[-1]
         epoch_losses.append(tot / (len(tr) / batch))
