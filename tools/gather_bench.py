@@ -31,16 +31,21 @@ import synth                 # noqa: E402
 HBM = 8000.0                 # GB/s, MI355X_MICROARCH.md
 
 
+SHAPE = os.environ.get('GATHER_BENCH_SHAPE', 'ICEWS18')       # GATHER_BENCH_SHAPE=YAGO GATHER_BENCH_D=400: config 5
+DIM = int(os.environ.get('GATHER_BENCH_D', '200'))
+SEQ = int(os.environ.get('GATHER_BENCH_SEQ', '10'))
+
+
 def workload(kind):
-    quads, ne, nr, unit = synth.make_stream('ICEWS18', seed=999)
+    quads, ne, nr, unit = synth.make_stream(SHAPE, seed=999)
     gd = P.build_graph_dict(quads, nr)
     if kind == 'global':
         return lambda: G.build_full_graphs(gd, list(gd.keys())), nr
-    hs = P.HistoryIndex(quads, 's', 10)
+    hs = P.HistoryIndex(quads, 's', SEQ)
     idx = np.random.RandomState(999).permutation(len(quads))[3 * 1024:4 * 1024]      # bench.py's first timed batch
     store = G.store_for(gd)
     if kind == 'both':       # the merged batch of both passes (bench.py --passes merged, the default)
-        ho = P.HistoryIndex(quads, 'o', 10)
+        ho = P.HistoryIndex(quads, 'o', SEQ)
         return lambda: G.build_batch_both(store, ne, nr, quads[idx, 0], quads[idx, 1], quads[idx, 2], hs.take(idx),
                                           ho.take(idx)), nr
     return lambda: G.build_batch(store, ne, nr, quads[idx, 0], quads[idx, 1], hs.take(idx), sort=True), nr
@@ -59,7 +64,8 @@ def time_launches(fn, sets, reps):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-def bench_graph(hb, nr, dev, d=200, legacy=True, label=''):
+def bench_graph(hb, nr, dev, d=None, legacy=True, label=''):
+    d = d or DIM
     g = G.DeviceGraph(hb, dev)
     n, nA = hb.N, getattr(hb, 'nA', hb.N)
     w = torch.randn(2 * nr, d * d // 100, device=dev) * 0.1
@@ -135,7 +141,7 @@ def main():
             results.append(bench_graph(build(), nr, dev, legacy=(heavy == 8 and budget == 16),
                                        label='h%d_b%d' % (heavy, budget)))
         if 'RENET_GATHER_UNR' not in os.environ:
-            for unr in ('2', '3', '4', '6', '8'):
+            for unr in (('2', '3', '4') if DIM == 400 else ('2', '3', '4', '6', '8')):
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), 'unr_child_' + kind],
                                    env=dict(os.environ, RENET_GATHER_UNR=unr), capture_output=True, text=True)
                 sys.stdout.write(r.stdout)
