@@ -171,7 +171,8 @@ def main():
     # ---- end-to-end rates with the host builder in the loop (extras, never `value`) ----------------
     #  e2e_inline : builder on the training thread (one batch at a time)
     #  e2e_value  : builder in forked worker processes (pipeline.BatchPrefetcher), uploads on this thread
-    e2e = e2e_inline = None
+    #  e2e_threads8 : builder in 8 threads of THIS process (no fork; the native passes and numpy release the GIL)
+    e2e = e2e_inline = e2e_threads = None
     e2e_workers = 0
     if args.e2e_steps > 0 and world == 1:      # single-GPU extra; multi-GPU runs time the device path only
         sync_all()
@@ -207,6 +208,19 @@ def main():
             done += 1
         sync_all()
         e2e = args.batch * world * done / (time.perf_counter() - t0)
+        # the same pipeline with 8 builder THREADS of this process instead of forked workers
+        pf = pipeline.BatchPrefetcher(host_step, range(n_total + 1000, n_total + 1000 + n_pipe), 8, threads=True)
+        it = iter(pf)
+        for hbs in [next(it) for _ in range(4)]:
+            train_step(*[up(h) for h in hbs])
+        sync_all()
+        t0 = time.perf_counter()
+        done = 0
+        for hbs in it:
+            train_step(*[up(h) for h in hbs])
+            done += 1
+        sync_all()
+        e2e_threads = args.batch * world * done / (time.perf_counter() - t0)
 
     if rank != 0:
         if world > 1:
@@ -344,7 +358,7 @@ def main():
                                    'nonempty': int(g0.nnz)}},
         'roofline': roofline, 'roofline_rgcn_gather': gather, 'roofline_gru': gru, 'parity': parity,
         'value_exact_f32': exact, 'pmc_source': pmc_file, 'kernels': kernels, 'gemm_shapes': gemm_shapes, 'cpu_baseline': cpu,
-        'host_build_ms': host_build_ms, 'e2e_value': e2e, 'e2e_workers': e2e_workers, 'e2e_inline': e2e_inline,
+        'host_build_ms': host_build_ms, 'e2e_value': e2e, 'e2e_workers': e2e_workers, 'e2e_inline': e2e_inline, 'e2e_threads8': e2e_threads,
         'last_loss': last_loss,
     }
     print(json.dumps(out))

@@ -18,16 +18,41 @@ def _run(step):
 class BatchPrefetcher(object):
     """for host_batches in BatchPrefetcher(fn, steps, workers): ...   where fn(step) is pure host work."""
 
-    def __init__(self, fn, steps, num_workers=None, chunksize=1):
+    def __init__(self, fn, steps, num_workers=None, chunksize=1, threads=False):
         self.fn, self.steps = fn, list(steps)
         self.num_workers = num_workers or max(1, min(32, (os.cpu_count() or 2) // 2))
         self.chunksize = chunksize
+        self.threads = threads
         self.pool = None
+
+    def _iter_threads(self):
+        """Worker THREADS of this process instead of forked processes: the builder spends most of its time in the
+        native passes (ctypes releases the GIL) and in large numpy kernels (which release it too), so a few threads
+        build several future batches concurrently without copying anything between processes."""
+        from concurrent.futures import ThreadPoolExecutor
+        ahead = 2 * self.num_workers
+        with ThreadPoolExecutor(self.num_workers) as ex:
+            pending = []
+            it = iter(self.steps)
+            for s in it:
+                pending.append(ex.submit(self.fn, s))
+                if len(pending) >= ahead:
+                    break
+            while pending:
+                item = pending.pop(0).result()
+                nxt = next(it, None)
+                if nxt is not None:
+                    pending.append(ex.submit(self.fn, nxt))
+                yield item
 
     def __iter__(self):
         if self.num_workers <= 1:
             for s in self.steps:
                 yield self.fn(s)
+            return
+        if self.threads:
+            for item in self._iter_threads():
+                yield item
             return
         _job['fn'] = self.fn                       # visible to the forked children
         ctx = mp.get_context('fork')
