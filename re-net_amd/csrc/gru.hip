@@ -27,7 +27,10 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MT = 16;           // sequences per workgroup (MFMA M)
-constexpr int NW = 8;            // waves per workgroup: 2 per SIMD so that W_hh fetch latency hides behind the partner's MFMAs
+#ifndef RENET_GRU_NW
+#define RENET_GRU_NW 8
+#endif
+constexpr int NW = RENET_GRU_NW; // waves per workgroup: 2 per SIMD so that W_hh fetch latency hides behind the partner's MFMAs
 constexpr int NT = NW * 64;
 constexpr int MAXL = 32;         // max packed steps (seq_len is 10 / 15 in the reference configs)
 
@@ -46,9 +49,28 @@ struct Layouts {
     int L[MAXLAY];
     int rows[MAXLAY];           // forward: rows of h_last (>= B); backward: B
     int lay_of[MAXP];
+    int rot_mod;                // backward: number of distinct starting k groups of the W stream (0 = the default)
+    int rot_mod_f;              // forward: same
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// Optional phase tracing of the persistent forward kernel (tools/gru_trace.py builds a separate library with
+// -DRENET_GRU_TRACE; the shipped library contains none of this): s_memtime stamps per wave and step for the first
+// GT_BLOCKS workgroups of problem 0.
+#ifdef RENET_GRU_TRACE
+constexpr int GT_BLOCKS = 32, GT_SLOTS = 8;
+__device__ unsigned long long* g_gru_trace = nullptr;      // [GT_BLOCKS][NW][MAXL][GT_SLOTS]
+__device__ __forceinline__ void gt_put(int wave, int step, int slot, unsigned long long v) {
+    if (g_gru_trace && blockIdx.y == 0 && blockIdx.x < GT_BLOCKS && (threadIdx.x & 63) == 0)
+        g_gru_trace[(((size_t)blockIdx.x * NW + wave) * MAXL + step) * GT_SLOTS + slot] = v;
+}
+#define GT_NOW() __builtin_amdgcn_s_memtime()
+#define GT_PUT(wave, step, slot, v) gt_put(wave, step, slot, (unsigned long long)(v))
+#else
+#define GT_NOW() 0ull
+#define GT_PUT(wave, step, slot, v)
+#endif
 
 template <int H>
 struct Cfg {
@@ -360,20 +382,51 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
     for (int t = tid; t < 3 * MT * Bc::LDP / 2; t += NT) reinterpret_cast<unsigned*>(Hp)[t] = 0u;   // and its planes
     __syncthreads();
     const int jj = lane & 15, kq = lane >> 4, ai = lane & 15;
+    // Every workgroup streams the SAME W_hh planes from L2 every step, and workgroups that start together run the
+    // same schedule: their requests for one chunk arrive at one L2 channel together (traced: the k loop of a unit
+    // block took 14 k cycles against 2 k of MFMA time).  The 32 workgroups that share an XCD's L2 (the dispatcher
+    // deals workgroups round-robin: XCD = linear block id mod 8) therefore start at different (k group, unit block)
+    // positions of the same cyclic order: 41.0 k -> 31.1 k cycles per step at H = 200, 124.5 k -> 91.8 k at H = 400.
+    // (The order of the fp32 accumulation over k depends on the workgroup: deterministic, not row-order invariant.)
+    const int rot_id = (int)((blockIdx.x + gridDim.x * blockIdx.y) >> 3);
+    // H = 400: the planes of the launch's GRUs (2 x 3 MB) exceed an XCD's 4 MB L2 -- there only the k position is
+    // rotated (workgroups stay on the same unit block, whose chunks are then fetched into L2 once): rotating the
+    // unit blocks as well measured 101.8 k instead of 91.8 k cycles per step
+    const int rmod = ly.rot_mod_f > 0 ? min(ly.rot_mod_f, Bc::KG) : Bc::KG;
+    const int rot_k = (rot_id % rmod) * (Bc::KG / rmod), rot_u = H <= 200 ? (rot_id / Bc::KG) % C::NUB : 0;
 
     for (int j = 0; j < L; ++j) {
         const int p0 = so.off[j];
         const int bs = so.off[j + 1] - p0;
         if (i0 >= bs) break;                                            // whole tile finished (sorted batch)
+        GT_PUT(wave, j, 0, GT_NOW());
+        unsigned long long gt_mfma = 0, gt_epi = 0;
+        (void)gt_mfma; (void)gt_epi;
 #pragma unroll 1
-        for (int ub = wave; ub < C::NUB; ub += NW) {
+        for (int ub0 = wave; ub0 < C::NUB; ub0 += NW) {
+            const unsigned long long gt_a = GT_NOW();
+            const int ub = ub0 + rot_u >= C::NUB ? ub0 + rot_u - C::NUB : ub0 + rot_u;
             const int u = ub * 16 + jj;                                 // this lane's hidden unit
             const bool uok = u < H;
             f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
+            // input-gate pre-activations of this lane's four (sequence, unit) pairs: requested BEFORE the matrix work
+            // and unconditionally (dead rows read the tile's last live row).  Loaded inside the `row is alive` branch
+            // of the epilogue they cost one full memory latency per row (hipcc drains vmcnt at every branch merge):
+            // 8 serialised latencies per wave and step
+            const int uc = uok ? u : 0;
+            float gr[4], gz[4], gn[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = min(i0 + 4 * kq + reg, bs - 1);
+                const float* gi = Gi + (size_t)(p0 + row) * C::K3 + uc;
+                gr[reg] = gi[0]; gz[reg] = gi[H]; gn[reg] = gi[2 * H];
+            }
+            const float b_r = bhh[uc], b_z = bhh[H + uc], b_n = bhh[2 * H + uc];
             const bf16x8* wf = Wp + (size_t)ub * Bc::KG * 9 * 64 + lane;       // fragment order (split_frag_kernel)
             const __bf16* ha = Hp + ai * Bc::LDP + kq * 8;
 #pragma unroll 2
-            for (int kg = 0; kg < Bc::KG; ++kg) {
+            for (int kg0 = 0; kg0 < Bc::KG; ++kg0) {
+                const int kg = kg0 + rot_k >= Bc::KG ? kg0 + rot_k - Bc::KG : kg0 + rot_k;
                 bf16x8 a[3], br[3], bz[3], bn[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
@@ -387,8 +440,12 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
                 an = mfma6(a, bn, an);
             }
             // C layout: column = lane & 15 (unit u), row = 4 * (lane >> 4) + reg (sequence)
+#ifdef RENET_GRU_TRACE
+            asm volatile("" : "+v"(ar), "+v"(az), "+v"(an));            // the MFMA results exist here
+#endif
+            const unsigned long long gt_b = GT_NOW();
+            gt_mfma += gt_b - gt_a;
             if (uok) {
-                const float b_r = bhh[u], b_z = bhh[H + u], b_n = bhh[2 * H + u];
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int i = 4 * kq + reg;
@@ -396,11 +453,10 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
                     float hv = hp;
                     if (i0 + i < bs) {
                         const size_t p = (size_t)(p0 + i0 + i);
-                        const float* gi = Gi + p * C::K3;
                         const float hn = an[reg] + b_n;
-                        const float r = sigmoidf_(gi[u] + ar[reg] + b_r);
-                        const float z = sigmoidf_(gi[H + u] + az[reg] + b_z);
-                        const float n = tanhf(gi[2 * H + u] + r * hn);
+                        const float r = sigmoidf_(gr[reg] + ar[reg] + b_r);
+                        const float z = sigmoidf_(gz[reg] + az[reg] + b_z);
+                        const float n = tanhf(gn[reg] + r * hn);
                         hv = (1.f - z) * n + z * hp;
                         float* sv = saved + p * 5 * H;
                         sv[u] = r; sv[H + u] = z; sv[2 * H + u] = n; sv[3 * H + u] = hn; sv[4 * H + u] = hp;
@@ -408,8 +464,13 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
                     Hn[i * C::LDH + u] = hv;
                 }
             }
+            gt_epi += GT_NOW() - gt_b;
         }
+        GT_PUT(wave, j, 1, gt_mfma);
+        GT_PUT(wave, j, 2, gt_epi);
+        GT_PUT(wave, j, 3, GT_NOW());
         __syncthreads();                                                // every wave is done reading Hs / Hp
+        GT_PUT(wave, j, 4, GT_NOW());
         for (int t = tid; t < MT * H; t += NT) {
             const int i = t / H, u = t - i * H;
             const float v = Hn[i * C::LDH + u];
@@ -418,7 +479,9 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
 #pragma unroll
             for (int p = 0; p < 3; ++p) Hp[p * MT * Bc::LDP + i * Bc::LDP + u] = s.p[p];
         }
+        GT_PUT(wave, j, 5, GT_NOW());
         __syncthreads();
+        GT_PUT(wave, j, 6, GT_NOW());
     }
     for (int t = tid; t < MT * H; t += NT) {                  // rows >= B were never touched: still h0 = 0
         const int i = t / H, u = t - i * H;
@@ -453,39 +516,56 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
     for (int t = tid; t < 3 * MT * Bc::LDP3 / 2; t += NT) reinterpret_cast<unsigned*>(Gp)[t] = 0u;
     __syncthreads();
     const int jj = lane & 15, kq = lane >> 4, ai = lane & 15;
+    const int rot_id = (int)((blockIdx.x + gridDim.x * blockIdx.y) >> 3);      // see gru_fwd_bf_kernel
+    const int rmod = ly.rot_mod > 0 ? min(ly.rot_mod, Bc::KG3) : Bc::KG3;
+    const int rot_k = (rot_id % rmod) * (Bc::KG3 / rmod), rot_u = H <= 200 ? (rot_id / Bc::KG3) % C::NUB : 0;
     constexpr int PLG = MT * Bc::LDP3;
 
     for (int j = L - 1; j >= 0; --j) {
         const int p0 = so.off[j];
         const int bs = so.off[j + 1] - p0;
         if (i0 >= bs) continue;                                         // tile not alive yet at this step
-        // phase 1: gate gradients of the live rows
-        for (int t = tid; t < MT * H; t += NT) {
-            const int i = t / H, u = t - i * H;
-            float gr = 0.f, gz = 0.f, gn = 0.f;
-            if (i0 + i < bs) {
-                const size_t p = (size_t)(p0 + i0 + i);
-                const float* sv = saved + p * 5 * H;
-                const float r = sv[u], z = sv[H + u], n = sv[2 * H + u], hn = sv[3 * H + u], hp = sv[4 * H + u];
-                const float g = dHs[i * C::LDH + u];
-                const float dan = g * (1.f - z) * (1.f - n * n);
-                const float daz = g * (hp - n) * z * (1.f - z);
-                const float dar = dan * hn * r * (1.f - r);
-                float* gi = dGi + p * C::K3;
-                float* gh = dGh + p * C::K3;
-                gi[u] = dar; gi[H + u] = daz; gi[2 * H + u] = dan;
-                gr = dar; gz = daz; gn = dan * r;
-                gh[u] = gr; gh[H + u] = gz; gh[2 * H + u] = gn;
-                dHs[i * C::LDH + u] = g * z;                            // direct path h_prev -> h
-            }
-            if (j > 0) {
-                const Planes3 sr = split3(gr), sz = split3(gz), sn = split3(gn);
-                __bf16* row = Gp + i * Bc::LDP3;
+        // phase 1: gate gradients of the live rows.  The saved activations are requested for ALL of this thread's
+        // elements first, unconditionally (dead rows read the tile's last live row): inside the `row is alive` branch
+        // every element paid its own memory latency (7 in a row per thread and step)
+        constexpr int P1 = (MT * H + NT - 1) / NT;
+        float s_r[P1], s_z[P1], s_n[P1], s_hn[P1], s_hp[P1];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    row[p * PLG + u] = sr.p[p];
-                    row[p * PLG + H + u] = sz.p[p];
-                    row[p * PLG + 2 * H + u] = sn.p[p];
+        for (int q = 0; q < P1; ++q) {
+            const int t = min(tid + NT * q, MT * H - 1);
+            const int i = t / H, u = t - i * H;
+            const float* sv = saved + (size_t)(p0 + min(i0 + i, bs - 1)) * 5 * H + u;
+            s_r[q] = sv[0]; s_z[q] = sv[H]; s_n[q] = sv[2 * H]; s_hn[q] = sv[3 * H]; s_hp[q] = sv[4 * H];
+        }
+#pragma unroll
+        for (int q = 0; q < P1; ++q) {
+            const int t = tid + NT * q;
+            if (t < MT * H) {
+                const int i = t / H, u = t - i * H;
+                float gr = 0.f, gz = 0.f, gn = 0.f;
+                if (i0 + i < bs) {
+                    const size_t p = (size_t)(p0 + i0 + i);
+                    const float r = s_r[q], z = s_z[q], n = s_n[q], hn = s_hn[q], hp = s_hp[q];
+                    const float g = dHs[i * C::LDH + u];
+                    const float dan = g * (1.f - z) * (1.f - n * n);
+                    const float daz = g * (hp - n) * z * (1.f - z);
+                    const float dar = dan * hn * r * (1.f - r);
+                    float* gi = dGi + p * C::K3;
+                    float* gh = dGh + p * C::K3;
+                    gi[u] = dar; gi[H + u] = daz; gi[2 * H + u] = dan;
+                    gr = dar; gz = daz; gn = dan * r;
+                    gh[u] = gr; gh[H + u] = gz; gh[2 * H + u] = gn;
+                    dHs[i * C::LDH + u] = g * z;                        // direct path h_prev -> h
+                }
+                if (j > 0) {
+                    const Planes3 sr = split3(gr), sz = split3(gz), sn = split3(gn);
+                    __bf16* row = Gp + i * Bc::LDP3;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        row[p * PLG + u] = sr.p[p];
+                        row[p * PLG + H + u] = sz.p[p];
+                        row[p * PLG + 2 * H + u] = sn.p[p];
+                    }
                 }
             }
         }
@@ -493,8 +573,9 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
         if (j > 0) {
             // phase 2: dh_prev += dGh W_hh  (rows of dead sequences have dGh = 0 and keep their dh)
 #pragma unroll 1
-            for (int ub = wave; ub < C::NUB; ub += NW) {
+            for (int ub0 = wave; ub0 < C::NUB; ub0 += NW) {
                 {
+                    const int ub = ub0 + rot_u >= C::NUB ? ub0 + rot_u - C::NUB : ub0 + rot_u;
                     const int u = ub * 16 + jj;
                     const bool uok = u < H;
                     f32x4 acc;
@@ -504,14 +585,15 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
                     const __bf16* ga = Gp + ai * Bc::LDP3 + kq * 8;
                     f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};                  // two chains: no MFMA waits on the previous one
 #pragma unroll 2
-                    for (int kg = 0; kg < Bc::KG3; ++kg) {
+                    for (int kg0 = 0; kg0 < Bc::KG3; ++kg0) {
+                        const int kg = kg0 + rot_k >= Bc::KG3 ? kg0 + rot_k - Bc::KG3 : kg0 + rot_k;
                         bf16x8 a[3], b[3];
 #pragma unroll
                         for (int p = 0; p < 3; ++p) {
                             a[p] = *reinterpret_cast<const bf16x8*>(ga + p * PLG + kg * 32);
                             b[p] = wf[(kg * 3 + p) * 64];
                         }
-                        if (kg & 1) acc2 = mfma6(a, b, acc2);
+                        if (kg0 & 1) acc2 = mfma6(a, b, acc2);
                         else acc = mfma6(a, b, acc);
                     }
                     if (uok) {
@@ -1039,6 +1121,12 @@ int split_frag(const float* in, int U, int K, int G, size_t sg, size_t su, size_
 
 extern "C" {
 
+#ifdef RENET_GRU_TRACE
+int renet_gru_trace_set(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gru_trace), &buf, sizeof(buf));
+}
+#endif
+
 // per GRU: forward = the bf16 planes of W_hh; backward = those of W_hh^T (bf16x6) or W_hh^T in fp32 (RENET_GEMM=f32)
 size_t renet_gru_workspace(int B, int H) {
     size_t m = fwd_plane_bytes(H);
@@ -1067,6 +1155,12 @@ int make_layouts(int n, const int32_t* const* step_off, const int* Ls, const int
         for (int j = 0; j <= MAXL; ++j) ly.so[i].off[j] = 0;
     }
     for (int k = 0; k < MAXP; ++k) ly.lay_of[k] = 0;
+    {
+        const char* e = getenv("RENET_GRU_ROT");
+        ly.rot_mod = e ? atoi(e) : 0;
+        const char* f = getenv("RENET_GRU_ROTF");
+        ly.rot_mod_f = f ? atoi(f) : 0;
+    }
     for (int k = 0; k < n; ++k) {
         int l = -1;
         for (int i = 0; i < nl; ++i)
