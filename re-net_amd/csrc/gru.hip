@@ -49,8 +49,8 @@ struct Layouts {
     int L[MAXLAY];
     int rows[MAXLAY];           // forward: rows of h_last (>= B); backward: B
     int lay_of[MAXP];
-    int rot_mod;                // backward: number of distinct starting k groups of the W stream (0 = the default)
-    int rot_mod_f;              // forward: same
+    int rot_mod;                // backward: number of distinct starting k groups of the W stream (0 = default; RENET_GRU_ROT)
+    int rot_mod_f;              // forward: same (RENET_GRU_ROTF)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
@@ -517,7 +517,9 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
     __syncthreads();
     const int jj = lane & 15, kq = lane >> 4, ai = lane & 15;
     const int rot_id = (int)((blockIdx.x + gridDim.x * blockIdx.y) >> 3);      // see gru_fwd_bf_kernel
-    const int rmod = ly.rot_mod > 0 ? min(ly.rot_mod, Bc::KG3) : Bc::KG3;
+    // H = 400 (planes larger than the L2): a few distinct starting positions beat all 38 (sweep over RENET_GRU_ROT,
+    // average of the forward and backward launch at config 5: 1 -> 910, 4 -> 754, 8 -> 756, 13 -> 802, 38 -> 818 us)
+    const int rmod = ly.rot_mod > 0 ? min(ly.rot_mod, Bc::KG3) : (H > 200 ? 6 : Bc::KG3);
     const int rot_k = (rot_id % rmod) * (Bc::KG3 / rmod), rot_u = H <= 200 ? (rot_id / Bc::KG3) % C::NUB : 0;
     constexpr int PLG = MT * Bc::LDP3;
 
@@ -1001,13 +1003,15 @@ inline size_t kp_of(int K) { return (size_t)((K + 31) / 32) * 32; }
 // The step kernels cut the W_hh stream 4x, but a launch whose workgroups all load, multiply and store in lockstep
 // leaves the memory system idle during the MFMA phase and the matrix pipe idle during the epilogue (the epilogue
 // alone -- Gi in, saved / h / planes out, 46 B per element and step -- is 12.6 us of a 20.8 us forward step),
-// while the persistent workgroups drift apart and overlap the two.  Default: persistent at H <= 200, step kernels at
-// H = 400 (where the 3 MB W_hh stream per workgroup and step dominates); RENET_GRU=steps|persistent forces one.
+// while the persistent workgroups drift apart and overlap the two.  With the W_hh stream of the persistent workgroups
+// de-synchronised (rot_k / rot_u in the kernels: 188 -> 142 us at H = 200, 858 -> ~790 us at H = 400) the persistent
+// kernels are the default everywhere; RENET_GRU=steps selects the per-step launches.
 bool use_persistent(int H) {
     const char* e = getenv("RENET_GRU");
     if (e && strcmp(e, "persistent") == 0) return true;
     if (e && strcmp(e, "steps") == 0) return false;
-    return H < 400;
+    (void)H;
+    return true;
 }
 
 struct StepState {                      // per problem: bf16 plane ping-pong of the A operand + fp32 dh
