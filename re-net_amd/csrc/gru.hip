@@ -50,7 +50,6 @@ struct Layouts {
     int rows[MAXLAY];           // forward: rows of h_last (>= B); backward: B
     int lay_of[MAXP];
     int rot_mod;                // backward: number of distinct starting k groups of the W stream (0 = default; RENET_GRU_ROT)
-    int rot_mod_f;              // forward: same (RENET_GRU_ROTF)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
@@ -392,8 +391,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
     // H = 400: the planes of the launch's GRUs (2 x 3 MB) exceed an XCD's 4 MB L2 -- there only the k position is
     // rotated (workgroups stay on the same unit block, whose chunks are then fetched into L2 once): rotating the
     // unit blocks as well measured 101.8 k instead of 91.8 k cycles per step
-    const int rmod = ly.rot_mod_f > 0 ? min(ly.rot_mod_f, Bc::KG) : Bc::KG;
-    const int rot_k = (rot_id % rmod) * (Bc::KG / rmod), rot_u = H <= 200 ? (rot_id / Bc::KG) % C::NUB : 0;
+    const int rot_k = rot_id % Bc::KG, rot_u = H <= 200 ? (rot_id / Bc::KG) % C::NUB : 0;
 
     for (int j = 0; j < L; ++j) {
         const int p0 = so.off[j];
@@ -1162,8 +1160,6 @@ int make_layouts(int n, const int32_t* const* step_off, const int* Ls, const int
     {
         const char* e = getenv("RENET_GRU_ROT");
         ly.rot_mod = e ? atoi(e) : 0;
-        const char* f = getenv("RENET_GRU_ROTF");
-        ly.rot_mod_f = f ? atoi(f) : 0;
     }
     for (int k = 0; k < n; ++k) {
         int l = -1;
