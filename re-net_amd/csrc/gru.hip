@@ -422,20 +422,33 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
             const float b_r = bhh[uc], b_z = bhh[H + uc], b_n = bhh[2 * H + uc];
             const bf16x8* wf = Wp + (size_t)ub * Bc::KG * 9 * 64 + lane;       // fragment order (split_frag_kernel)
             const __bf16* ha = Hp + ai * Bc::LDP + kq * 8;
-#pragma unroll 2
+            // W_hh fragments through a register ring, PF k groups ahead of the MFMAs that consume them (left to
+            // itself the compiler re-uses four registers quads and keeps 1-3 loads in flight: the loop then runs at
+            // one L2 latency per k group, 8.5 k cycles per unit block against 2 k of MFMA time)
+            constexpr int PF = Bc::KG > 8 ? 2 : (Bc::KG > 3 ? 3 : Bc::KG - 1);
+            bf16x8 wb[PF + 1][3][3];                                    // [slot][gate][plane]
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int kq_ = q + rot_k >= Bc::KG ? q + rot_k - Bc::KG : q + rot_k;
+#pragma unroll
+                for (int f = 0; f < 9; ++f) wb[q][f / 3][f % 3] = wf[(kq_ * 9 + f) * 64];
+            }
+#pragma unroll
             for (int kg0 = 0; kg0 < Bc::KG; ++kg0) {
                 const int kg = kg0 + rot_k >= Bc::KG ? kg0 + rot_k - Bc::KG : kg0 + rot_k;
-                bf16x8 a[3], br[3], bz[3], bn[3];
+                if (kg0 + PF < Bc::KG) {
+                    const int kn = kg0 + PF + rot_k >= Bc::KG ? kg0 + PF + rot_k - Bc::KG : kg0 + PF + rot_k;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    a[p] = *reinterpret_cast<const bf16x8*>(ha + p * MT * Bc::LDP + kg * 32);
-                    br[p] = wf[(kg * 9 + p) * 64];
-                    bz[p] = wf[(kg * 9 + 3 + p) * 64];
-                    bn[p] = wf[(kg * 9 + 6 + p) * 64];
+                    for (int f = 0; f < 9; ++f) wb[(kg0 + PF) % (PF + 1)][f / 3][f % 3] = wf[(kn * 9 + f) * 64];
                 }
-                ar = mfma6(a, br, ar);
-                az = mfma6(a, bz, az);
-                an = mfma6(a, bn, an);
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 a[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(ha + p * MT * Bc::LDP + kg * 32);
+                ar = mfma6(a, wb[kg0 % (PF + 1)][0], ar);
+                az = mfma6(a, wb[kg0 % (PF + 1)][1], az);
+                an = mfma6(a, wb[kg0 % (PF + 1)][2], an);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // C layout: column = lane & 15 (unit u), row = 4 * (lane >> 4) + reg (sequence)
 #ifdef RENET_GRU_TRACE
@@ -529,18 +542,21 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
         // elements first, unconditionally (dead rows read the tile's last live row): inside the `row is alive` branch
         // every element paid its own memory latency (7 in a row per thread and step)
         constexpr int P1 = (MT * H + NT - 1) / NT;
-        float s_r[P1], s_z[P1], s_n[P1], s_hn[P1], s_hp[P1];
+        constexpr int PC = P1 > 7 ? 7 : P1;                             // elements requested together (35 registers)
+#pragma unroll 1
+        for (int q0 = 0; q0 < P1; q0 += PC) {
+        float s_r[PC], s_z[PC], s_n[PC], s_hn[PC], s_hp[PC];
 #pragma unroll
-        for (int q = 0; q < P1; ++q) {
-            const int t = min(tid + NT * q, MT * H - 1);
+        for (int q = 0; q < PC; ++q) {
+            const int t = min(tid + NT * (q0 + q), MT * H - 1);
             const int i = t / H, u = t - i * H;
             const float* sv = saved + (size_t)(p0 + min(i0 + i, bs - 1)) * 5 * H + u;
             s_r[q] = sv[0]; s_z[q] = sv[H]; s_n[q] = sv[2 * H]; s_hn[q] = sv[3 * H]; s_hp[q] = sv[4 * H];
         }
 #pragma unroll
-        for (int q = 0; q < P1; ++q) {
-            const int t = tid + NT * q;
-            if (t < MT * H) {
+        for (int q = 0; q < PC; ++q) {
+            const int t = tid + NT * (q0 + q);
+            if (q0 + q < P1 && t < MT * H) {
                 const int i = t / H, u = t - i * H;
                 float gr = 0.f, gz = 0.f, gn = 0.f;
                 if (i0 + i < bs) {
@@ -569,6 +585,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
                 }
             }
         }
+        }
         __syncthreads();
         if (j > 0) {
             // phase 2: dh_prev += dGh W_hh  (rows of dead sequences have dGh = 0 and keep their dh)
@@ -584,17 +601,36 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
                     const bf16x8* wf = WTp + (size_t)ub * Bc::KG3 * 3 * 64 + lane;
                     const __bf16* ga = Gp + ai * Bc::LDP3 + kq * 8;
                     f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};                  // two chains: no MFMA waits on the previous one
-#pragma unroll 2
-                    for (int kg0 = 0; kg0 < Bc::KG3; ++kg0) {
-                        const int kg = kg0 + rot_k >= Bc::KG3 ? kg0 + rot_k - Bc::KG3 : kg0 + rot_k;
-                        bf16x8 a[3], b[3];
+                    // W_hh^T fragments through a register ring, PFB k groups ahead (see gru_fwd_bf_kernel)
+                    constexpr int PFB = 5, RB = PFB + 1;
+                    bf16x8 wb[RB][3];
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) {
-                            a[p] = *reinterpret_cast<const bf16x8*>(ga + p * PLG + kg * 32);
-                            b[p] = wf[(kg * 3 + p) * 64];
+                    for (int q = 0; q < PFB; ++q) {
+                        const int kq_ = q + rot_k >= Bc::KG3 ? q + rot_k - Bc::KG3 : q + rot_k;
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) wb[q][p] = wf[(kq_ * 3 + p) * 64];
+                    }
+#pragma unroll 1
+                    for (int base = 0; base < Bc::KG3; base += RB) {
+#pragma unroll
+                        for (int r = 0; r < RB; ++r) {
+                            const int kg0 = base + r;
+                            if (kg0 < Bc::KG3) {
+                                const int kg = kg0 + rot_k >= Bc::KG3 ? kg0 + rot_k - Bc::KG3 : kg0 + rot_k;
+                                if (kg0 + PFB < Bc::KG3) {
+                                    const int kn = kg0 + PFB + rot_k >= Bc::KG3 ? kg0 + PFB + rot_k - Bc::KG3 : kg0 + PFB + rot_k;
+#pragma unroll
+                                    for (int p = 0; p < 3; ++p) wb[(r + PFB) % RB][p] = wf[(kn * 3 + p) * 64];
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                bf16x8 a[3];
+#pragma unroll
+                                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(ga + p * PLG + kg * 32);
+                                if (r & 1) acc2 = mfma6(a, wb[r], acc2);
+                                else acc = mfma6(a, wb[r], acc);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
-                        if (kg0 & 1) acc2 = mfma6(a, b, acc2);
-                        else acc = mfma6(a, b, acc);
                     }
                     if (uok) {
 #pragma unroll
