@@ -181,7 +181,21 @@ __global__ __launch_bounds__(1024) void softmax_ce_lds_kernel(const float* logit
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* x = logits + (size_t)b * ld;
     float m = -INFINITY;
-    for (int c = threadIdx.x; c < C; c += 1024) {
+    // eight row loads in flight per thread (written as one load + wait + LDS store per iteration the compiler kept
+    // exactly one: 22 serialised HBM latencies per thread for a 23 033-wide row)
+    int c = threadIdx.x;
+    for (; c + 7 * 1024 < C; c += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = x[c + q * 1024];
+        __builtin_amdgcn_sched_barrier(0);           // all eight requested before the first is consumed
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            row[c + q * 1024] = v[q];
+            m = fmaxf(m, v[q]);
+        }
+    }
+    for (; c < C; c += 1024) {
         const float v = x[c];
         row[c] = v;
         m = fmaxf(m, v);
