@@ -591,3 +591,26 @@ def test_builder_rejects_ids_outside_the_declared_ranges():
     bad[0] = -1
     with pytest.raises(ValueError):
         G.build_batch(store, ne, nr, bad, quads[idx, 1], hs.take(idx))
+
+
+def test_thread_prefetcher_keeps_order_and_propagates_errors():
+    """pipeline.BatchPrefetcher(threads=True): results in step order whatever the completion order, bounded
+    look-ahead, and a worker's exception reaches the consumer."""
+    import time
+    import pipeline
+
+    def fn(s):
+        time.sleep(0.002 * ((7 * s) % 5))
+        return s * s
+    assert list(pipeline.BatchPrefetcher(fn, range(37), 6, threads=True)) == [s * s for s in range(37)]
+    assert list(pipeline.BatchPrefetcher(fn, range(3), 1, threads=True)) == [0, 1, 4]        # serial path
+
+    def bad(s):
+        if s == 5:
+            raise ValueError('boom')
+        return s
+    got = []
+    with pytest.raises(ValueError):
+        for x in pipeline.BatchPrefetcher(bad, range(10), 4, threads=True):
+            got.append(x)
+    assert got == [0, 1, 2, 3, 4]
