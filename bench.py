@@ -47,9 +47,11 @@ def parse():
                          'the default keeps the whole run within a few minutes, SURVEY 8d asks for >= 10)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='torch threads for the CPU baseline (0 = min(32, cores))')
     ap.add_argument('--e2e-steps', type=int, default=5)
-    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong', 'exact'],
                     help='weak: --batch quadruples per GPU (default); strong: --batch quadruples per step in total, '
-                         'batch / N per GPU')
+                         'batch / N per GPU, each rank with its own (smaller) reference batch; exact: ONE reference '
+                         'batch of --batch quadruples per step, every rank builds its graph and keeps 1/N of the '
+                         'sequences, gradients are summed (SURVEY 8e option (i): N-GPU step == 1-GPU step)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="f32: fp32-class GEMMs (bf16x6 split, or exact fp32 with RENET_GEMM=f32); bf16: GEMM operands "
                          "rounded to bf16, fp32 accumulate (BASELINE config 5)")
@@ -107,18 +109,26 @@ def main():
     flat = opt.grads
     perm = np.random.RandomState(999).permutation(len(quads))
 
-    rank_batch = args.batch if args.scaling == 'weak' else max(1, args.batch // world)
+    exact = args.scaling == 'exact'
+    if exact:
+        args.passes = 'merged'
+        if opt.reducer is not None:
+            opt.reducer.average = False          # the ranks hold disjoint shares of ONE batch: gradients add up
+    rank_batch = args.batch if args.scaling in ('weak', 'exact') else max(1, args.batch // world)
 
     if args.no_pair:
         args.passes = 'serial'
 
     def prepare(step):
-        idx = parallel.shard_indices(perm, step, rank, world, rank_batch)
+        idx = parallel.shard_indices(perm, step, 0, 1, rank_batch) if exact else \
+            parallel.shard_indices(perm, step, rank, world, rank_batch)
         b = quads[idx]
         if args.passes == 'merged':
-            both = net.prepare_both(b, hist_s.take(idx), hist_o.take(idx), graph_dict)
+            both = net.prepare_both(b, hist_s.take(idx), hist_o.take(idx), graph_dict,
+                                    shard=(rank, world) if exact and world > 1 else None)
             if both is not None:
                 return (both,)
+            assert not exact, 'exact scaling needs histories on both sides of the batch'
         return (net.prepare(b, hist_s.take(idx), graph_dict, subject=True),
                 net.prepare(b, hist_o.take(idx), graph_dict, subject=False))
 
@@ -166,7 +176,7 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    value = rank_batch * world * args.steps / elapsed
+    value = (rank_batch if exact else rank_batch * world) * args.steps / elapsed
 
     # ---- end-to-end rates with the host builder in the loop (extras, never `value`) ----------------
     #  e2e_inline : builder on the training thread (one batch at a time)
@@ -348,7 +358,8 @@ def main():
         'metric': 'RGCN+GRU encoder triples/s at bs=%d n_hidden=%d (full training step, both directions)'
                   % (args.batch, args.hidden),
         'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': args.scaling,
+        'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'strong' if exact else args.scaling,
+        'scaling_mode': args.scaling,
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'gemm_mode': K.GEMM_MODE, 'passes': args.passes,
         'config': {'workload': '%s-shaped synthetic stream (seed 999), n_hidden=%d, seq_len=%d, batch=%d per GPU, '
                                'dropout=%.2f, fwd+bwd both directions + clip + Adam' %

@@ -712,6 +712,52 @@ def build_batch_both(store, num_ent, num_rels, s, r, o, fh_s, fh_o, glob_index=N
     return hb
 
 
+def shard_sequences(hb, rank, world):
+    """SURVEY 8e option (i), the EXACT data-parallel split of ONE reference batch: every rank builds the same batch
+    (same node sets, same induced graphs, same norm -- quirk 4 makes them depend on every member of the batch) and
+    keeps only its share of the SEQUENCES: sorted sequences rank, rank + world, rank + 2 world, ... (lengths stay
+    non-increasing and balanced across the ranks).  The graph arrays are shared with `hb`; the packed sequence layout,
+    labels and scatter plans are re-derived for the subset.  Summing the ranks' losses (each weighted b_rank / B, see
+    RENet.loss_prepared_both(share=...)) and gradients reproduces the single-process batch up to fp32 summation order.
+    The RGCN layers still run on the whole batch graph on every rank: this option trades scaling of the graph part
+    for bit-comparable semantics; `parallel.shard_indices` (per-rank reference batches) is the scalable default."""
+    import copy
+    if world <= 1:
+        return hb
+    out = copy.copy(hb)                                   # graph fields shared (read-only from here on)
+    pos = np.arange(rank, hb.B, world)                    # sorted positions kept by this rank
+    live = pos[pos < hb.nnz]
+    out.B, out.nnz = len(pos), len(live)
+    out.perm = hb.perm[pos]
+    ln = hb.lens[live]
+    out.lens = ln
+    for f in ('s_sorted', 'r_sorted', 'rel_label', 'ent_label', 'is_obj'):
+        if hasattr(hb, f):
+            setattr(out, f, np.ascontiguousarray(getattr(hb, f)[pos]))
+    L = int(ln[0]) if len(ln) else 0
+    out.L = L
+    out.S = int(ln.sum())
+    bs = (ln[None, :] > np.arange(L)[:, None]).sum(axis=1) if L else np.zeros(0, np.int64)
+    off = np.concatenate(([0], np.cumsum(bs))).astype(np.int64)
+    out.batch_sizes = bs.astype(np.int64)
+    out.step_off = off.astype(np.int32)
+    # new packed row (step j, subset sequence i') <- old packed row off_old[j] + live[i']
+    j_of = np.repeat(np.arange(L, dtype=np.int64), bs)
+    i_of = np.arange(out.S, dtype=np.int64) - np.repeat(off[:-1], bs)
+    old = hb.step_off.astype(np.int64)[j_of] + live[i_of]
+    for f in ('subj_row', 'row_ent', 'row_rel', 'glob_row', 'step_t_packed'):
+        if hasattr(hb, f):
+            setattr(out, f, np.ascontiguousarray(np.asarray(getattr(hb, f))[old]))
+    out.row_seq = i_of.astype(np.int32)
+    for f in ('packed_from_seqmajor', 'subj_row_seqmajor'):     # sequence-major helpers of the full batch: not kept
+        if hasattr(out, f):
+            delattr(out, f)
+    out.plan_subj_row = SegPlan.host(out.subj_row)
+    out.plan_s = SegPlan.host(out.s_sorted)
+    out.plan_r = SegPlan.host(out.r_sorted)
+    return out
+
+
 def build_full_graphs(graph_dict, times):
     """Disjoint union of the FULL graphs of `times` (Aggregator.py:44-55 / 87-98, global model)."""
     hb = HostBatch()

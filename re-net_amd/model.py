@@ -157,7 +157,7 @@ class RENet(nn.Module):
         prep.o_idx = torch.from_numpy(hbatch['o']).to(dev)
         return prep
 
-    def host_batch_both(self, triplets, s_hist, o_hist, graph_dict):
+    def host_batch_both(self, triplets, s_hist, o_hist, graph_dict, shard=None):
         """Host half of BOTH passes of a training step as one merged batch (graph.build_batch_both); None when
         either direction has no history at all (callers then fall back to the two separate passes)."""
         trip = triplets.detach().cpu().numpy() if isinstance(triplets, torch.Tensor) else np.asarray(triplets)
@@ -170,12 +170,18 @@ class RENet(nn.Module):
                                 trip[:, 2], fs, fo, glob_index=table.index)
         if hb.L > self.seq_len:
             raise ValueError('history longer than seq_len (%d > %d)' % (hb.L, self.seq_len))
-        return {'both': True, 'b': 2 * len(trip), 'pb': G.PackedBatch(hb)}
+        share = 1.0
+        if shard is not None:            # (rank, world): this rank's sequences of the SAME batch (graph.shard_sequences)
+            full = hb.B
+            hb = G.shard_sequences(hb, int(shard[0]), int(shard[1]))
+            share = hb.B / float(full)
+        return {'both': True, 'b': hb.B, 'share': share, 'pb': G.PackedBatch(hb)}
 
     def prepare_both_from_host(self, hbatch):
         dev = self.ent_embeds.device
         prep = PreparedBatch()
         prep.subject, prep.b = None, hbatch['b']
+        prep.share = hbatch.get('share', 1.0)
         g = G.DeviceGraph(hbatch['pb'], dev)
         g.glob = self.aggregator.glob_table.get(self.global_emb, self.h_dim, dev).mat
         prep.g, prep.perm = g, g.host.perm
@@ -185,9 +191,11 @@ class RENet(nn.Module):
         prep.step_off = ops.host_offsets(g.host.step_off)
         return prep
 
-    def prepare_both(self, triplets, s_hist, o_hist, graph_dict):
-        """prepare() for the merged batch of both passes; None -> use prepare() twice."""
-        hbatch = self.host_batch_both(triplets, s_hist, o_hist, graph_dict)
+    def prepare_both(self, triplets, s_hist, o_hist, graph_dict, shard=None):
+        """prepare() for the merged batch of both passes; None -> use prepare() twice.
+        shard = (rank, world): keep this rank's share of the batch's sequences (exact data-parallel split: the
+        ranks' losses and gradients SUM to those of the whole batch)."""
+        hbatch = self.host_batch_both(triplets, s_hist, o_hist, graph_dict, shard=shard)
         return None if hbatch is None else self.prepare_both_from_host(hbatch)
 
     def loss_prepared_both(self, prep):
@@ -203,12 +211,15 @@ class RENet(nn.Module):
         s_h, s_q = ops.dual_gru(x, xr, self.encoder, self.encoder_r, prep.step_off, prep.b)
         s_h, s_q = s_h[0], s_q[0]
         p = self.drop_p if self.training else 0.0
+        # sum of two B-row means = 2 x the 2B-row mean; a rank holding a share of the batch's sequences (exact
+        # data-parallel split) contributes share x that, so that the ranks' losses and gradients SUM to the batch's
+        scale = 2.0 * getattr(prep, 'share', 1.0)
         loss_sub = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_h, self.rel_embeds, prep.r_idx,
                                       self.linear.weight, self.linear.bias, prep.o_idx, prep.plan_s,
-                                      prep.plan_r, p, ops.next_seed() if p > 0 else 0, 2.0)
+                                      prep.plan_r, p, ops.next_seed() if p > 0 else 0, scale)
         loss_r = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_q, None, None, self.linear_r.weight,
                                     self.linear_r.bias, prep.r_label, prep.plan_s, None, p,
-                                    ops.next_seed() if p > 0 else 0, 2.0)
+                                    ops.next_seed() if p > 0 else 0, scale)
         return loss_sub + 0.1 * loss_r
 
     def prepare(self, triplets, hist, graph_dict, subject=True):
@@ -279,7 +290,7 @@ class RENet(nn.Module):
 class PreparedBatch(object):
     """Device-resident inputs of one direction of one step (see RENet.prepare)."""
     __slots__ = ('g', 'subject', 'b', 'perm', 's_idx', 'r_idx', 'o_idx', 'plan_s', 'plan_r', 'batch_sizes',
-                 'step_off', 'r_label')
+                 'step_off', 'r_label', 'share')
 
 
 def _device_plan(idx, device):

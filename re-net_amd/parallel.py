@@ -93,6 +93,7 @@ class OverlapReducer(object):
         self.early_ids = {id(p) for p in early_params}
         self.early_uses = early_uses * len(self.early_ids)
         self.count, self.work = 0, None
+        self.average = True                       # False: SUM (ranks hold disjoint shares of one batch, bench --scaling exact)
         f = flat_grads.flat
         self.early = f[self.lo:self.lo + self.n]
         self.rest = [f[:self.lo], f[self.lo + self.n:]]
@@ -137,7 +138,8 @@ class OverlapReducer(object):
             self.work.wait()                      # device: makes the current stream wait for the side stream
             if self.stream is not None:
                 torch.cuda.current_stream().wait_stream(self.stream)
-        self.fg.flat.div_(world)
+        if self.average:
+            self.fg.flat.div_(world)
         self.count, self.work = 0, None
 
 

@@ -116,3 +116,45 @@ def test_merged_pass_equals_the_two_passes():
         assert net.prepare_both(quads[first], hs.take(first), ho.take(first), gd) is None
     finally:
         undo()
+
+
+def test_sequence_shards_of_one_batch_sum_to_the_batch():
+    """SURVEY 8e option (i): every rank builds the SAME merged batch and keeps its share of the sequences
+    (graph.shard_sequences); the ranks' losses and gradients SUM to those of the unsharded batch."""
+    import cpu_abi_emulation
+    undo = cpu_abi_emulation.install()
+    try:
+        import model as M
+        import parallel
+        quads, num_ent, R = _data()
+        gd = P.build_graph_dict(quads, R)
+        hs, ho = P.HistoryIndex(quads, 's'), P.HistoryIndex(quads, 'o')
+        torch.manual_seed(5)
+        net = M.RENet(num_ent, 100, R, dropout=0.0, seq_len=10)
+        gen = torch.Generator().manual_seed(2)
+        net.global_emb = {int(t): torch.randn(1, 1, 100, generator=gen) * 0.1 for t in gd}
+        net.eval()
+        idx = np.random.RandomState(9).permutation(len(quads))[:150]
+        b = quads[idx]
+        flat = parallel.FlatGrads(net)
+        full = net.prepare_both(b, hs.take(idx), ho.take(idx), gd)
+        lf = net.loss_prepared_both(full)
+        lf.backward()
+        gf = flat.flat.clone()
+        for world in (2, 3, 8):
+            flat.zero()
+            total, rows, perms = 0.0, 0, []
+            for rank in range(world):
+                pr = net.prepare_both(b, hs.take(idx), ho.take(idx), gd, shard=(rank, world))
+                assert pr.g.N == full.g.N and pr.g.E == full.g.E            # the same batch graph on every rank
+                l = net.loss_prepared_both(pr)
+                l.backward()                                                 # gradients accumulate = all-reduce SUM
+                total += float(l)
+                rows += pr.b
+                perms.append(np.asarray(pr.perm))
+            assert rows == full.b
+            assert sorted(np.concatenate(perms).tolist()) == list(range(full.b))   # every sequence on exactly one rank
+            assert abs(total - float(lf)) <= 2e-6 * abs(float(lf)), (world, total, float(lf))
+            assert float((flat.flat - gf).abs().max()) <= 4e-6 * float(gf.abs().max()), world
+    finally:
+        undo()

@@ -190,3 +190,59 @@ def test_renet_two_ranks_equal_accumulation_over_the_same_batches(tmp_path):
             assert float((got[0]['flat'][step] - ref).abs().max()) <= 1e-5 * scale
     finally:
         undo()
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY 8e option (i): the EXACT split -- both ranks build the SAME reference batch, keep half of its sequences
+# (graph.shard_sequences) and SUM their gradients: == the single-process step on that batch.
+# ---------------------------------------------------------------------------------------------
+def _renet_exact_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cpu_abi_emulation
+    cpu_abi_emulation.install()
+    import ops
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    net, quads, gd, hs, ho, perm = _renet_setup()
+    flat = parallel.FlatGrads(net)
+    early = [p for n, p in net.named_parameters() if n in ('linear.weight', 'linear.bias')]
+    red = parallel.OverlapReducer(flat, flat.span(('linear.weight', 'linear.bias'), net), early)
+    red.average = False
+    red.set_uses(1)
+    ops.grad_done_hook = red.on_grad_done
+    idx = perm[:120]
+    prep = net.prepare_both(quads[idx], hs.take(idx), ho.take(idx), gd, shard=(rank, world))
+    loss = net.loss_prepared_both(prep)
+    loss.backward()
+    red.finish()
+    lsum = torch.tensor([float(loss)])
+    dist.all_reduce(lsum)
+    torch.save({'flat': flat.flat.clone(), 'loss': float(lsum), 'rows': prep.b}, out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exact_split_of_one_batch_over_two_ranks(tmp_path):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    world, port, out = 2, _free_port(), str(tmp_path / 'x%d.pt')
+    mp.spawn(_renet_exact_worker, args=(world, port, out), nprocs=world, join=True)
+    got = [torch.load(out % r) for r in range(world)]
+    assert torch.equal(got[0]['flat'], got[1]['flat'])
+    import cpu_abi_emulation
+    undo = cpu_abi_emulation.install()
+    try:
+        net, quads, gd, hs, ho, perm = _renet_setup()
+        flat = parallel.FlatGrads(net)
+        idx = perm[:120]
+        full = net.prepare_both(quads[idx], hs.take(idx), ho.take(idx), gd)
+        assert got[0]['rows'] + got[1]['rows'] == full.b
+        loss = net.loss_prepared_both(full)
+        loss.backward()
+        assert abs(got[0]['loss'] - float(loss)) <= 2e-6 * abs(float(loss))
+        scale = float(flat.flat.abs().max())
+        assert float((got[0]['flat'] - flat.flat).abs().max()) <= 1e-5 * scale
+    finally:
+        undo()
