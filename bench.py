@@ -109,8 +109,8 @@ def main():
     flat = opt.grads
     perm = np.random.RandomState(999).permutation(len(quads))
 
-    exact = args.scaling == 'exact'
-    if exact:
+    exact_split = args.scaling == 'exact'
+    if exact_split:
         args.passes = 'merged'
         if opt.reducer is not None:
             opt.reducer.average = False          # the ranks hold disjoint shares of ONE batch: gradients add up
@@ -120,15 +120,15 @@ def main():
         args.passes = 'serial'
 
     def prepare(step):
-        idx = parallel.shard_indices(perm, step, 0, 1, rank_batch) if exact else \
+        idx = parallel.shard_indices(perm, step, 0, 1, rank_batch) if exact_split else \
             parallel.shard_indices(perm, step, rank, world, rank_batch)
         b = quads[idx]
         if args.passes == 'merged':
             both = net.prepare_both(b, hist_s.take(idx), hist_o.take(idx), graph_dict,
-                                    shard=(rank, world) if exact and world > 1 else None)
+                                    shard=(rank, world) if exact_split and world > 1 else None)
             if both is not None:
                 return (both,)
-            assert not exact, 'exact scaling needs histories on both sides of the batch'
+            assert not exact_split, 'exact scaling needs histories on both sides of the batch'
         return (net.prepare(b, hist_s.take(idx), graph_dict, subject=True),
                 net.prepare(b, hist_o.take(idx), graph_dict, subject=False))
 
@@ -176,7 +176,7 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    value = (rank_batch if exact else rank_batch * world) * args.steps / elapsed
+    value = (rank_batch if exact_split else rank_batch * world) * args.steps / elapsed
 
     # ---- end-to-end rates with the host builder in the loop (extras, never `value`) ----------------
     #  e2e_inline : builder on the training thread (one batch at a time)
@@ -358,7 +358,7 @@ def main():
         'metric': 'RGCN+GRU encoder triples/s at bs=%d n_hidden=%d (full training step, both directions)'
                   % (args.batch, args.hidden),
         'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'strong' if exact else args.scaling,
+        'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'strong' if exact_split else args.scaling,
         'scaling_mode': args.scaling,
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'gemm_mode': K.GEMM_MODE, 'passes': args.passes,
         'config': {'workload': '%s-shaped synthetic stream (seed 999), n_hidden=%d, seq_len=%d, batch=%d per GPU, '
