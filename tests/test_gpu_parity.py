@@ -284,6 +284,52 @@ def test_gru_matches_torch_cpu(dev, i, h, nseq, kernels, monkeypatch):
         np.testing.assert_allclose(p.grad.cpu().numpy(), getattr(ref, name).grad.numpy(), rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize('passes', ['separate', 'merged'])
+def test_train_mode_gradients_match_finite_differences_under_replayed_masks(dev, passes):
+    """Train mode (dropout 0.5 at all four sites: RGCN self-loop, sequence assembly x2, both heads): with the seed
+    counter reset before every forward the masks replay, so loss(theta) is a fixed function -- its analytic gradient
+    (every backward kernel regenerating its forward mask) must match the directional finite difference along the
+    gradient, per parameter tensor."""
+    import ops
+    c = train_case('small', 200)
+    net, gd = _build_model(c, dev, dropout=0.5)
+    net.train()
+    batch_np = c['batch']
+    batch = torch.from_numpy(batch_np).to(dev)
+
+    def loss_fn():
+        torch.manual_seed(4242)
+        ops.reset_seed_counter(0)
+        if passes == 'merged':
+            return net.loss_prepared_both(net.prepare_both(batch_np, c['hists']['s'], c['hists']['o'], gd))
+        return net(batch, c['hists']['s'], c['hists']['o'], gd, subject=True) + \
+            net(batch, c['hists']['s'], c['hists']['o'], gd, subject=False)
+
+    net.zero_grad()
+    l0 = loss_fn()
+    l0.backward()
+    assert float(loss_fn()) == float(l0), 'masks must replay'
+    grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    checked = 0
+    for k, p in net.named_parameters():
+        g = grads.get(k)
+        if g is None or float(g.norm()) < 1e-6:
+            continue
+        d = g / g.norm()
+        eps = 2e-2 * max(float(p.detach().abs().max()), 1e-3)
+        with torch.no_grad():
+            p.add_(eps * d)
+            lp = float(loss_fn())
+            p.sub_(2 * eps * d)
+            lm = float(loss_fn())
+            p.add_(eps * d)
+        fd = (lp - lm) / (2 * eps)
+        an = float(g.norm())                          # directional derivative along g / |g|
+        assert abs(fd - an) <= 0.05 * an + 2e-4, (passes, k, fd, an)
+        checked += 1
+    assert checked >= 10
+
+
 # ---------------------------------------------------------------------------------------------
 # global model vs the reference (golden)
 # ---------------------------------------------------------------------------------------------
