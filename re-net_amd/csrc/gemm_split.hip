@@ -373,6 +373,74 @@ __global__ __launch_bounds__(THREADS) void gemm_split_kernel(SplitArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// TALL variant of the two-phase kernel: 256 x 128 tile, 8 waves (4 x 2, each 64 x 64 as above), one workgroup per
+// CU.  The in-loop split is paid per operand ELEMENT: a 256 x 128 x 32 step splits 12 288 elements for 2 x the MACs of
+// a 128 x 128 x 32 step (8 192 elements), i.e. 0.75x the VALU / LDS-store work per flop -- the resource the k-loop
+// is bound by (header of the fused variant).  Used for outputs with >= 1000 such tiles (use_tall).
+// ------------------------------------------------------------------------------------------------------
+constexpr int BMT = 256, THREADS_T = 512;
+constexpr int PLANE_T = BMT * LDS_ROW;
+constexpr size_t TALL_LDS = (size_t)(3 * PLANE_T + 3 * PLANE) * sizeof(__bf16);
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(THREADS_T) void gemm_split_tall_kernel(SplitArgs g) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem_t[];
+    __bf16* sA = smem_t;
+    __bf16* sB = smem_t + 3 * PLANE_T;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx, by;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    const int m0 = by * BMT, n0 = bx * BN;
+    const int z = blockIdx.z;
+    const int kt0 = z * g.k_tiles_per_split;
+    const int kt_total = (g.K + BK - 1) / BK;
+    const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
+    constexpr bool A_CK = !TA;
+    constexpr bool B_CK = TB;
+    constexpr int NIA = BMT * 8 / THREADS_T, NIB = BN * 8 / THREADS_T;         // 4 and 2 items per thread
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[NIA], rb[NIB];
+    ItemLoader<A_CK, THREADS_T, BMT, NIA> la;
+    ItemLoader<B_CK, THREADS_T, BN, NIB> lb;
+    la.init(g.A, g.lda, g.M, g.K, m0, tid);
+    lb.init(g.B, g.ldb, g.N, g.K, n0, tid);
+    if (kt0 < kt1) {
+        la.load(kt0 * BK, ra);
+        lb.load(kt0 * BK, rb);
+    }
+    const bool a_edge = m0 + BMT > g.M, b_edge = n0 + BN > g.N;
+    const int arow = (wm * 64 + (lane & 31)) * LDS_ROW;
+    const int brow = (wn * 64 + (lane & 31)) * LDS_ROW;
+    const int ksel = (lane >> 5) * 8;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        __syncthreads();                               // previous tile fully consumed
+        const bool k_edge = (kt + 1) * BK > g.K;
+        if (a_edge || k_edge) store_items<A_CK, true, THREADS_T, BMT, NIA>(sA, g.M, g.K, m0, kt * BK, tid, ra);
+        else store_items<A_CK, false, THREADS_T, BMT, NIA>(sA, g.M, g.K, m0, kt * BK, tid, ra);
+        if (b_edge || k_edge) store_items<B_CK, true, THREADS_T, BN, NIB>(sB, g.N, g.K, n0, kt * BK, tid, rb);
+        else store_items<B_CK, false, THREADS_T, BN, NIB>(sB, g.N, g.K, n0, kt * BK, tid, rb);
+        __syncthreads();
+        const int k0n = min(kt + 1, kt1 - 1) * BK;     // next tile (the last step reloads its own: harmless)
+        mfma_tile_ld<PLANE_T, PLANE, NIA + NIB>(sA, sB, arow, brow, ksel, acc, [&](auto ic) {
+            constexpr int i = ic.value;
+            if constexpr (i < NIA) la.load_item(i, k0n, ra[i]);
+            else lb.load_item(i - NIA, k0n, rb[i - NIA]);
+        });
+    }
+    store_tile(g, m0, n0, z, wm, wn, lane, acc);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // FUSED variant: every wave runs its MFMAs and the split of the NEXT k-tile in ONE instruction stream.
 //
 // Measured on MI355X (tools/mfma_probe.hip, tools/fill_probe.hip; shader cycles per 128x128x32 k-tile):
@@ -1081,6 +1149,33 @@ int launch_fused(const SplitArgs& g, dim3 grid, hipStream_t st) {
     return RENET_OK;
 }
 
+template <bool TA, bool TB>
+int launch_tall(const SplitArgs& g, dim3 grid, hipStream_t st) {
+    static bool attr_set = false;      // benign race: the attribute is idempotent
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_split_tall_kernel<TA, TB>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)TALL_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    RENET_LAUNCH((gemm_split_tall_kernel<TA, TB>), grid, dim3(THREADS_T), TALL_LDS, st, g);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+// 256-row tiles when the output has enough of them to fill the chip a few times (RENET_GEMM_TALL=0 disables,
+// =<n> sets the minimum tile count)
+bool use_tall(int M, int nbx, int split_k) {
+    static int min_tiles = -1;
+    if (min_tiles < 0) {
+        const char* e = getenv("RENET_GEMM_TALL");
+        min_tiles = e ? atoi(e) : 1000;             // measured: logits 2048 x 23033 x 600 (1440 tiles) 395 -> 362 us;
+                                                    // dW 23033 x 600 x 2048 (450 tiles: 1.76 rounds) 447 -> 480 us
+        if (e && min_tiles == 0) min_tiles = 0x7fffffff;
+    }
+    return (long)nbx * ((M + BMT - 1) / BMT) * split_k >= min_tiles;
+}
+
 // Which k-loop: the fused kernel (one workgroup per CU, 122.9 KB LDS) when the whole grid fits in ONE round of
 // 256 workgroups -- there a lone workgroup finishes a k-tile in ~2500 cycles against ~3900 for the two-phase
 // kernel (MI355X: 51 vs 35 TFLOP/s on a 64-tile problem, 155 vs 126 on 256 tiles) -- and the two-phase kernel
@@ -1160,6 +1255,12 @@ static int gemm_planes_launch(bool bf16_mode, int ta, int tb, int M, int N, int 
         else if (!ta && tb) RENET_LAUNCH((gemm_bf16_kernel<false, true>), grid, dim3(THREADS), 0, st, g);
         else if (ta && !tb) RENET_LAUNCH((gemm_bf16_kernel<true, false>), grid, dim3(THREADS), 0, st, g);
         else RENET_LAUNCH((gemm_bf16_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
+    } else if (use_tall(M, nbx, split_k)) {
+        dim3 grid(nbx, (M + BMT - 1) / BMT, split_k);
+        if (!ta && !tb) e = launch_tall<false, false>(g, grid, st);
+        else if (!ta && tb) e = launch_tall<false, true>(g, grid, st);
+        else if (ta && !tb) e = launch_tall<true, false>(g, grid, st);
+        else e = launch_tall<true, true>(g, grid, st);
     } else {
         dim3 grid(nbx, nby, split_k);
         if (!ta && !tb) RENET_LAUNCH((gemm_split_kernel<false, false>), grid, dim3(THREADS), 0, st, g);

@@ -68,13 +68,14 @@ print('ok')
 '''
 
 
-@pytest.mark.parametrize('kernel', ['fused', 'split'])
+@pytest.mark.parametrize('kernel', ['fused', 'split', 'tall'])
 def test_gemm_both_k_loop_structures(dev, kernel):
-    """The bf16x6 GEMM has two k-loop structures (gemm_split.hip) picked by grid size; force each one over
-    shapes on both sides of that threshold."""
+    """The bf16x6 GEMM has two k-loop structures (gemm_split.hip) picked by grid size, the two-phase one with a
+    128 x 128 or a 256 x 128 ('tall') tile; force each one over shapes on both sides of the thresholds."""
     import subprocess
     import sys
-    env = dict(os.environ, RENET_GEMM_KERNEL=kernel)
+    env = dict(os.environ, RENET_GEMM_KERNEL='split' if kernel == 'tall' else kernel,
+               RENET_GEMM_TALL='1' if kernel == 'tall' else '0')
     pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 're-net_amd')
     r = subprocess.run([sys.executable, '-c', _GEMM_KERNEL_CHECK, pkg], env=env, capture_output=True, text=True,
                        timeout=600)
