@@ -164,3 +164,66 @@ def unsort(parts, batch):
         full[perm] = a
         res[key] = full
     return res
+
+
+# ------------------------------------------------------------------------------------------------
+# global model at pretrain scale (pretrain.py:72-86: ONE batch = every training timestamp, batch_size 1024 >= T)
+# ------------------------------------------------------------------------------------------------
+GLOBAL_CASES = {
+    # ICEWS18-shaped: 240 full graphs in one RGCN pass (N ~ 230 k nodes, E ~ 740 k directed edges: the largest
+    # gather-SpMM workload of the reference), max pooling (pretrain.py default --maxpool 1)
+    'global_icews18_d200': dict(shape='ICEWS18', hidden=200, seq_len=10, maxpool=1, param_seed=2801),
+}
+
+
+def global_shapes(num_ent, num_rels, d):
+    return {
+        'ent_embeds': (num_ent, d),
+        'encoder_global.weight_ih_l0': (3 * d, d), 'encoder_global.weight_hh_l0': (3 * d, d),
+        'encoder_global.bias_ih_l0': (3 * d,), 'encoder_global.bias_hh_l0': (3 * d,),
+        'aggregator.rgcn1.loop_weight': (d, d), 'aggregator.rgcn1.weight': (2 * num_rels, d * d // 100),
+        'aggregator.rgcn2.loop_weight': (d, d), 'aggregator.rgcn2.weight': (2 * num_rels, d * d // 100),
+        'linear_s.weight': (num_ent, d), 'linear_s.bias': (num_ent,),
+        'linear_o.weight': (num_ent, d), 'linear_o.bias': (num_ent,),
+    }
+
+
+def soft_targets(quads, num_ent, col):
+    """Per-timestamp empirical distribution of column `col` (0 = subjects, 2 = objects): the INPUT the pretrain
+    loss is computed against.  (A clean per-timestamp normalisation -- the reference's get_true_distribution has
+    boundary quirks that tests/test_host_cpu.py pins separately; here it is only a seeded input of the right
+    shape and sparsity.)  -> float64 [T, num_ent], rows in ascending time."""
+    times, inv = np.unique(quads[:, 3], return_inverse=True)
+    out = np.zeros((len(times), num_ent))
+    np.add.at(out, (inv, quads[:, col]), 1.0)
+    return out / out.sum(axis=1, keepdims=True)
+
+
+def build_global_case(name):
+    """-> dict(spec, quads, num_ent, num_rels, times, params, true_s, true_o)."""
+    spec = dict(GLOBAL_CASES[name])
+    synth = _synth()
+    quads, num_ent, num_rels, unit = synth.make_stream(spec['shape'], seed=999, num_t=spec.get('num_t'))
+    d = spec['hidden']
+    params = fixtures.make_params(spec['param_seed'], global_shapes(num_ent, num_rels, d))
+    rng = np.random.RandomState(spec['param_seed'] + 1)
+    k = 1.0 / np.sqrt(d)
+    for nm in sorted(params):
+        if nm.startswith('encoder_global') or nm.startswith('linear_'):
+            params[nm] = rng.uniform(-k, k, size=params[nm].shape).astype(np.float32)
+    return dict(name=name, spec=spec, quads=quads, num_ent=num_ent, num_rels=num_rels, time_unit=unit,
+                times=np.unique(quads[:, 3]), params=params,
+                true_s=soft_targets(quads, num_ent, 0), true_o=soft_targets(quads, num_ent, 2))
+
+
+def oracle_global_step(case, subject=True):
+    """The oracle's eval-mode pretrain step (global_model.py:35-55) on a global case -> (loss, params-with-grads)."""
+    import torch
+    spec = case['spec']
+    params = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in case['params'].items()}
+    ogd = O.build_graph_dict(case['quads'], case['num_rels'])
+    true = case['true_o'] if subject else case['true_s']                # global_model.py:38-43
+    loss = O.global_forward_loss(params, case['times'], true, ogd, spec['seq_len'], subject=subject,
+                                 maxpool=spec['maxpool'])
+    loss.backward()
+    return loss, params, ogd

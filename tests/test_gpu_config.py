@@ -231,3 +231,54 @@ def test_paired_step_equals_two_sequential_passes(dev):
     for k, g in res['seq'][1].items():
         scale = float(g.abs().max())
         assert float((res['pair'][1][k] - g).abs().max()) <= 1e-5 * scale + 1e-12, k
+
+
+# ---------------------------------------------------------------------------------------------
+# global model at PRETRAIN scale (pretrain.py:82: one batch = every training timestamp => all 240 full graphs of
+# the ICEWS18-shaped stream in ONE RGCN pass, N 417 704 / E 743 216 -- the beyond-cache gather regime, the
+# segmented max-pool readout and its backward, the [240 x 23 033] soft-CE head)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['global_icews18_d200'])
+def test_global_model_at_pretrain_scale_matches_reference_and_oracle(dev, name):
+    import global_model as GM
+    import preprocess as P
+    gold = load_golden('config_%s.npz' % name)
+    case = C.build_global_case(name)
+    spec = case['spec']
+    d = spec['hidden']
+    net = GM.RENet_global(case['num_ent'], d, case['num_rels'], dropout=0.0, seq_len=spec['seq_len'],
+                          maxpool=spec['maxpool'])
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in case['params'].items()})
+    net.to(dev)
+    net.eval()
+    gd = P.build_graph_dict(case['quads'], case['num_rels'])
+    times = case['times']
+    loss = net(torch.from_numpy(times.copy()), torch.from_numpy(case['true_s']).to(dev),
+               torch.from_numpy(case['true_o']).to(dev), gd, subject=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    # (a) the unmodified reference's recorded outputs
+    ref = float(gold['loss'])
+    assert abs(loss.item() - ref) < 1e-4 * abs(ref), (loss.item(), ref)
+    for k, p in net.named_parameters():
+        if ('grad.' + k) in gold or ('grad.' + k + '__samp') in gold:
+            ok, err, scale = C.compare_packed(gold, 'grad.' + k, p.grad.cpu().numpy(), rel=2e-3)
+            assert ok, ('reference', k, err, scale)
+    # (b) the oracle, every gradient entry
+    o_loss, o_params, _ = C.oracle_global_step(case, subject=True)
+    assert abs(loss.item() - o_loss.item()) < 1e-4 * abs(o_loss.item())
+    for k, p in net.named_parameters():
+        og = o_params[k].grad
+        if og is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        g, og = p.grad.cpu().numpy(), og.numpy()
+        scale = float(np.abs(og).max())
+        assert float(np.abs(g - og).max()) <= 2e-3 * scale + 1e-9, ('oracle', k, float(np.abs(g - og).max()), scale)
+    # get_global_emb over the whole timeline (global_model.py:57-73; 240 predict() calls)
+    with torch.no_grad():
+        ge = net.get_global_emb(times, gd)
+    assert [int(x) for x in ge.keys()] == gold['global_emb_keys'].tolist()
+    vals = np.stack([ge[x].view(-1).cpu().numpy() for x in ge.keys()])
+    ok, err, scale = C.compare_packed(gold, 'global_emb_vals', vals, rel=5e-4)
+    assert ok, ('global_emb', err, scale)

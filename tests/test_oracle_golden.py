@@ -257,3 +257,45 @@ def test_oracle_matches_reference_at_config_scale(name):
         g = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
         ok, err, scale = C.compare_packed(gold, 'grad.' + k, g, rel=1e-3)
         assert ok, (k, err, scale)
+
+
+# ---------------------------------------------------------------------------------------------
+# global model at PRETRAIN scale: all 240 full graphs of the ICEWS18-shaped stream in one RGCN pass
+# (N 417 704 / E 743 216), pretrain.py:82 -- oracle vs the UNMODIFIED reference's recorded outputs
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['global_icews18_d200'])
+def test_oracle_global_model_matches_reference_at_pretrain_scale(name):
+    from oracle import config_cases as C
+    gold = load_golden('config_%s.npz' % name)
+    case = C.build_global_case(name)
+    loss, params, ogd = C.oracle_global_step(case, subject=True)
+    ref = float(gold['loss'])
+    assert abs(loss.item() - ref) < 1e-5 * abs(ref), (loss.item(), ref)
+    n = sum(ogd[int(t)].num_nodes for t in case['times'][:-1])          # graphs strictly before the last target time
+    e = sum(len(ogd[int(t)].src) for t in case['times'][:-1])
+    assert (n, e) == (int(gold['graph_nodes']), int(gold['graph_edges']))
+    for k, p in params.items():
+        if ('grad.' + k) in gold or ('grad.' + k + '__samp') in gold:
+            ok, err, scale = C.compare_packed(gold, 'grad.' + k, p.grad.numpy(), rel=1e-3)
+            assert ok, (k, err, scale)
+    # get_global_emb (global_model.py:57-73) at sampled positions of the timeline
+    import torch
+    p0 = {k: torch.from_numpy(v) for k, v in case['params'].items()}
+    keys = gold['global_emb_keys']
+    times = case['times']
+    unit = case['time_unit']
+    rows = []
+    with torch.no_grad():
+        for k in (0, 1, 7, len(keys) // 2, len(keys) - 1):
+            # entry keyed by times[k] is the embedding predict() returns for the NEXT timestamp
+            nxt = int(times[k + 1]) if k + 1 < len(times) else int(times[-1] + unit)
+            assert int(keys[k]) == int(times[k])
+            s_q, _ = O.global_predict(p0, nxt, ogd, case['spec']['seq_len'], subject=True, maxpool=case['spec']['maxpool'])
+            rows.append((k, s_q.numpy()))
+    full = np.zeros((len(keys), case['spec']['hidden']), np.float32)
+    idx = fixtures.sample_idx(full.size)
+    samp = np.asarray(gold['global_emb_vals__samp'])
+    for k, v in rows:
+        sel = np.nonzero(idx // full.shape[1] == k)[0]
+        assert len(sel)
+        np.testing.assert_allclose(v[idx[sel] % full.shape[1]], samp[sel], rtol=2e-4, atol=2e-5)

@@ -92,6 +92,54 @@ def gen(name):
     np.savez_compressed(os.path.join(OUT, 'config_%s.npz' % name), **out)
 
 
+def gen_global(name):
+    """RENet_global.forward (subject pass, pretrain.py:82) + backward at pretrain scale -- every training timestamp
+    in ONE batch => all full graphs in one RGCN pass -- and get_global_emb over the whole timeline
+    (global_model.py:57-73), by the UNMODIFIED reference.  Writes tests/golden/config_<name>.npz."""
+    ref = ref_loader.load()
+    case = C.build_global_case(name)
+    spec, quads, num_ent, num_rels = case['spec'], case['quads'], case['num_ent'], case['num_rels']
+    d, seq_len, times = spec['hidden'], spec['seq_len'], case['times']
+    out = dict(d=d, seq_len=seq_len, maxpool=spec['maxpool'], num_t=np.int64(len(times)))
+    cap = {}
+    with ref_loader.cpu_mode():
+        graph_dict = {}
+        order = np.argsort(quads[:, 3], kind='stable')
+        q = quads[order]
+        ts, starts = np.unique(q[:, 3], return_index=True)
+        ends = np.concatenate((starts[1:], [len(q)]))
+        for t, a, b in zip(ts, starts, ends):
+            graph_dict[int(t)] = ref.utils.get_big_graph(q[a:b, :3], num_rels)
+        model = ref.global_model.RENet_global(num_ent, d, num_rels, dropout=0.0, model=0, seq_len=seq_len, num_k=10,
+                                              maxpool=spec['maxpool'])
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in case['params'].items()})
+        model.eval()
+        hook = model.aggregator.rgcn2.register_forward_hook(
+            lambda m, i, o: cap.setdefault('gsz', []).append((int(o.number_of_nodes()), int(o.number_of_edges()))))
+        enc = model.encoder_global.register_forward_hook(lambda m, i, o: cap.setdefault('enc', []).append(o[1].detach().clone()))
+        t0 = time.time()
+        loss = model(torch.from_numpy(times.copy()), torch.from_numpy(case['true_s']), torch.from_numpy(case['true_o']),
+                     graph_dict, subject=True)
+        loss.backward()
+        hook.remove()
+        enc.remove()
+        print('%s: reference pretrain step %.1f s, loss %.6f, graph N=%d E=%d'
+              % (name, time.time() - t0, loss.item(), cap['gsz'][0][0], cap['gsz'][0][1]), flush=True)
+        out['loss'] = np.float64(loss.item())
+        out['graph_nodes'], out['graph_edges'] = np.int64(cap['gsz'][0][0]), np.int64(cap['gsz'][0][1])
+        pack_tensor(out, 's_q_sorted', cap['enc'][0].view(-1, d))      # rows: timestamps descending, t = 0 dropped
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                pack_tensor(out, 'grad.' + k, p.grad)
+        with torch.no_grad():
+            t0 = time.time()
+            ge = model.get_global_emb(times, graph_dict)
+            out['global_emb_keys'] = np.asarray([int(k) for k in ge.keys()], dtype=np.int64)
+            pack_tensor(out, 'global_emb_vals', torch.stack([ge[k].view(-1) for k in ge.keys()]))
+            print('  get_global_emb: %.1f s, %d entries' % (time.time() - t0, len(ge)), flush=True)
+    np.savez_compressed(os.path.join(OUT, 'config_%s.npz' % name), **out)
+
+
 if __name__ == '__main__':
-    for n in (sys.argv[1:] or sorted(C.CASES)):
-        gen(n)
+    for n in (sys.argv[1:] or sorted(C.CASES) + sorted(C.GLOBAL_CASES)):
+        (gen_global if n in C.GLOBAL_CASES else gen)(n)
