@@ -42,9 +42,16 @@ def parse():
     ap.add_argument('--hidden', type=int, default=200)
     ap.add_argument('--seq-len', type=int, default=10)
     ap.add_argument('--dropout', type=float, default=0.5)
-    ap.add_argument('--cpu-steps', type=int, default=3,
-                    help='oracle steps timed for cpu_baseline after 1 warm-up (0 = skip; ~8 s each on the GPU box: '
-                         'the default keeps the whole run within a few minutes, SURVEY 8d asks for >= 10)')
+    ap.add_argument('--cpu-steps', type=int, default=10,
+                    help='oracle steps timed for cpu_baseline after --cpu-warmup untimed ones (0 = skip; ~3 s each on '
+                         'the GPU box with 32 threads; SURVEY 8d: >= 10 steps after 2 warm-ups, medians)')
+    ap.add_argument('--cpu-warmup', type=int, default=2)
+    ap.add_argument('--enc-steps', type=int, default=50,
+                    help='steps of the encoder-only companion measurement (RGCN x2 + sequence assembly + GRU x2, '
+                         'forward + backward, no heads / clip / Adam; 0 = skip)')
+    ap.add_argument('--companions', type=int, default=1,
+                    help='N > 1 only: also time the strong and exact scaling modes (same K steps each) and report '
+                         'them as scaling_strong / scaling_exact in the same JSON line (0 = skip)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='torch threads for the CPU baseline (0 = min(32, cores))')
     ap.add_argument('--e2e-steps', type=int, default=5)
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong', 'exact'],
@@ -109,74 +116,124 @@ def main():
     flat = opt.grads
     perm = np.random.RandomState(999).permutation(len(quads))
 
-    exact_split = args.scaling == 'exact'
-    if exact_split:
-        args.passes = 'merged'
-        if opt.reducer is not None:
-            opt.reducer.average = False          # the ranks hold disjoint shares of ONE batch: gradients add up
-    rank_batch = args.batch if args.scaling in ('weak', 'exact') else max(1, args.batch // world)
-
     if args.no_pair:
         args.passes = 'serial'
-
-    def prepare(step):
-        idx = parallel.shard_indices(perm, step, 0, 1, rank_batch) if exact_split else \
-            parallel.shard_indices(perm, step, rank, world, rank_batch)
-        b = quads[idx]
-        if args.passes == 'merged':
-            both = net.prepare_both(b, hist_s.take(idx), hist_o.take(idx), graph_dict,
-                                    shard=(rank, world) if exact_split and world > 1 else None)
-            if both is not None:
-                return (both,)
-            assert not exact_split, 'exact scaling needs histories on both sides of the batch'
-        return (net.prepare(b, hist_s.take(idx), graph_dict, subject=True),
-                net.prepare(b, hist_o.take(idx), graph_dict, subject=False))
-
-    def step_loss(*preps):
-        if len(preps) == 1:              # same arithmetic per row; every kernel sees the rows of both passes
-            return net.loss_prepared_both(preps[0])
-        if args.passes == 'serial':
-            return net.loss_prepared(preps[0]) + net.loss_prepared(preps[1])
-        return net.loss_prepared_pair(*preps)       # the four GRU recurrences of the two passes share one launch
-
-    def train_step(*preps):
-        if opt.reducer is not None:      # head backward passes that complete the early gradient bucket this step
-            opt.reducer.set_uses(1 if len(preps) == 1 else 2)
-        loss = step_loss(*preps)
-        loss.backward()
-        opt.step()                       # gradient all-reduce (N>1) -> clip -> Adam -> zero_grad
-        return loss
-
-    n_total = args.warmup + args.steps
-    t0 = time.time()
-    prepared = [prepare(k) for k in range(n_total)]
-    torch.cuda.synchronize()
-    host_build_ms = (time.time() - t0) * 1e3 / max(n_total, 1)
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        train_step(*prepared[k])
-    assert flat.check_views(), 'param.grad views were replaced'
+    class Mode(object):
+        """One scaling mode of the data-parallel step: which quadruples a rank takes and how gradients combine."""
 
+        def __init__(self, scaling):
+            self.scaling = scaling
+            self.exact = scaling == 'exact'
+            self.rank_batch = args.batch if scaling in ('weak', 'exact') else max(1, args.batch // world)
+            self.global_batch = args.batch if scaling in ('strong', 'exact') else args.batch * world
+            self.passes = 'merged' if self.exact else args.passes
+
+        def prepare(self, step):
+            idx = parallel.shard_indices(perm, step, 0, 1, self.rank_batch) if self.exact else \
+                parallel.shard_indices(perm, step, rank, world, self.rank_batch)
+            b = quads[idx]
+            if self.passes == 'merged':
+                both = net.prepare_both(b, hist_s.take(idx), hist_o.take(idx), graph_dict,
+                                        shard=(rank, world) if self.exact and world > 1 else None)
+                if both is not None:
+                    return (both,)
+                assert not self.exact, 'exact scaling needs histories on both sides of the batch'
+            return (net.prepare(b, hist_s.take(idx), graph_dict, subject=True),
+                    net.prepare(b, hist_o.take(idx), graph_dict, subject=False))
+
+        def step_loss(self, *preps):
+            if len(preps) == 1:              # same arithmetic per row; every kernel sees the rows of both passes
+                return net.loss_prepared_both(preps[0])
+            if self.passes == 'serial':
+                return net.loss_prepared(preps[0]) + net.loss_prepared(preps[1])
+            return net.loss_prepared_pair(*preps)       # the four GRU recurrences of the two passes share one launch
+
+        def train_step(self, *preps):
+            with opt.step_scope(head_passes=1 if len(preps) == 1 else 2, average=not self.exact):
+                loss = self.step_loss(*preps)
+                loss.backward()
+                opt.step()                   # gradient all-reduce (N>1) -> clip -> Adam -> zero_grad
+            return loss
+
+        def run(self, timer=None):
+            """W untimed + K timed steps on device-resident batches -> (elapsed seconds [max over ranks], last
+            loss, host build ms per step, the prepared batches)."""
+            n_total = args.warmup + args.steps
+            t0 = time.time()
+            prepared = [self.prepare(k) for k in range(n_total)]
+            torch.cuda.synchronize()
+            host_ms = (time.time() - t0) * 1e3 / max(n_total, 1)
+            for k in range(args.warmup):
+                self.train_step(*prepared[k])
+            assert flat.check_views(), 'param.grad views were replaced'
+            if timer is not None:
+                K.set_timer(timer)
+            sync_all()
+            t0 = time.perf_counter()
+            for k in range(args.warmup, n_total):
+                loss = self.train_step(*prepared[k])
+            sync_all()
+            elapsed = time.perf_counter() - t0
+            K.set_timer(None)
+            last = float(loss.item())
+            if world > 1:
+                tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                elapsed = float(tmax.item())
+            return elapsed, last, host_ms, prepared
+
+    mode = Mode(args.scaling)
+    args.passes = mode.passes
+    exact_split, rank_batch = mode.exact, mode.rank_batch
+    prepare, step_loss, train_step = mode.prepare, mode.step_loss, mode.train_step
+    n_total = args.warmup + args.steps
     timer = K.KernelTimer()
-    K.set_timer(timer)
-    sync_all()
-    t0 = time.perf_counter()
-    for k in range(args.warmup, n_total):
-        loss = train_step(*prepared[k])
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    K.set_timer(None)
-    last_loss = float(loss.item())
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    value = (rank_batch if exact_split else rank_batch * world) * args.steps / elapsed
+    elapsed, last_loss, host_build_ms, prepared = mode.run(timer)
+    value = mode.global_batch * args.steps / elapsed
+
+    # ---- N > 1: the other scaling modes of the same step, so that the line is explicit about global batch size ----
+    companions = {}
+    if world > 1 and args.companions:
+        for sc in ('weak', 'strong', 'exact'):
+            if sc == args.scaling:
+                continue
+            m2 = Mode(sc)
+            el2, loss2, _, _ = m2.run()
+            companions['scaling_' + sc] = {'value': m2.global_batch * args.steps / el2,
+                                           'ms_per_step': el2 * 1e3 / args.steps, 'global_batch': m2.global_batch,
+                                           'batch_per_gpu': m2.rank_batch, 'last_loss': loss2}
+
+    # ---- encoder-only companion: RGCN x2 + sequence assembly + GRU x2, forward + backward (SURVEY 8d asks for the
+    # encoder-only device rate next to the full step; the metric is NAMED "RGCN+GRU encoder triples/s").  The heads
+    # are replaced by fixed random cotangents on h_n / q_n; no clip / Adam; gradients are zeroed outside the timing.
+    encoder_only = None
+    if args.enc_steps > 0 and world == 1 and len(prepared[args.warmup]) == 1:
+        cot = torch.randn(2, 2 * rank_batch, args.hidden, device=dev)
+
+        def enc_step(prep):
+            x, xr = net.aggregator.encode(prep.g, net.ent_embeds, net.rel_embeds, reverse=False)
+            s_h, s_q = ops_mod.dual_gru(x, xr, net.encoder, net.encoder_r, prep.step_off, prep.b)
+            ((s_h[0] * cot[0, :prep.b]).sum() + (s_q[0] * cot[1, :prep.b]).sum()).backward()
+        import ops as ops_mod
+        for k in range(3):
+            enc_step(prepared[k][0])
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(args.enc_steps):
+            enc_step(prepared[args.warmup + (k % args.steps)][0])
+        sync_all()
+        dt = time.perf_counter() - t0
+        flat.zero()
+        encoder_only = {'value': rank_batch * args.enc_steps / dt, 'unit': 'triples/s', 'ms_per_step': dt * 1e3 / args.enc_steps,
+                        'steps': args.enc_steps,
+                        'what': 'RGCN x2 + sequence assembly + GRU x2 (both encoders), both directions, forward + '
+                                'backward incl. their parameter gradients; no score heads, clip or Adam'}
 
     # ---- end-to-end rates with the host builder in the loop (extras, never `value`) ----------------
     #  e2e_inline : builder on the training thread (one batch at a time)
@@ -203,7 +260,7 @@ def main():
             return (net.host_batch(b, hist_s.take(idx), graph_dict, subject=True),
                     net.host_batch(b, hist_o.take(idx), graph_dict, subject=False))
         n_pipe = max(40, 8 * args.e2e_steps)
-        e2e_workers = max(1, min(24, (os.cpu_count() or 2) // (2 * world)))
+        e2e_workers = pipeline.worker_budget(world)
         pf = pipeline.BatchPrefetcher(host_step, range(n_total + 100, n_total + 100 + n_pipe), e2e_workers)
         up = pipeline.Uploader(net)                              # H2D on a copy stream, off the compute queue
         it = iter(pf)
@@ -326,17 +383,33 @@ def main():
     # the parity check: HIP eval-mode loss vs oracle loss on identical batches and (current) parameters ----------
     cpu = parity = None
     if args.cpu_steps > 0 and world == 1:
-        cpu, oracle_losses, cpu_steps_idx = cpu_baseline(args, quads, num_ent, num_rels, hist_s, hist_o, net, perm)
+        cpu, oracle_losses, cpu_steps_idx, oracle_grad = cpu_baseline(args, quads, num_ent, num_rels, hist_s, hist_o,
+                                                                      net, perm)
         net.eval()
         hip_losses = []
         with torch.no_grad():
             for k in cpu_steps_idx:
                 hip_losses.append(float(step_loss(*prepare(k)).item()))      # the path that was timed
+        # gradient of the first checked batch: the HIP backward pass (eval-mode masks, no optimizer step) against the
+        # oracle's autograd, in the flat parameter layout -- whole-vector relative error, norms, and 4096 seeded samples
+        flat.zero()
+        step_loss(*prepare(cpu_steps_idx[0])).backward()
+        g_hip = flat.flat.detach().cpu().double().numpy()
+        flat.zero()
         net.train()
+        g_ref = np.zeros_like(g_hip)
+        names = {id(p_): n_ for n_, p_ in net.named_parameters()}
+        for p_, off in zip(flat.params, flat.offsets):
+            g_ref[off:off + p_.numel()] = oracle_grad[names[id(p_)]].reshape(-1)
+        samp = np.random.RandomState(4096).randint(0, g_ref.size, size=4096)
         rel = [abs(a - b_) / abs(b_) for a, b_ in zip(hip_losses, oracle_losses)]
         parity = {'hip_loss': hip_losses[0], 'oracle_loss': oracle_losses[0], 'rel_err': max(rel),
                   'batches': len(rel), 'mode': 'eval (dropout off), parameters after the timed steps',
-                  'tolerance': 2e-3 if args.dtype == 'bf16' else 2e-4}
+                  'tolerance': 2e-3 if args.dtype == 'bf16' else 2e-4,
+                  'grad_rel_err': float(np.linalg.norm(g_hip - g_ref) / np.linalg.norm(g_ref)),
+                  'grad_norm_hip': float(np.linalg.norm(g_hip)), 'grad_norm_oracle': float(np.linalg.norm(g_ref)),
+                  'grad_sampled_max_err_over_max': float(np.abs(g_hip[samp] - g_ref[samp]).max() / np.abs(g_ref).max()),
+                  'grad_tolerance': 5e-2 if args.dtype == 'bf16' else 2e-3}
 
     # ---- exact-fp32 companion (RENET_GEMM=f32: v_mfma_f32_32x32x2_f32 products instead of bf16x6) ------------
     exact = None
@@ -359,7 +432,7 @@ def main():
                   % (args.batch, args.hidden),
         'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'strong' if exact_split else args.scaling,
-        'scaling_mode': args.scaling,
+        'scaling_mode': args.scaling, 'global_batch': mode.global_batch,
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'gemm_mode': K.GEMM_MODE, 'passes': args.passes,
         'config': {'workload': '%s-shaped synthetic stream (seed 999), n_hidden=%d, seq_len=%d, batch=%d per GPU, '
                                'dropout=%.2f, fwd+bwd both directions + clip + Adam' %
@@ -368,10 +441,19 @@ def main():
                    'batch_graph': {'nodes': int(g0.N), 'edges': int(g0.E), 'history_steps': int(g0.S),
                                    'nonempty': int(g0.nnz)}},
         'roofline': roofline, 'roofline_rgcn_gather': gather, 'roofline_gru': gru, 'parity': parity,
-        'value_exact_f32': exact, 'pmc_source': pmc_file, 'kernels': kernels, 'gemm_shapes': gemm_shapes, 'cpu_baseline': cpu,
+        'encoder_only': encoder_only,
+        'kernel_only': {'ms_per_step': sum(e_['ms_per_step'] for e_ in kernels.values()),
+                        'value': rank_batch / max(sum(e_['ms_per_step'] for e_ in kernels.values()) * 1e-3, 1e-12),
+                        'what': 'sum of the HIP-event durations of the timed C-ABI kernel classes per step (the classes '
+                                'listed in `kernels`; untimed glue launches are not included)'},
+        'value_exact_f32': exact, 'pmc_source': pmc_file,
+        'traffic_source': ('%s: rocprofv3 --pmc passes of this command (tools/pmc_traffic.py), NOT measured in this run' % pmc_file) if pmc_file else None, 'kernels': kernels, 'gemm_shapes': gemm_shapes, 'cpu_baseline': cpu,
         'host_build_ms': host_build_ms, 'e2e_value': e2e, 'e2e_workers': e2e_workers, 'e2e_inline': e2e_inline, 'e2e_threads8': e2e_threads,
         'last_loss': last_loss,
     }
+    out.update(companions)
+    if world > 1 and not companions:
+        out['multi_gpu_note'] = 'companion scaling modes skipped (--companions 0)'
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -380,7 +462,7 @@ def main():
 def cpu_baseline(args, quads, num_ent, num_rels, hist_s, hist_o, net, perm):
     """Times the oracle (oracle/renet_oracle.py: the reference's algorithm restated on torch-CPU; the reference
     itself is not on this box) on a bounded sample of the SAME workload: `cpu_steps` training steps (forward both
-    directions + backward, eval-mode dropout) at the same batch size after one warm-up, per-stage medians.
+    directions + backward, eval-mode dropout) at the same batch size after `cpu_warmup` untimed ones, per-stage medians.
     Returns (record, oracle losses per timed step, the step indices used).  Reported baseline, not a target."""
     from oracle import renet_oracle as O
     import parallel
@@ -391,7 +473,9 @@ def cpu_baseline(args, quads, num_ent, num_rels, hist_s, hist_o, net, perm):
     ge = {t: v.view(-1).cpu() for t, v in net.global_emb.items()}
     ogd = O.build_graph_dict(quads, num_rels)
     times, stages, losses, steps_idx = [], [], [], []
-    for k in range(args.cpu_steps + 1):
+    warm = max(0, args.cpu_warmup)
+    first_grad = None
+    for k in range(args.cpu_steps + warm):
         step = 1000 + k
         idx = parallel.shard_indices(perm, step, 0, 1, args.batch)
         hs, hst = hist_s.to_lists(idx)
@@ -405,9 +489,12 @@ def cpu_baseline(args, quads, num_ent, num_rels, hist_s, hist_o, net, perm):
         loss.backward()
         tm.mark('backward')
         dt = time.perf_counter() - t0
+        if k == warm:          # gradient of the first timed step, for bench `parity.grad_rel_err`
+            first_grad = {n: (p.grad.detach().double().numpy() if p.grad is not None else np.zeros(tuple(p.shape)))
+                          for n, p in params.items()}
         for p in params.values():
             p.grad = None
-        if k > 0 or args.cpu_steps == 0:
+        if k >= warm:
             times.append(dt)
             stages.append(dict(tm.t))
             losses.append(float(loss.item()))
@@ -417,10 +504,10 @@ def cpu_baseline(args, quads, num_ent, num_rels, hist_s, hist_o, net, perm):
     stage_ms = {k: float(np.median([s_[k] for s_ in stages])) * 1e3 for k in stages[0]}
     rec = {'value': args.batch / t, 'unit': 'triples/s', 'cores': int(threads), 'kind': 'port',
            'host_cpus': os.cpu_count(), 'ms_per_step': t * 1e3, 'stage_ms_median': stage_ms,
-           'sample': '%d training steps (fwd both directions + bwd, eval-mode dropout) of batch %d after 1 warm-up, '
+           'sample': '%d training steps (fwd both directions + bwd, eval-mode dropout) of batch %d after %d warm-ups, '
                      'oracle/renet_oracle.py on torch-CPU with %d threads; medians'
-                     % (len(times), args.batch, threads)}
-    return rec, losses, steps_idx
+                     % (len(times), args.batch, warm, threads)}
+    return rec, losses, steps_idx, first_grad
 
 
 if __name__ == '__main__':

@@ -284,6 +284,14 @@ size_t renet_adam_workspace(size_t n);
 int renet_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, float max_norm, int step, int zero_grad, float* workspace,
                     size_t workspace_bytes, float* grad_norm_out, void* stream);
+/* The same step on the gradient g * grad_scale (norm, clip coefficient and update all see the scaled gradient):
+ * grad_scale = 1 / world_size turns the SUM all-reduce of the data-parallel exchange into the mean without a
+ * separate pass over the 81 MB buffer (the reference has no distributed step; train.py:140-142 on the averaged
+ * gradient is what gradient accumulation over world_size batches would do). */
+int renet_adam_step_scaled(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, float max_norm, float grad_scale, int step,
+                           int zero_grad, float* workspace, size_t workspace_bytes, float* grad_norm_out,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * HOST-side batch-graph builder passes (no device work; pointers are HOST arrays): the native form of

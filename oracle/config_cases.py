@@ -227,3 +227,47 @@ def oracle_global_step(case, subject=True):
                                  maxpool=spec['maxpool'])
     loss.backward()
     return loss, params, ogd
+
+
+# ------------------------------------------------------------------------------------------------
+# inference state machine at config scale (test.py's loop, model.py:216-419): N_ent 23 033, R 256, num_k 1000
+# ------------------------------------------------------------------------------------------------
+EVAL_CASES = {
+    # ICEWS18-shaped stream cut 216 / 12 / 12 timestamps (train / valid / test); the evaluated quadruples are the
+    # first `per_t` of each of the first `n_t` validation timestamps => n_t - 1 timestamp advances, each scoring
+    # 2 * num_k sampled entities with a [R, N_ent] joint distribution (model.py:229-297)
+    'eval_icews18_d200': dict(shape='ICEWS18', hidden=200, seq_len=10, num_k=1000, n_train_t=216, n_valid_t=12,
+                              n_t=3, per_t=6, model_seed=3801, global_seed=3802),
+}
+
+
+def build_eval_case(name):
+    """-> dict(spec, num_ent, num_rels, train, valid, test, eval_idx (rows of valid), params, gparams).
+    Score-head weights are drawn at a scale that gives PEAKED distributions (logit std ~2-3, as a trained model
+    has): with the near-uniform softmax of default-initialised heads the 1000th and 1001st of 5.9 M joint
+    probabilities differ by ~1e-9 relative and the top-k SET itself would be decided by fp32 summation order."""
+    spec = dict(EVAL_CASES[name])
+    synth = _synth()
+    quads, num_ent, num_rels, unit = synth.make_stream(spec['shape'], seed=999)
+    times = np.unique(quads[:, 3])
+    a, b = spec['n_train_t'], spec['n_train_t'] + spec['n_valid_t']
+    tr = quads[quads[:, 3] < times[a]]
+    va = quads[(quads[:, 3] >= times[a]) & (quads[:, 3] < times[b])]
+    te = quads[quads[:, 3] >= times[b]]
+    d = spec['hidden']
+    pm = fixtures.make_params(spec['model_seed'], renet_shapes(num_ent, num_rels, d))
+    pg = fixtures.make_params(spec['global_seed'], global_shapes(num_ent, num_rels, d))
+    rng = np.random.RandomState(spec['model_seed'] + 1)
+    k = 1.0 / np.sqrt(d)
+    for p_ in (pm, pg):
+        for nm in sorted(p_):
+            if nm.startswith('encoder'):
+                p_[nm] = rng.uniform(-k, k, size=p_[nm].shape).astype(np.float32)
+            elif nm.startswith('linear') and nm.endswith('weight'):
+                p_[nm] = rng.uniform(-1.0, 1.0, size=p_[nm].shape).astype(np.float32)
+            elif nm.startswith('linear'):
+                p_[nm] = rng.uniform(-0.5, 0.5, size=p_[nm].shape).astype(np.float32)
+    vt = np.unique(va[:, 3])
+    eval_idx = np.concatenate([np.nonzero(va[:, 3] == vt[j])[0][:spec['per_t']] for j in range(spec['n_t'])])
+    return dict(name=name, spec=spec, num_ent=num_ent, num_rels=num_rels, time_unit=unit, train=tr, valid=va, test=te,
+                eval_idx=eval_idx, params=pm, gparams=pg)

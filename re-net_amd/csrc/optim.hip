@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float4* __rest
 
 struct AdamCfg {
     float lr, beta1, beta2, eps, wd, max_norm, bc1, bc2_sqrt;
+    float grad_scale;          // the gradient is g * grad_scale (1 / world_size after a SUM all-reduce)
     int zero_grad;
 };
 
@@ -56,10 +57,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        const float norm = c.grad_scale * sqrtf((red[0] + red[1]) + (red[2] + red[3]));
         float coef = 1.f;
         if (c.max_norm > 0.f) coef = fminf(c.max_norm / (norm + 1e-6f), 1.f);      // clip_grad_norm_
-        s_coef = coef;
+        s_coef = coef * c.grad_scale;
         if (blockIdx.x == 0 && norm_out) *norm_out = norm;
     }
     __syncthreads();
@@ -99,6 +100,13 @@ size_t renet_adam_workspace(size_t n) {
 int renet_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, float max_norm, int step, int zero_grad, float* workspace,
                     size_t workspace_bytes, float* grad_norm_out, void* stream) {
+    return renet_adam_step_scaled(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, max_norm, 1.f, step, zero_grad,
+                                  workspace, workspace_bytes, grad_norm_out, stream);
+}
+
+int renet_adam_step_scaled(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, float max_norm, float grad_scale, int step, int zero_grad,
+                           float* workspace, size_t workspace_bytes, float* grad_norm_out, void* stream) {
     if (step < 1 || lr < 0.f || beta1 < 0.f || beta1 >= 1.f || beta2 < 0.f || beta2 >= 1.f) return RENET_ERR_BADARG;
     if (n == 0) return RENET_OK;
     if (workspace_bytes < renet_adam_workspace(n)) return RENET_ERR_WORKSPACE;
@@ -115,6 +123,7 @@ int renet_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, 
     c.bc1 = 1.f - powf(beta1, (float)step);
     c.bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     c.zero_grad = zero_grad;
+    c.grad_scale = grad_scale;
     RENET_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, workspace, blocks, c,
                        grad_norm_out);
     RENET_LAUNCH_CHECK();

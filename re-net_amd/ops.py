@@ -41,10 +41,35 @@ def _c(t):
 # (4 uses per direction, 18 MB each) and linear.weight (55 MB) that removes ~45 add/fill kernels per step.
 INPLACE_GRADS = True
 
-# Set by parallel.HipAdam when gradients are exchanged between ranks: called with the parameter right after a
-# Function accumulated its contribution into param.grad in place (the score head's weight and bias), so that the
-# all-reduce of that bucket can start while the rest of the backward pass runs.
-grad_done_hook = None
+# Registered by parallel.HipAdam when gradients are exchanged between ranks: callbacks keyed by PARAMETER identity,
+# called with the parameter right after a Function accumulated its contribution into param.grad in place (the score
+# head's weight and bias), so that the all-reduce of that bucket can start while the rest of the backward pass runs.
+# A registry, not one global slot: two optimizers (RENet + RENet_global, tests) each keep their own hooks, and
+# unregister_grad_done_hook releases everything the callback keeps alive.
+_grad_done_hooks = {}          # id(param) -> {token: callback}
+_hook_tokens = {'next': 0}
+
+
+def register_grad_done_hook(params, callback):
+    _hook_tokens['next'] += 1
+    token = _hook_tokens['next']
+    for p in params:
+        _grad_done_hooks.setdefault(id(p), {})[token] = callback
+    return token
+
+
+def unregister_grad_done_hook(token):
+    for pid in list(_grad_done_hooks):
+        _grad_done_hooks[pid].pop(token, None)
+        if not _grad_done_hooks[pid]:
+            del _grad_done_hooks[pid]
+
+
+def grad_done(param):
+    cbs = _grad_done_hooks.get(id(param))
+    if cbs:
+        for cb in list(cbs.values()):
+            cb(param)
 
 # Test hook (tests/test_gpu_config.py): when set to a callable(name, tensor), the training path reports its
 # internal activations (GRU final states, entity logits before the in-place CE) -- None in production.
@@ -282,6 +307,7 @@ class MultiGRUFn(Function):
                 # of dX stays unwritten
                 dxx = torch.empty_like(xx)
                 K.gemm(dgi, w_ihs[k][:, :live], out=dxx[:, :live])
+                dxx[:, live:].zero_()         # defined values for any other consumer (hooks, detect_anomaly): 6 MB
             else:
                 dxx = K.gemm(dgi, w_ihs[k])
             out += [dxx, dwi, dwh, dbi, dbh]
@@ -346,9 +372,9 @@ class HeadCEFn(Function):
             d_b = None
         else:
             d_b = K.colsum(dlogits)
-        if grad_done_hook is not None and t_w is not None and t_b is not None:
-            grad_done_hook(ctx.srcs[2])
-            grad_done_hook(ctx.srcs[3])
+        if t_w is not None and t_b is not None:
+            grad_done(ctx.srcs[2])
+            grad_done(ctx.srcs[3])
         da_rows, dh, dc_rows = K.concat3_bwd(dfeat, d, parts, drop_p, seed)
         d_a = d_c = None
         if t_a is not None:

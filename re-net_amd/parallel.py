@@ -11,7 +11,7 @@ W = 8, a fifth of the step, so the exchange is cut into TWO large buckets (few, 
 per-link bound) and the first one overlaps the backward pass: the score head's parameters (linear.weight +
 bias: 55 of the 81 MB) receive their last gradient contribution when the second entity-head backward has run
 -- the FIRST thing the backward pass does -- so their all-reduce is launched on a side stream at that point
-(ops.grad_done_hook) and runs under the GRU / RGCN backward (~1.5 ms); the rest follows in step().
+(ops.register_grad_done_hook) and runs under the GRU / RGCN backward (~1.5 ms); the rest follows in step().
 No measured multi-GPU curve exists yet (one-GPU boxes only): the logic is covered by world-size-2 gloo tests.
 """
 import os
@@ -81,28 +81,47 @@ class OverlapReducer(object):
     """Two-bucket gradient all-reduce with the first bucket overlapped with the backward pass.
 
     early = the flat region of the parameters whose gradient is complete EARLY in the backward pass (RE-Net: the
-    entity score head, model.py:38, whose backward runs first); `early_uses` in-place accumulations complete it
-    per step (the subject and the object pass: 2).  on_grad_done(param) is called by the autograd Functions right
-    after they accumulated into param.grad (ops.grad_done_hook); when the early bucket is complete its all-reduce
-    is issued asynchronously on a side stream (device tensors) / as an async gloo op (CPU tensors) and proceeds
-    while the rest of the backward pass runs.  finish() waits for it, reduces the remaining bucket and averages."""
+    entity score head, model.py:38, whose backward runs first).  A step DECLARES how many in-place accumulations
+    complete that bucket (`begin_step(head_passes)`: 2 for the subject + object passes, 1 for the merged pass);
+    on_grad_done(param) is called by the autograd Functions right after they accumulated into param.grad
+    (ops.grad_done_hooks); when the declared count is reached the bucket's all-reduce is issued asynchronously on a
+    side stream (device tensors) / as an async gloo op (CPU tensors) and proceeds while the rest of the backward
+    pass runs.  The tail regions (everything else: GRU / RGCN / embeddings, 26 MB at ICEWS18 sizes) are issued
+    asynchronously on the same side stream in finish(), i.e. right behind the last backward kernel, so that all
+    regions are in flight together; finish() then waits for all of them.  (The tail's gradients are only complete
+    when the LAST backward kernel has run -- ent_embeds receives contributions from the very last scatter-add --
+    so there is nothing left to overlap it with but the early bucket's own transfer.)
+
+    Safety: a backward pass outside a declared step (smoke / eval with grad, an exception between
+    backward and step, more accumulations than declared) never launches early -- the counter only runs between
+    begin_step() and finish(), hook calls after the launch raise, and finish() falls back to the synchronous
+    exchange whenever the early launch did not happen."""
 
     def __init__(self, flat_grads, early_span, early_params, early_uses=2, group=None):
         self.fg, self.group = flat_grads, group
         self.lo, self.n = early_span
         self.early_ids = {id(p) for p in early_params}
-        self.early_uses = early_uses * len(self.early_ids)
-        self.count, self.work = 0, None
+        self.uses_per_pass = len(self.early_ids)
+        self.early_uses = early_uses * self.uses_per_pass
+        self.count, self.work, self.armed = 0, None, False
         self.average = True                       # False: SUM (ranks hold disjoint shares of one batch, bench --scaling exact)
         f = flat_grads.flat
         self.early = f[self.lo:self.lo + self.n]
         self.rest = [f[:self.lo], f[self.lo + self.n:]]
         self.stream = torch.cuda.Stream() if f.is_cuda else None
 
+    def begin_step(self, head_passes=2, average=True):
+        """Arms the early launch for ONE step: `head_passes` backward passes of the early bucket's parameters will
+        run before finish().  Clears any state a previous, unfinished step left behind."""
+        if self.work is not None:                 # an abandoned step's collective: complete it before re-arming
+            self._wait_early()
+        self.early_uses = int(head_passes) * self.uses_per_pass
+        self.average = bool(average)
+        self.count, self.work, self.armed = 0, None, True
+
     def set_uses(self, n):
-        """in-place accumulations that complete the early bucket per step: 2 for the subject + object passes,
-        1 when a step runs them as one merged pass (RENet.loss_prepared_both)"""
-        self.early_uses = n * len(self.early_ids)
+        """Deprecated spelling of begin_step(head_passes=n) (kept for callers of round 2)."""
+        self.begin_step(n, self.average)
 
     def active(self):
         # RENET_FORCE_REDUCER=1 runs the collectives even in a one-rank group (a no-op exchange): lets a one-GPU box
@@ -111,36 +130,61 @@ class OverlapReducer(object):
             return False
         return dist.get_world_size(self.group) > 1 or os.environ.get('RENET_FORCE_REDUCER') == '1'
 
-    def on_grad_done(self, param):
-        if id(param) not in self.early_ids or not self.active():
-            return
-        self.count += 1
-        if self.count == self.early_uses and self.work is None:
-            if self.stream is not None:
-                self.stream.wait_stream(torch.cuda.current_stream())      # the accumulating kernels are queued
-                with torch.cuda.stream(self.stream):
-                    self.work = dist.all_reduce(self.early, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            else:
-                self.work = dist.all_reduce(self.early, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+    def _async(self, t):
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())          # the accumulating kernels are queued
+            with torch.cuda.stream(self.stream):
+                return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def finish(self):
-        """Call after backward(): completes the exchange; the flat buffer then holds the rank-averaged gradient."""
+    def _wait_early(self):
+        self.work.wait()                          # device: makes the current stream wait for the side stream
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.work = None
+
+    def on_grad_done(self, param):
+        if id(param) not in self.early_ids or not self.armed or not self.active():
+            return
+        if self.work is not None:
+            # the bucket is being reduced on the side stream: one more in-place accumulation into it would race
+            raise RuntimeError('OverlapReducer: a backward pass accumulated into the score head\'s gradient after its '
+                               'all-reduce was launched (begin_step(head_passes=%d) declared too few passes)'
+                               % (self.early_uses // max(self.uses_per_pass, 1)))
+        self.count += 1
+        if self.count == self.early_uses:
+            self.work = self._async(self.early)
+
+    def finish(self, fold_scale=False):
+        """Call after backward(): completes the exchange; the flat buffer then holds the rank-combined gradient:
+        the SUM when `average` is False, else the mean -- divided in place here, or (fold_scale=True, HipAdam) left
+        as the sum with `pending_scale` = 1 / world for the optimizer kernel to apply (no extra pass over 81 MB)."""
+        armed, self.armed = self.armed, False
+        self.pending_scale = 1.0
         if not self.active():
             self.count, self.work = 0, None
             return
         world = dist.get_world_size(self.group)
-        for t in self.rest:
-            if t.numel():
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        if self.work is None:                     # the early bucket never completed early (e.g. empty batches)
-            dist.all_reduce(self.early, op=dist.ReduceOp.SUM, group=self.group)
+        if self.work is not None and self.count != self.early_uses:      # cannot happen (the hook raises); belt and braces
+            raise RuntimeError('OverlapReducer: early bucket launched after %d of %d accumulations'
+                               % (self.count, self.early_uses))
+        # tail bucket(s): asynchronously as well, so that the two regions' transfers are both in flight
+        tails = [self._async(t) for t in self.rest if t.numel()]
+        if self.work is None:                     # never launched early (undeclared step, empty batches, fewer passes)
+            tails.append(self._async(self.early))
         else:
-            self.work.wait()                      # device: makes the current stream wait for the side stream
-            if self.stream is not None:
-                torch.cuda.current_stream().wait_stream(self.stream)
+            self._wait_early()
+        for w in tails:
+            w.wait()
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
         if self.average:
-            self.fg.flat.div_(world)
+            if fold_scale:
+                self.pending_scale = 1.0 / world
+            else:
+                self.fg.flat.div_(world)
         self.count, self.work = 0, None
+        del armed
 
 
 def shard_indices(perm, step, rank, world, batch_size):
@@ -171,7 +215,11 @@ class FlatParams(object):
 
 class HipAdam(object):
     """torch.optim.Adam(lr, weight_decay) + clip_grad_norm_(max_norm) + zero_grad as ONE fused HIP step on
-    the flat buffers (renet_adam_step).  Matches train.py:61,140-142."""
+    the flat buffers (renet_adam_step).  Matches train.py:61,140-142.
+
+    Data-parallel use: wrap every step in `with opt.step_scope(head_passes=...)` (declares how many backward passes
+    of the score head the step runs, so that its 55 MB gradient bucket can be all-reduced under the rest of the
+    backward pass); a step outside a scope still works -- the whole exchange then happens inside step()."""
 
     def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0):
         import renet_hip as K
@@ -184,20 +232,64 @@ class HipAdam(object):
         self.t = 0
         self.norm = torch.zeros(1, device=self.m.device, dtype=torch.float32)
         self.reducer = None
+        self._hook = None
         names = [n for n, _ in module.named_parameters()]
         if 'linear.weight' in names and 'linear.bias' in names:       # RENet: overlap the score head's bucket
-            import ops
             early = [p for n, p in module.named_parameters() if n in ('linear.weight', 'linear.bias')]
             self.reducer = OverlapReducer(self.grads, self.grads.span(('linear.weight', 'linear.bias'), module), early)
-            ops.grad_done_hook = self.reducer.on_grad_done
+            # registry keyed by parameter identity (a second optimizer must not steal a global hook);
+            # close() / garbage collection of this optimizer unregisters
+            import ops
+            self._hook = ops.register_grad_done_hook(early, self.reducer.on_grad_done)
+
+    def close(self):
+        """Unregisters the gradient hooks (the reducer, the flat buffers and the parameters are released with it)."""
+        if self._hook is not None:
+            import ops
+            ops.unregister_grad_done_hook(self._hook)
+            self._hook = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown
+            pass
+
+    def step_scope(self, head_passes=2, average=True):
+        """Context manager around ONE training step (forward, backward, step())."""
+        return _StepScope(self, head_passes, average)
 
     def step(self):
         """all-reduce (if distributed; the score head's bucket was started during backward) -> clip -> Adam ->
-        zero_grad."""
+        zero_grad.  The 1/world of the gradient average is folded into the optimizer kernel (no pass over 81 MB)."""
+        scale = 1.0
         if self.reducer is not None:
-            self.reducer.finish()
-        else:
-            self.grads.allreduce_mean()
+            self.reducer.finish(fold_scale=True)
+            scale = self.reducer.pending_scale
+        elif dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM)
+            scale = 1.0 / dist.get_world_size()
         self.t += 1
         self.K.adam_step(self.params.flat, self.grads.flat, self.m, self.v, self.lr, self.betas[0], self.betas[1],
-                         self.eps, self.wd, self.max_norm, self.t, True, self.norm)
+                         self.eps, self.wd, self.max_norm, self.t, True, self.norm, grad_scale=scale)
+
+
+class _StepScope(object):
+    def __init__(self, opt, head_passes, average):
+        self.opt, self.head_passes, self.average = opt, head_passes, average
+
+    def __enter__(self):
+        if self.opt.reducer is not None:
+            self.opt.reducer.begin_step(self.head_passes, self.average)
+        return self.opt
+
+    def __exit__(self, exc_type, exc, tb):
+        r = self.opt.reducer
+        if r is not None and r.armed:
+            # the step was abandoned before step() (exception, early exit): complete a launched collective so that
+            # no rank is left with a pending RCCL op, and disarm
+            r.armed = False
+            if r.work is not None:
+                r._wait_early()
+            r.count = 0
+        return False

@@ -11,6 +11,14 @@ import os
 _job = {}
 
 
+def worker_budget(world=1, cpus=None, cap=24):
+    """Builder worker processes PER RANK such that all ranks of a node together (world ranks x (workers + the
+    training thread)) stay within the host's cores: cpus // (2 * world), at least 1, at most `cap` (one batch
+    takes ~14 ms to build and ~4 ms to consume: beyond ~8 workers per rank the device is the bottleneck)."""
+    cpus = cpus or os.cpu_count() or 2
+    return max(1, min(int(cap), cpus // (2 * max(int(world), 1))))
+
+
 def _run(step):
     return _job['fn'](step)
 

@@ -77,6 +77,9 @@ _SIGNATURES = {
     'renet_adam_workspace': (c_size_t, [c_size_t]),
     'renet_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,
                                 c_float, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    'renet_adam_step_scaled': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,
+                                       c_float, c_float, c_float, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p,
+                                       c_void_p]),
     'renet_host_filter_edges': (ctypes.c_int64, [c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p,
                                                  ctypes.c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'renet_host_filter_edges_sparse': (ctypes.c_int64, [c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int64, c_void_p,
@@ -648,11 +651,12 @@ def segment_pool_bwd(dout, seg_ptr, arg, num_graphs, is_max, n):
     return dh
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, max_norm, step, zero_grad=True, norm_out=None):
-    """Fused clip + Adam + zero_grad on flat fp32 buffers (in place)."""
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, max_norm, step, zero_grad=True, norm_out=None,
+              grad_scale=1.0):
+    """Fused clip + Adam + zero_grad on flat fp32 buffers (in place); the gradient is g * grad_scale."""
     n = p.numel()
     nbytes = lib().renet_adam_workspace(n)
     ws = torch.empty(nbytes // 4, device=p.device, dtype=torch.float32)
-    _check(lib().renet_adam_step(_f32(p), _f32(g), _f32(m), _f32(v), n, float(lr), float(beta1), float(beta2),
-                                 float(eps), float(weight_decay), float(max_norm), int(step), int(zero_grad),
-                                 ws.data_ptr(), nbytes, _f32(norm_out), _stream()), 'adam_step')
+    _check(lib().renet_adam_step_scaled(_f32(p), _f32(g), _f32(m), _f32(v), n, float(lr), float(beta1), float(beta2),
+                                        float(eps), float(weight_decay), float(max_norm), float(grad_scale), int(step),
+                                        int(zero_grad), ws.data_ptr(), nbytes, _f32(norm_out), _stream()), 'adam_step')

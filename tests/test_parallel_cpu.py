@@ -142,17 +142,26 @@ def _renet_worker(rank, world, port, out):
     flat = parallel.FlatGrads(net)
     early = [p for n, p in net.named_parameters() if n in ('linear.weight', 'linear.bias')]
     red = parallel.OverlapReducer(flat, flat.span(('linear.weight', 'linear.bias'), net), early)
-    ops.grad_done_hook = red.on_grad_done
     started = []
     orig = red.on_grad_done
 
     def spy(p):
         orig(p)
         started.append(red.work is not None)
-    ops.grad_done_hook = spy
+    ops.register_grad_done_hook(early, spy)
     res = []
+    # a backward pass OUTSIDE a declared step (smoke / eval with grad / exception before step()) must
+    # never launch the early bucket, and finish() must still produce the exchanged gradient (synchronous path)
+    idx = parallel.shard_indices(perm, 5, rank, world, 96)
+    _renet_grads(net, quads, gd, hs, ho, idx, pair=False)
+    assert started and not any(started), started
+    red.finish()
+    undeclared = flat.flat.clone()
+    flat.zero()
+    del started[:]
     for step in range(2):
         idx = parallel.shard_indices(perm, step, rank, world, 96)
+        red.begin_step(head_passes=2)
         _renet_grads(net, quads, gd, hs, ho, idx, pair=(step == 1))
         assert flat.check_views()
         assert started[-1] and not any(started[:-1][-3:]), started      # launched by the LAST of the 4 notifications
@@ -160,8 +169,19 @@ def _renet_worker(rank, world, port, out):
         res.append(flat.flat.clone())
         flat.zero()
         del started[:]
+    # declaring too few head passes: the second pass would accumulate into a bucket that is being reduced -> error
+    red.begin_step(head_passes=1)
+    idx = parallel.shard_indices(perm, 0, rank, world, 96)
+    try:
+        _renet_grads(net, quads, gd, hs, ho, idx, pair=False)
+        raised = False
+    except RuntimeError as e:
+        raised = 'declared too few passes' in str(e)
+    red.begin_step(head_passes=2)          # re-arming completes the abandoned collective on every rank
+    red.armed = False
+    flat.zero()
     seeds = [ops.next_seed() for _ in range(3)]
-    torch.save({'flat': res, 'seeds': seeds}, out % rank)
+    torch.save({'flat': res, 'seeds': seeds, 'undeclared': undeclared, 'raised': raised}, out % rank)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -173,6 +193,8 @@ def test_renet_two_ranks_equal_accumulation_over_the_same_batches(tmp_path):
     mp.spawn(_renet_worker, args=(world, port, out), nprocs=world, join=True)
     got = [torch.load(out % r) for r in range(world)]
     assert torch.equal(got[0]['flat'][0], got[1]['flat'][0])          # both ranks hold the same averaged gradient
+    assert torch.equal(got[0]['undeclared'], got[1]['undeclared']) and float(got[0]['undeclared'].abs().max()) > 0
+    assert got[0]['raised'] and got[1]['raised']
     assert set(got[0]['seeds']).isdisjoint(got[1]['seeds'])           # dropout seeds differ per rank
     import cpu_abi_emulation
     undo = cpu_abi_emulation.install()
@@ -209,9 +231,8 @@ def _renet_exact_worker(rank, world, port, out):
     flat = parallel.FlatGrads(net)
     early = [p for n, p in net.named_parameters() if n in ('linear.weight', 'linear.bias')]
     red = parallel.OverlapReducer(flat, flat.span(('linear.weight', 'linear.bias'), net), early)
-    red.average = False
-    red.set_uses(1)
-    ops.grad_done_hook = red.on_grad_done
+    ops.register_grad_done_hook(early, red.on_grad_done)
+    red.begin_step(head_passes=1, average=False)
     idx = perm[:120]
     prep = net.prepare_both(quads[idx], hs.take(idx), ho.take(idx), gd, shard=(rank, world))
     loss = net.loss_prepared_both(prep)
@@ -246,3 +267,40 @@ def test_exact_split_of_one_batch_over_two_ranks(tmp_path):
         assert float((got[0]['flat'] - flat.flat).abs().max()) <= 1e-5 * scale
     finally:
         undo()
+
+
+# ---------------------------------------------------------------------------------------------
+# 8 ranks on one node, each with its own builder workers (pipeline.BatchPrefetcher): the per-rank worker budget
+# must keep the node within its cores ("8 ranks x 16 prefetch workers do not oversubscribe"), and the
+# prefetchers of all ranks must deliver their batches in step order while running side by side.
+# ---------------------------------------------------------------------------------------------
+def _prefetch_worker(rank, world, port, out):
+    import pipeline
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    cpus = 256                                  # an 8-GPU MI355X node's host
+    w = pipeline.worker_budget(world, cpus=cpus)
+    tot = torch.tensor([w + 1])                 # workers + the training thread of this rank
+    dist.all_reduce(tot)
+    here = pipeline.worker_budget(world)        # this container (8 cores): 1 worker per rank => built inline
+    pf = pipeline.BatchPrefetcher(lambda step: (rank, step, int(np.arange(step + 1).sum())), range(10, 22),
+                                  max(here, 2) if rank == 0 else here)     # rank 0 really forks two workers
+    got = list(pf)
+    torch.save({'total': int(tot), 'cpus': cpus, 'workers': w, 'here': here, 'got': got}, out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_with_prefetch_workers_stay_within_the_cores(tmp_path):
+    import pipeline
+    world, port, out = 8, _free_port(), str(tmp_path / 'p%d.pt')
+    mp.spawn(_prefetch_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        g = torch.load(out % r)
+        assert g['workers'] == 16 and g['total'] <= g['cpus'] // 1 and g['total'] == world * 17
+        assert g['got'] == [(r, s, s * (s + 1) // 2) for s in range(10, 22)]
+    for cpus in (8, 32, 96, 128, 256):
+        for w in (1, 2, 4, 8):
+            n = pipeline.worker_budget(w, cpus=cpus)
+            assert n >= 1 and (n == 1 or w * (n + 1) <= cpus)

@@ -140,6 +140,103 @@ def gen_global(name):
     np.savez_compressed(os.path.join(OUT, 'config_%s.npz' % name), **out)
 
 
+def gen_eval(name):
+    """test.py's evaluation loop (model.RENet.evaluate_filter, model.py:216-419) of the UNMODIFIED reference at
+    config scale: N_ent 23 033, R 256, num_k 1000, over quadruples of the first validation timestamps -- every
+    timestamp advance samples 2 x 1000 entities and scores a [256 x 23 033] joint distribution for each.  The
+    random entity samples, the shadowing entities (unsorted-top-k order, see tools/make_golden.py:gen_eval) and the
+    predicted graphs are recorded.  Writes tests/golden/config_<name>.npz."""
+    import copy
+    from oracle import renet_oracle as O
+    ref = ref_loader.load()
+    case = C.build_eval_case(name)
+    spec, num_ent, num_rels = case['spec'], case['num_ent'], case['num_rels']
+    d, seq_len, num_k = spec['hidden'], spec['seq_len'], spec['num_k']
+    tr, va, te = case['train'], case['valid'], case['test']
+    t0 = time.time()
+    (s_hist, s_hist_t), (o_hist, o_hist_t), st = O.build_histories(tr, num_ent, history_len=seq_len)
+    (vs, vst), (vo, vot), st = O.build_histories(va, num_ent, history_len=seq_len, state=st)
+    (ts_, tst), (to_, tot), st = O.build_histories(te, num_ent, history_len=seq_len, state=st)
+    print('%s: histories %.0f s' % (name, time.time() - t0), flush=True)
+    samples, cand_topk = [], []
+    Cat = torch.distributions.categorical.Categorical
+    orig_sample, orig_topk = Cat.sample, torch.topk
+
+    def rec_sample(self, shape=torch.Size()):
+        o = orig_sample(self, shape)
+        samples.append(o.clone())
+        print('  sampled %d entities (%d distinct) at %.0f s' % (o.numel(), len(set(o.tolist())), time.time() - t0),
+              flush=True)
+        return o
+
+    def rec_topk(inp, k, *a, **kw):
+        o = orig_topk(inp, k, *a, **kw)
+        if inp.dim() == 1 and inp.numel() % num_k == 0 and inp.numel() <= num_k * num_k and k == num_k \
+                and inp.numel() != num_rels * num_ent:
+            cand_topk.append(o[1].clone())
+        return o
+    ranks, losses = [], []
+    with ref_loader.cpu_mode(), torch.no_grad():
+        graph_dict = {}
+        ts, starts = np.unique(tr[:, 3], return_index=True)
+        ends = np.concatenate((starts[1:], [len(tr)]))
+        for t, a, b in zip(ts, starts, ends):
+            graph_dict[int(t)] = ref.utils.get_big_graph(tr[a:b, :3], num_rels)
+        n_graphs0 = len(graph_dict)
+        model = ref.model.RENet(num_ent, d, num_rels, dropout=0.0, model=0, seq_len=seq_len, num_k=num_k)
+        gmodel = ref.global_model.RENet_global(num_ent, d, num_rels, dropout=0.0, model=0, seq_len=seq_len,
+                                               num_k=num_k, maxpool=1)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in case['params'].items()})
+        gmodel.load_state_dict({k: torch.from_numpy(v) for k, v in case['gparams'].items()})
+        model.eval(); gmodel.eval()
+        total = torch.from_numpy(np.concatenate((tr, va, te)))
+        valid = torch.from_numpy(va)
+        model.global_emb = gmodel.get_global_emb(np.unique(tr[:, 3]), graph_dict)
+        model.graph_dict = graph_dict
+        model.init_history(tr, (s_hist, s_hist_t), (o_hist, o_hist_t), valid, (vs, vst), (vo, vot), te,
+                           (ts_, tst), (to_, tot))
+        model.latest_time = valid[0][3]
+        print('  state ready at %.0f s' % (time.time() - t0), flush=True)
+        Cat.sample, torch.topk = rec_sample, rec_topk
+        try:
+            for i in case['eval_idx']:
+                rk, loss = model.evaluate_filter(valid[i], (vs[i], vst[i]), (vo[i], vot[i]), gmodel, total)
+                ranks.append(rk)
+                losses.append(loss.item())
+                print('  quad %d: ranks %s loss %.5f at %.0f s' % (i, rk.tolist(), loss.item(), time.time() - t0),
+                      flush=True)
+        finally:
+            Cat.sample, torch.topk = orig_sample, orig_topk
+    assert len(cand_topk) == len(samples) and len(samples) % 2 == 0, (len(cand_topk), len(samples))
+    # the candidate index refers to the de-duplicated key order of preds_list (dict insertion order == first
+    # occurrence order of the samples): map through it
+    shadow = []
+    for a in range(len(samples) // 2):
+        row = []
+        for side in (0, 1):
+            smp = samples[2 * a + side].tolist()
+            keys = list(dict.fromkeys(smp))
+            # model.py:229-235 keys preds_list by TENSOR objects (identity hash): every sample is its own key,
+            # duplicates included -- the candidate index therefore addresses the raw sample list
+            row.append(int(smp[int(cand_topk[2 * a + side][-1]) // num_k]))
+        shadow.append(row)
+    out = dict(d=d, seq_len=seq_len, num_k=num_k, eval_idx=case['eval_idx'], shadow=np.asarray(shadow, np.int64).reshape(-1, 2),
+               ranks=np.asarray(ranks), losses=np.asarray(losses),
+               samples=np.stack([x.numpy() for x in samples]), n_new_graphs=np.int64(len(graph_dict) - n_graphs0))
+    trip = []
+    for t in list(graph_dict.keys())[n_graphs0:]:
+        g = graph_dict[t]
+        m = g.number_of_edges() // 2
+        ids = g.ndata['id'].view(-1).numpy()
+        q = np.stack((ids[g._src[:m].numpy()], g.edata['type_s'][:m].numpy(), ids[g._dst[:m].numpy()],
+                      np.full(m, int(t))), axis=1)
+        trip.append(q[np.lexsort((q[:, 2], q[:, 1], q[:, 0]))])
+    out['new_graph_quads'] = np.concatenate(trip) if trip else np.zeros((0, 4), np.int64)
+    np.savez_compressed(os.path.join(OUT, 'config_%s.npz' % name), **out)
+    print('  done: %d new graphs, %d predicted quads, %.0f s' % (out['n_new_graphs'], len(out['new_graph_quads']),
+                                                                   time.time() - t0), flush=True)
+
+
 if __name__ == '__main__':
-    for n in (sys.argv[1:] or sorted(C.CASES) + sorted(C.GLOBAL_CASES)):
-        (gen_global if n in C.GLOBAL_CASES else gen)(n)
+    for n in (sys.argv[1:] or sorted(C.CASES) + sorted(C.GLOBAL_CASES) + sorted(C.EVAL_CASES)):
+        (gen_global if n in C.GLOBAL_CASES else gen_eval if n in C.EVAL_CASES else gen)(n)
