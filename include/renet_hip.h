@@ -47,6 +47,11 @@ int renet_version(void);
 int renet_gather_rows(const float* table, const int32_t* idx, int n, int D, float* out, void* stream);
 int renet_segment_add(const float* src, const int32_t* order, const int32_t* seg_ptr,
                       const int32_t* seg_target, int U, int D, float* dst, void* stream);
+/* Two segmented adds that share ONE plan in one launch: dst0[target[u]] += sum of src0 rows, dst1[target[u]] += sum
+ * of src1 rows (the first RGCN layer's backward reduces both the message gradient and the self-loop gradient of the
+ * batch graph's nodes to entity rows, keyed by the same node -> entity map). */
+int renet_segment_add2(const float* src0, const float* src1, const int32_t* order, const int32_t* seg_ptr,
+                       const int32_t* seg_target, int U, int D, float* dst0, float* dst1, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * RGCN block-diagonal gather-SpMM  (RGCN.py:79-94 msg_func + fn.sum + apply_func, fused with the
@@ -97,6 +102,27 @@ int renet_rgcn_gather_items(const float* x, int D, const int32_t* it_src, const 
                             int transpose_w, const float* addend, float drop_p, uint64_t seed, int relu,
                             float* out, int N, const int32_t* heavy_rows, int n_heavy, int src_limit,
                             int addend_rows, int pruned, void* stream);
+
+/* The FIRST RGCN layer addressed through the entity table (utils.py:239 + RGCN.py:35,79-94): the reference
+ * materialises h0 = ent_embeds[id] ([N, D], one row per node of the batch graph) and multiplies it by W_loop; since
+ * h0 @ W_loop == (ent_embeds @ W_loop)[id], the layer can read BOTH its source rows and its self-loop addend from
+ * [table_rows, D] tables (ent_embeds and ent_embeds @ W_loop, computed once per step on N_ent rows instead of N):
+ *   out[v] = act( scale[v] * sum_{e=(u->v)} blockmul(table[row_map[u]], W[type_e]) + drop(addend_table[row_map[v]]) )
+ * it_src_t / it_type_t / col_t are the item stream / CSR columns with the source rows already composed through
+ * row_map (renet_compose_table_items); flush items carry row_map[v] inside it_type (-3 - row_map[v]).  Forward
+ * only (the backward pass of the layer is the ordinary transposed gather on [N, D] gradients). */
+int renet_rgcn_gather_items_table(const float* table, int table_rows, int D, const int32_t* it_src_t,
+                                  const int32_t* it_type_t, const int32_t* grp_ptr, int n_groups,
+                                  const int32_t* row_ptr, const int32_t* col_t, const int32_t* etype,
+                                  const int32_t* row_map, const float* scale, const float* W, int T, int type_shift,
+                                  const float* addend_table, float drop_p, uint64_t seed, int relu, float* out, int N,
+                                  const int32_t* heavy_rows, int n_heavy, void* stream);
+/* Composes the per-batch index arrays of the table-addressed layer on the device (once per batch):
+ * it_src_t / it_type_t [n_items], col_t [E] (CSR columns), e_src_t [E] (relation-bucketed edge list of
+ * renet_rgcn_bwd_w) = the plain arrays with every SOURCE row u replaced by row_map[u]. */
+int renet_compose_table_items(const int32_t* row_map, const int32_t* it_src, const int32_t* it_type, int n_items,
+                              const int32_t* col, const int32_t* e_src, int E, int32_t* it_src_t,
+                              int32_t* it_type_t, int32_t* col_t, int32_t* e_src_t, void* stream);
 
 /* Backward prologue of one RGCN layer (element-wise, RGCN.py:42-50 + :93-94 reversed):
  *   g_pre = g_out * (relu ? out > 0 : 1);  gn = g_pre * norm[v];  g_loop = g_pre * dropmask       */

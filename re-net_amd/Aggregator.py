@@ -118,7 +118,7 @@ class RGCNAggregator(nn.Module):
 
     def encode(self, g, ent_embeds, rel_embeds, reverse):
         """Device side: h0 gather, two RGCN layers, packed sequence assembly (Aggregator.py:136-165)."""
-        g.ndata['h'] = ops.GatherRowsFn.apply(ent_embeds, g.node_ent, g.plan_node_ent)      # utils.py:239
+        g.ndata['h'] = ops.TableRows(ent_embeds, g.node_ent, g.plan_node_ent)               # utils.py:239, deferred
         self.rgcn1(g, reverse)
         g.out_rows = g.nA               # only the subject rows of layer 2 are ever read (Aggregator.py:139-140)
         self.rgcn2(g, reverse)
@@ -181,7 +181,7 @@ class RGCNAggregator_global(nn.Module):
         (Aggregator.py:44-61 / 87-105) -> [len(times), h]."""
         hb = G.build_full_graphs(graph_dict, times)
         g = G.DeviceGraph(hb, ent_embeds.device)
-        g.ndata['h'] = ops.GatherRowsFn.apply(ent_embeds, g.node_ent, g.plan_node_ent)
+        g.ndata['h'] = ops.TableRows(ent_embeds, g.node_ent, g.plan_node_ent)               # deferred gather
         self.rgcn1(g, reverse)
         self.rgcn2(g, reverse)
         h2 = g.ndata.pop('h')

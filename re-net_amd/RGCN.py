@@ -50,6 +50,17 @@ class RGCNBlockLayer(RGCNLayer):
 
     def forward(self, g, reverse):
         p = self.drop_p if self.training else 0.0
+        h_in = g.ndata['h']
+        if isinstance(h_in, ops.TableRows):
+            # first layer of a pass: h0 = table[idx] is never materialised (ops.RGCNTableLayerFn); beyond the 2 GiB
+            # reach of the kernels' 32-bit buffer offsets fall back to the materialised rows
+            if getattr(g, 'out_rows', None) is None and hasattr(g, 'grp_ptr') and \
+                    max(g.N, h_in.table.shape[0]) * h_in.table.shape[1] * 4 < (1 << 31):
+                g.ndata['h'] = ops.RGCNTableLayerFn.apply(h_in.table, self.weight, self.loop_weight, g, bool(reverse),
+                                                          self.activation is not None, p,
+                                                          ops.next_seed() if p > 0 else 0)
+                return g
+            g.ndata['h'] = h_in.materialise()
         # g.out_rows (set by the aggregator for the LAST layer) = evaluate only the first out_rows rows
         h = ops.RGCNLayerFn.apply(g.ndata['h'], self.weight, self.loop_weight, g, bool(reverse),
                                   self.activation is not None, p, ops.next_seed() if p > 0 else 0,

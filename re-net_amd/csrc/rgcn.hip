@@ -65,6 +65,8 @@ struct GatherArgs {
     int n_heavy, heavy_thresh;
     int src_limit;              // edges whose source row is >= src_limit are skipped (pruned layer-2 backward)
     int addend_rows;            // rows >= addend_rows have no addend
+    const int32_t* row_map;     // layer 1 on the entity table: addend row of output row v = row_map[v] (hub rows; the
+                                // item stream carries it inside its flush items); nullptr = v
     int N, T, shift, relu;
     DropCfg drop;
 };
@@ -351,6 +353,9 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, uint32_t vo
 
 constexpr int kItemFlush = -1;   // it_type of a flush item
 constexpr int kItemNop = -2;     // lanes past the end of a group
+// it_type <= kItemFlushMap: a flush item whose self-loop addend lives in row (kItemFlushMap - it_type) of the addend
+// tensor instead of row it_src (layer 1 on the entity table: addend = (ent_embeds @ W_loop)[entity of the row])
+constexpr int kItemFlushMap = -3;
 
 template <int SI, int NCH, bool TR>
 __device__ __forceinline__ void row_epilogue(const GatherArgs& g, int row, bool has_ad, float sc, int lane,
@@ -412,11 +417,12 @@ __device__ __forceinline__ void gather_item_group(const ItemArgs& a, int grp) {
             const int src = __builtin_amdgcn_readlane(my_src, idx);            // wave-uniform (SGPR)
             const int t = (k + u) < n ? __builtin_amdgcn_readlane(my_t, idx) : kItemNop;   // (n may be 64)
             const bool edge = t >= 0 && src < g.src_limit;
-            const bool flush = t == kItemFlush;
+            const bool flush = t == kItemFlush || t <= kItemFlushMap;
             const bool flush_ad = flush && g.addend != nullptr && src < g.addend_rows;
             int tt = t + g.shift;
             if (tt >= g.T) tt -= g.T;
-            const uint32_t xs = (edge || flush_ad) ? (uint32_t)src * ROWB : 0u;
+            const int ldrow = t <= kItemFlushMap ? kItemFlushMap - t : src;      // row the x / addend load reads
+            const uint32_t xs = (edge || flush_ad) ? (uint32_t)ldrow * ROWB : 0u;
             const uint32_t ws = edge ? (uint32_t)tt * WROWB : 0u;
             scv[u] = sp[flush ? src : 0];
 #pragma unroll
@@ -439,7 +445,7 @@ __device__ __forceinline__ void gather_item_group(const ItemArgs& a, int grp) {
             if (t >= 0) {                                     // (a skipped edge multiplied zeros: harmless)
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) blockmul<SI, TR>(xv[u][c], wv[u][c], acc[c]);
-            } else if (t == kItemFlush) {
+            } else if (t == kItemFlush || t <= kItemFlushMap) {
                 const bool has_ad = g.addend != nullptr && src < g.addend_rows;
                 row_epilogue<SI, NCH, TR>(g, src, has_ad, g.scale ? scv[u] : 1.f, lane, acc, xv[u]);
 #pragma unroll
@@ -464,6 +470,7 @@ __device__ __forceinline__ void gather_hub_row(const GatherArgs& a, int v) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int e0 = a.row_ptr[v], e1 = a.row_ptr[v + 1];
     const bool has_ad = a.addend != nullptr && v < a.addend_rows;
+    const int adrow = (has_ad && a.row_map) ? a.row_map[v] : v;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, kBufSpan);
     const __amdgpu_buffer_rsrc_t rad = make_rsrc(a.addend ? a.addend : a.x, kBufSpan);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.W, kBufSpan);
@@ -476,7 +483,7 @@ __device__ __forceinline__ void gather_hub_row(const GatherArgs& a, int v) {
         xoff[c] = ch < (uint32_t)CH ? ch * 16u : kOob;
         woff[c] = ch < (uint32_t)CH ? ch * (16u * WCH) : kOob;
         acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        adv[c] = buf_load4s(rad, (has_ad && wave == 0) ? xoff[c] : kOob, has_ad ? (uint32_t)v * ROWB : 0u);
+        adv[c] = buf_load4s(rad, (has_ad && wave == 0) ? xoff[c] : kOob, has_ad ? (uint32_t)adrow * ROWB : 0u);
     }
     for (int base = e0; base < e1; base += 64) {
         const int cnt = min(64, e1 - base);
@@ -761,11 +768,16 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float4* __restri
     }
 }
 
-__global__ __launch_bounds__(kThreads) void segment_add_kernel(const float4* __restrict__ src,
+__global__ __launch_bounds__(kThreads) void segment_add_kernel(const float4* __restrict__ src0,
+                                                               const float4* __restrict__ src1,
                                                                const int32_t* __restrict__ order,
                                                                const int32_t* __restrict__ seg_ptr,
                                                                const int32_t* __restrict__ seg_target,
-                                                               int U, int CH, float4* __restrict__ dst) {
+                                                               int U, int CH, float4* __restrict__ dst0,
+                                                               float4* __restrict__ dst1) {
+    // blockIdx.y selects one of two (source, destination) pairs that share the plan (renet_segment_add2)
+    const float4* __restrict__ src = blockIdx.y ? src1 : src0;
+    float4* __restrict__ dst = blockIdx.y ? dst1 : dst0;
     // One workgroup per segment: the 4 waves take rows k0+w, k0+w+4, ... (hot entities / relations own
     // hundreds of rows), 4 independent row loads in flight per wave, fixed-order LDS combine.
     __shared__ float4 red[kWaves][128];
@@ -803,6 +815,31 @@ __global__ __launch_bounds__(kThreads) void segment_add_kernel(const float4* __r
     }
 }
 
+// ---- index composition for the table-addressed first layer --------------------------------------------
+__global__ __launch_bounds__(256) void compose_table_items_kernel(const int32_t* __restrict__ row_map,
+                                                                  const int32_t* __restrict__ it_src,
+                                                                  const int32_t* __restrict__ it_type, int n_items,
+                                                                  const int32_t* __restrict__ col,
+                                                                  const int32_t* __restrict__ e_src, int E,
+                                                                  int32_t* __restrict__ it_src_t,
+                                                                  int32_t* __restrict__ it_type_t,
+                                                                  int32_t* __restrict__ col_t,
+                                                                  int32_t* __restrict__ e_src_t) {
+    const int total = n_items + 2 * E;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i < n_items) {
+            const int s = it_src[i], t = it_type[i];
+            if (t >= 0) { it_src_t[i] = row_map[s]; it_type_t[i] = t; }            // edge item: source -> table row
+            else if (t == -1) { it_src_t[i] = s; it_type_t[i] = -3 - row_map[s]; }  // flush: keep the output row, carry
+            else { it_src_t[i] = s; it_type_t[i] = t; }                            //        its table row in the type
+        } else if (i < n_items + E) {
+            col_t[i - n_items] = row_map[col[i - n_items]];
+        } else {
+            e_src_t[i - n_items - E] = row_map[e_src[i - n_items - E]];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -827,8 +864,20 @@ int renet_segment_add(const float* src, const int32_t* order, const int32_t* seg
     if (U == 0) return RENET_OK;
     if (D > 512) return RENET_ERR_UNSUPPORTED;
     RENET_LAUNCH(segment_add_kernel, dim3(U), dim3(kThreads), 0,
-                       (hipStream_t)stream, (const float4*)src, order, seg_ptr, seg_target, U, D / 4,
-                       (float4*)dst);
+                       (hipStream_t)stream, (const float4*)src, (const float4*)src, order, seg_ptr, seg_target, U, D / 4,
+                       (float4*)dst, (float4*)dst);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_segment_add2(const float* src0, const float* src1, const int32_t* order, const int32_t* seg_ptr,
+                       const int32_t* seg_target, int U, int D, float* dst0, float* dst1, void* stream) {
+    if (U < 0 || D <= 0 || (D & 3)) return RENET_ERR_BADARG;
+    if (U == 0) return RENET_OK;
+    if (D > 512) return RENET_ERR_UNSUPPORTED;
+    RENET_LAUNCH(segment_add_kernel, dim3(U, 2), dim3(kThreads), 0,
+                       (hipStream_t)stream, (const float4*)src0, (const float4*)src1, order, seg_ptr, seg_target, U, D / 4,
+                       (float4*)dst0, (float4*)dst1);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -859,19 +908,20 @@ int renet_rgcn_gather(const float* x, int D, const int32_t* row_ptr, const int32
     }
 }
 
-int renet_rgcn_gather_items(const float* x, int D, const int32_t* it_src, const int32_t* it_type,
-                            const int32_t* grp_ptr, int n_groups, const int32_t* row_ptr, const int32_t* col,
-                            const int32_t* etype, const float* scale, const float* W, int T, int type_shift,
-                            int transpose_w, const float* addend, float drop_p, uint64_t seed, int relu,
-                            float* out, int N, const int32_t* heavy_rows, int n_heavy, int src_limit,
-                            int addend_rows, int pruned, void* stream) {
+static int gather_items_impl(const float* x, int x_rows, int D, const int32_t* it_src, const int32_t* it_type,
+                             const int32_t* grp_ptr, int n_groups, const int32_t* row_ptr, const int32_t* col,
+                             const int32_t* etype, const float* scale, const float* W, int T, int type_shift,
+                             int transpose_w, const float* addend, float drop_p, uint64_t seed, int relu,
+                             float* out, int N, const int32_t* heavy_rows, int n_heavy, int src_limit,
+                             int addend_rows, int pruned, const int32_t* row_map, void* stream) {
     if (!renet_dim_ok(D)) return RENET_ERR_UNSUPPORTED;
     if (n_heavy < 0 || (n_heavy > 0 && !heavy_rows) || n_groups < 0) return RENET_ERR_BADARG;
     if (N < 0 || T <= 0 || type_shift < 0 || type_shift >= T || drop_p < 0.f || drop_p >= 1.f)
         return RENET_ERR_BADARG;
     if (N == 0 || (n_groups == 0 && n_heavy == 0)) return RENET_OK;
     // 32-bit buffer offsets with the skip marker at the span (kBufSpan / kOob): tensors must stay below 2 GiB
-    if ((size_t)N * D * sizeof(float) >= ((size_t)1 << 31) || (size_t)T * D * (D / 100) * sizeof(float) >= ((size_t)1 << 31))
+    if ((size_t)max(N, x_rows) * D * sizeof(float) >= ((size_t)1 << 31) ||
+        (size_t)T * D * (D / 100) * sizeof(float) >= ((size_t)1 << 31))
         return RENET_ERR_UNSUPPORTED;
     ItemArgs a;
     a.g.x = x; a.g.row_ptr = row_ptr; a.g.col = col; a.g.etype = etype; a.g.scale = scale; a.g.W = W;
@@ -879,6 +929,7 @@ int renet_rgcn_gather_items(const float* x, int D, const int32_t* it_src, const 
     a.g.heavy = heavy_rows; a.g.n_heavy = n_heavy; a.g.heavy_thresh = 0;
     a.g.src_limit = src_limit > 0 ? src_limit : 0x7fffffff;
     a.g.addend_rows = addend_rows > 0 ? addend_rows : 0x7fffffff;
+    a.g.row_map = row_map;
     a.g.drop = make_drop(drop_p, seed);
     a.it_src = it_src; a.it_type = it_type; a.grp_ptr = grp_ptr; a.n_groups = n_groups;
     hipStream_t st = (hipStream_t)stream;
@@ -900,6 +951,41 @@ int renet_rgcn_gather_items(const float* x, int D, const int32_t* it_src, const 
             if (unr == 4) return launch_gather_items<4, 2, 4>(a, tr, pr, st);
             return launch_gather_items<4, 2, 2>(a, tr, pr, st);
     }
+}
+
+int renet_rgcn_gather_items(const float* x, int D, const int32_t* it_src, const int32_t* it_type,
+                            const int32_t* grp_ptr, int n_groups, const int32_t* row_ptr, const int32_t* col,
+                            const int32_t* etype, const float* scale, const float* W, int T, int type_shift,
+                            int transpose_w, const float* addend, float drop_p, uint64_t seed, int relu,
+                            float* out, int N, const int32_t* heavy_rows, int n_heavy, int src_limit,
+                            int addend_rows, int pruned, void* stream) {
+    return gather_items_impl(x, N, D, it_src, it_type, grp_ptr, n_groups, row_ptr, col, etype, scale, W, T, type_shift,
+                             transpose_w, addend, drop_p, seed, relu, out, N, heavy_rows, n_heavy, src_limit,
+                             addend_rows, pruned, nullptr, stream);
+}
+
+int renet_rgcn_gather_items_table(const float* table, int table_rows, int D, const int32_t* it_src_t,
+                                  const int32_t* it_type_t, const int32_t* grp_ptr, int n_groups,
+                                  const int32_t* row_ptr, const int32_t* col_t, const int32_t* etype,
+                                  const int32_t* row_map, const float* scale, const float* W, int T, int type_shift,
+                                  const float* addend_table, float drop_p, uint64_t seed, int relu, float* out, int N,
+                                  const int32_t* heavy_rows, int n_heavy, void* stream) {
+    if (!row_map || table_rows <= 0) return RENET_ERR_BADARG;
+    return gather_items_impl(table, table_rows, D, it_src_t, it_type_t, grp_ptr, n_groups, row_ptr, col_t, etype, scale,
+                             W, T, type_shift, 0, addend_table, drop_p, seed, relu, out, N, heavy_rows, n_heavy, 0, 0, 0,
+                             row_map, stream);
+}
+
+int renet_compose_table_items(const int32_t* row_map, const int32_t* it_src, const int32_t* it_type, int n_items,
+                              const int32_t* col, const int32_t* e_src, int E, int32_t* it_src_t,
+                              int32_t* it_type_t, int32_t* col_t, int32_t* e_src_t, void* stream) {
+    if (n_items < 0 || E < 0 || !row_map) return RENET_ERR_BADARG;
+    const int total = n_items + 2 * E;
+    if (total == 0) return RENET_OK;
+    RENET_LAUNCH(compose_table_items_kernel, dim3(min(2048, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                 row_map, it_src, it_type, n_items, col, e_src, E, it_src_t, it_type_t, col_t, e_src_t);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
 }
 
 int renet_rgcn_bwd_prep(const float* g_out, const float* out, const float* norm, int relu,

@@ -860,3 +860,13 @@ class DeviceGraph(object):
         if not hasattr(self, 'nA'):
             self.nA = getattr(self, 'N', None)
         self.host = hb if not isinstance(hb, PackedBatch) else _HostView(pb)
+        self._table_items = None
+
+    def table_items(self):
+        """(it_src_t, it_type_t, col_t, e_src_t): the item stream / CSR columns / dW edge sources with every source
+        row replaced by its ENTITY id, for the first RGCN layer addressed through the entity table
+        (renet_hip.compose_table_items); composed on the device on first use."""
+        if self._table_items is None:
+            import renet_hip
+            self._table_items = renet_hip.compose_table_items(self)
+        return self._table_items

@@ -175,6 +175,70 @@ class RGCNLayerFn(Function):
         return dh, None if acc else d_w, d_loop, None, None, None, None, None, None
 
 
+class TableRows(object):
+    """Deferred `table[idx]` (utils.py:239: h0 = ent_embeds[id]): handed to the first RGCN layer as g.ndata['h'], which
+    then reads the entity table through idx instead of a materialised [N, D] copy (RGCNTableLayerFn)."""
+    __slots__ = ('table', 'idx', 'plan')
+
+    def __init__(self, table, idx, plan):
+        self.table, self.idx, self.plan = table, idx, plan
+
+    def materialise(self):
+        return GatherRowsFn.apply(self.table, self.idx, self.plan)
+
+
+class RGCNTableLayerFn(Function):
+    """The FIRST RGCNBlockLayer of a pass (RGCN.py:33-51,79-94 on h0 = ent_embeds[id], utils.py:239) without ever
+    materialising h0: h0 @ W_loop == (ent_embeds @ W_loop)[id], so the self-loop GEMM runs on the N_ent rows of the
+    entity table (23 k at ICEWS18 sizes) instead of the N rows of the batch graph (92 k on the merged batch), and the
+    gather-SpMM reads its source rows and its addend through g.node_ent from the two [N_ent, D] tables (18 MB each:
+    cache resident) -- renet_rgcn_gather_items_table.  Backward: the transposed gather on the [N, D] gradient as in
+    RGCNLayerFn, then ONE reduction to entity rows: d_ent += segsum(dh) + segsum(g_loop) @ W_loop^T and
+    dW_loop = ent^T @ segsum(g_loop) -- again GEMMs over N_ent rows."""
+
+    @staticmethod
+    def forward(ctx, table, weight, loop_weight, g, reverse, relu, drop_p, seed):
+        ctx.src_tab, ctx.src_w, ctx.src_loop = table, weight, loop_weight
+        table, weight, loop_weight = _c(table), _c(weight), _c(loop_weight)
+        shift = g.num_types // 2 if reverse else 0
+        ew = K.gemm(table, loop_weight)                               # RGCN.py:35 on the entity table
+        out = torch.empty(g.N, table.shape[1], device=table.device, dtype=torch.float32)
+        K.rgcn_gather_items_table(table, g, weight, shift, ew, drop_p, seed, relu, out)
+        ctx.g, ctx.relu, ctx.drop_p, ctx.seed, ctx.shift = g, relu, drop_p, seed, shift
+        ctx.save_for_backward(table, weight, loop_weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        table, weight, loop_weight, out = ctx.saved_tensors
+        g = ctx.g
+        tgt_tab, tgt_loop, tgt_w = grad_target(ctx.src_tab), grad_target(ctx.src_loop), grad_target(ctx.src_w)
+        g_out = _c(g_out)
+        n, d = out.shape
+        dev = out.device
+        gn = torch.empty(n, d, device=dev, dtype=torch.float32)
+        g_loop = torch.empty(n, d, device=dev, dtype=torch.float32)
+        K.rgcn_bwd_prep(g_out, out, g.norm, ctx.relu, ctx.drop_p, ctx.seed, gn, g_loop)
+        dh = torch.empty(n, d, device=dev, dtype=torch.float32)
+        pair_shift = (ctx.shift + g.num_types // 2) % g.num_types
+        K.rgcn_gather_items(gn, g, weight, pair_shift, True, None, 0.0, 0, False, dh, use_norm=False)
+        acc = tgt_w is not None
+        d_w = tgt_w if acc else torch.empty_like(weight)
+        K.rgcn_bwd_w(table, gn, g.table_items()[3], g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr,
+                     g.num_types, ctx.shift, d_w, beta=1.0 if acc else 0.0)
+        # per-entity sums of the self-loop gradient, then the two self-loop GEMMs on N_ent rows
+        gs = torch.zeros(table.shape, device=dev, dtype=torch.float32)
+        d_tab = tgt_tab if tgt_tab is not None else torch.zeros(table.shape, device=dev, dtype=torch.float32)
+        K.segment_add2(dh, g_loop, g.plan_node_ent, d_tab, gs)
+        K.gemm(gs, loop_weight, tb=True, out=d_tab, beta=1.0)             # += segsum(g_loop) @ W_loop^T
+        if tgt_loop is not None:
+            K.gemm(table, gs, ta=True, out=tgt_loop, beta=1.0)
+            d_loop = None
+        else:
+            d_loop = K.gemm(table, gs, ta=True)
+        return (None if tgt_tab is not None else d_tab), None if acc else d_w, d_loop, None, None, None, None, None
+
+
 class SeqAssembleFn(Function):
     """Aggregator.py:139-165: packed GRU inputs X [S,4D], Xr [S,3D] with fused dropout."""
 

@@ -24,12 +24,19 @@ _SIGNATURES = {
     'renet_version': (c_int, []),
     'renet_gather_rows': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'renet_segment_add': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'renet_segment_add2': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                   c_void_p]),
     'renet_rgcn_gather': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_int, c_int, c_void_p, c_float, c_u64, c_int, c_void_p, c_int, c_void_p,
                                   c_int, c_int, c_int, c_int, c_void_p]),
     'renet_rgcn_gather_items': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_u64,
                                         c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'renet_rgcn_gather_items_table': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                              c_float, c_u64, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    'renet_compose_table_items': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     'renet_rgcn_bwd_prep': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_u64, c_int, c_int,
                                     c_void_p, c_void_p, c_void_p]),
     'renet_rgcn_bwd_w_workspace': (c_size_t, [c_int, c_int]),
@@ -229,6 +236,12 @@ def segment_add(src, plan, dst):
     return dst
 
 
+def segment_add2(src0, src1, plan, dst0, dst1):
+    """dst0[target] += segment sums of src0 and dst1[target] += segment sums of src1, one launch, one plan."""
+    _check(lib().renet_segment_add2(_f32(src0), _f32(src1), _i32(plan.order), _i32(plan.seg_ptr), _i32(plan.target),
+                                    plan.num_segments, src0.shape[1], _f32(dst0), _f32(dst1), _stream()), 'segment_add2')
+
+
 def rgcn_gather(x, row_ptr, col, etype, scale, weight, type_shift, transpose_w, addend, drop_p, seed,
                 relu, out, heavy_rows=None, heavy_thresh=0, src_limit=0, addend_rows=0, n_edges=None):
     """n_edges: edges actually walked by this launch (pruned launches), for the byte accounting only."""
@@ -288,6 +301,42 @@ def rgcn_gather_items(x, g, weight, type_shift, transpose_w, addend, drop_p, see
         name = 'rgcn_gather_%s_%s' % ('bwdh' if transpose_w else 'fwd', 'pruned' if pruned else 'full')
         _timer.end(name, t0, nbytes=float(gather_bytes(e, n_rows, d, weight.numel(), addend is not None)),
                    tag=float(gather_bytes(e, n_rows, d, weight.numel(), False)))       # tag: the strict bytes
+    return out
+
+
+def compose_table_items(g):
+    """Index arrays of the table-addressed first layer for DeviceGraph `g` (renet_compose_table_items): source rows
+    composed through g.node_ent.  -> (it_src_t, it_type_t, col_t, e_src_t), int32 device tensors."""
+    ni, e = g.it_src.numel(), g.col.numel()
+    buf = torch.empty(2 * ni + 2 * e + 16, device=g.col.device, dtype=torch.int32)
+    a0, a1, a2 = (ni + 3) & ~3, 2 * ((ni + 3) & ~3), 2 * ((ni + 3) & ~3) + ((e + 3) & ~3)
+    it_src_t, it_type_t, col_t, e_src_t = buf[:ni], buf[a0:a0 + ni], buf[a1:a1 + e], buf[a2:a2 + e]
+    _check(lib().renet_compose_table_items(_i32(g.node_ent), _i32(g.it_src), _i32(g.it_type), ni, _i32(g.col),
+                                           _i32(g.e_src), e, it_src_t.data_ptr(), it_type_t.data_ptr(),
+                                           col_t.data_ptr(), e_src_t.data_ptr(), _stream()), 'compose_table_items')
+    return it_src_t, it_type_t, col_t, e_src_t
+
+
+def rgcn_gather_items_table(table, g, weight, type_shift, addend_table, drop_p, seed, relu, out):
+    """renet_rgcn_gather_items_table: the first RGCN layer reading source rows and the self-loop addend through
+    g.node_ent from [N_ent, D] tables (forward, full graph)."""
+    d = table.shape[1]
+    n_rows = out.shape[0]
+    it_src_t, it_type_t, col_t, _ = g.table_items()
+    heavy = g.heavy_rows
+    t0 = _timer.begin() if _timer is not None else None
+    _check(lib().renet_rgcn_gather_items_table(_f32(table), table.shape[0], d, _i32(it_src_t), _i32(it_type_t),
+                                               _i32(g.grp_ptr), int(g.n_groups), _i32(g.row_ptr), _i32(col_t),
+                                               _i32(g.etype), _i32(g.node_ent), _f32(g.norm), _f32(weight),
+                                               weight.shape[0], int(type_shift), _f32(addend_table), float(drop_p),
+                                               int(seed), int(relu), _f32(out), n_rows,
+                                               _i32(heavy) if heavy is not None else None,
+                                               heavy.numel() if heavy is not None else 0, _stream()),
+           'rgcn_gather_items_table')
+    if t0 is not None:          # SURVEY 8d's ALGORITHMIC bytes: one source row per edge, one output (+ addend) row per node
+        _timer.end('rgcn_gather_fwd_full', t0,
+                   nbytes=float(gather_bytes(g.E, n_rows, d, weight.numel(), addend_table is not None)),
+                   tag=float(gather_bytes(g.E, n_rows, d, weight.numel(), False)))
     return out
 
 

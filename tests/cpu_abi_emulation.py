@@ -33,6 +33,26 @@ def segment_add(src, plan, dst):
     return dst
 
 
+def segment_add2(src0, src1, plan, dst0, dst1):
+    segment_add(src0, plan, dst0)
+    segment_add(src1, plan, dst1)
+
+
+def rgcn_gather_items_table(table, g, weight, type_shift, addend_table, drop_p, seed, relu, out):
+    ent = g.node_ent.long()
+    return rgcn_gather_items(table[ent], g, weight, type_shift, False, addend_table[ent] if addend_table is not None
+                             else None, drop_p, seed, relu, out, use_norm=True)
+
+
+def compose_table_items(g):
+    ent = g.node_ent.long()
+    t = g.it_type.long()
+    s_ = g.it_src.long()
+    it_src_t = torch.where(t >= 0, ent[s_], s_).int()
+    it_type_t = torch.where(t == -1, -3 - ent[s_], t).int()
+    return it_src_t, it_type_t, ent[g.col.long()].int(), ent[g.e_src.long()].int()
+
+
 def _blockmul(x, w, d, tr):
     si = d // 100
     xs = x.reshape(-1, 100, si)
@@ -259,7 +279,8 @@ def segment_pool_bwd(dout, seg_ptr, arg, num_graphs, is_max, n):
     return dh
 
 
-EMULATED = ['gather_rows', 'segment_add', 'rgcn_gather_items', 'rgcn_bwd_prep', 'rgcn_bwd_w', 'gemm', 'colsum',
+EMULATED = ['gather_rows', 'segment_add', 'segment_add2', 'rgcn_gather_items', 'rgcn_gather_items_table',
+            'compose_table_items', 'rgcn_bwd_prep', 'rgcn_bwd_w', 'gemm', 'colsum',
             'scale_by_device_scalar', 'seq_assemble_fwd', 'seq_assemble_bwd', 'gru_fwd', 'gru_bwd', 'gru_fwd_multi',
             'gru_bwd_multi', 'gru_fwd_layouts', 'gru_bwd_layouts', 'concat3_fwd', 'concat3_bwd', 'dropout', 'softmax_ce', 'segment_pool_fwd',
             'segment_pool_bwd']

@@ -180,3 +180,56 @@ def test_item_gather_every_unroll_variant(dev, unr):
     r = subprocess.run([sys.executable, '-c', _UNR_CHECK, PKG, os.path.dirname(os.path.abspath(__file__))], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'ok' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+# ---------------------------------------------------------------------------------------------
+# first layer addressed through the entity table (ops.RGCNTableLayerFn, renet_rgcn_gather_items_table):
+# == the layer on the materialised h0 = table[node_ent] (ops.GatherRowsFn + ops.RGCNLayerFn), forward and every
+# gradient, with dropout on (the mask is keyed by (node row, column) in both forms) and hub rows present
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('d', [100, 200, 400])
+@pytest.mark.parametrize('drop_p', [0.0, 0.4])
+def test_table_addressed_first_layer_equals_materialised_layer(dev, d, drop_p):
+    import graph as G
+    import ops
+    n, n_ent, num_rels = 3000, 700, 9
+    T = 2 * num_rels
+    rng = np.random.RandomState(17 + d)
+    # paired edges (both directions of every fact, utils.py:74-76) so that the transposed gather of the backward
+    # pass is the same CSR
+    m = 6000
+    a, b, r = rng.randint(0, n, m), rng.randint(0, n, m), rng.randint(0, num_rels, m)
+    hubs = rng.randint(0, n, 4)
+    a[:400] = hubs[rng.randint(0, 4, 400)]                                   # a few rows with ~100 in/out edges
+    src, dst, et = np.concatenate((a, b)), np.concatenate((b, a)), np.concatenate((r, r + num_rels))
+    hb = G.HostBatch.from_edges(n, src, dst, et, num_rels)
+    hb.node_ent = rng.randint(0, n_ent, n).astype(np.int32)
+    hb.plan_node_ent = G.SegPlan.host(hb.node_ent)
+    g = G.DeviceGraph(hb, dev)
+    assert g.heavy_rows is not None and g.heavy_rows.numel() >= 2
+
+    def leaf(a_):
+        return torch.from_numpy(a_.astype(np.float32)).to(dev).requires_grad_(True)
+    tab0, w0, l0 = rng.randn(n_ent, d) * 0.3, rng.randn(T, d * d // 100) * 0.2, rng.randn(d, d) * 0.1
+    cot = torch.from_numpy(rng.randn(n, d).astype(np.float32)).to(dev)
+    res = []
+    for table_path in (True, False):
+        tab, w, lw = leaf(tab0), leaf(w0), leaf(l0)
+        if table_path:
+            out = ops.RGCNTableLayerFn.apply(tab, w, lw, g, False, True, drop_p, 1234)
+        else:
+            h0 = ops.GatherRowsFn.apply(tab, g.node_ent, g.plan_node_ent)
+            out = ops.RGCNLayerFn.apply(h0, w, lw, g, False, True, drop_p, 1234, None)
+        (out * cot).sum().backward()
+        torch.cuda.synchronize()
+        res.append([t.detach().cpu().double().numpy() for t in (out, tab.grad, w.grad, lw.grad)])
+    for name, x, y in zip(('out', 'd_table', 'd_weight', 'd_loop'), res[0], res[1]):
+        scale = np.abs(y).max()
+        assert scale > 0
+        assert np.abs(x - y).max() <= (1e-6 if name == 'out' else 2e-5) * scale, (name, np.abs(x - y).max(), scale)
+    # and against the fp64 definition (dropout off)
+    if drop_p == 0.0:
+        norm = hb.norm
+        h0 = tab0[hb.node_ent]
+        want = reference(h0, src, dst, et, w0, d, T, 0, False, norm, h0 @ l0, True, n, 0, 0)
+        assert np.abs(res[0][0] - want).max() <= 2e-5 * np.abs(want).max()
