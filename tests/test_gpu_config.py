@@ -370,7 +370,7 @@ def test_inference_at_config_scale_matches_reference(dev, shadowing):
     dr = np.abs(ranks[keep] - gold['ranks'][keep])
     print('rank differences:', dr.reshape(-1).tolist())
     # filtered ranks among 23 033 entities: fp32 near-ties may move a rank by a few positions
-    assert float(np.mean(dr <= 2)) >= 0.9 and dr.max() <= 25, dr
+    assert float(np.mean(dr == 0)) >= 0.9 and dr.max() <= 3, dr         # observed on MI355X: all equal
     from oracle import renet_oracle as O
     m1, m2 = O.mrr_hits(ranks[keep].reshape(-1)), O.mrr_hits(gold['ranks'][keep].reshape(-1))
     assert abs(m1['mrr'] - m2['mrr']) < 2e-3

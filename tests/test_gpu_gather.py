@@ -213,6 +213,12 @@ def test_table_addressed_first_layer_equals_materialised_layer(dev, d, drop_p):
     tab0, w0, l0 = rng.randn(n_ent, d) * 0.3, rng.randn(T, d * d // 100) * 0.2, rng.randn(d, d) * 0.1
     cot = torch.from_numpy(rng.randn(n, d).astype(np.float32)).to(dev)
     res = []
+    # pre-activations within fp32 rounding of zero take either side of the ReLU depending on the summation order
+    # (one flipped element moves a gradient entry by ~1e-2 of its tensor's max): give those elements no cotangent
+    with torch.no_grad():
+        pre = ops.RGCNTableLayerFn.apply(leaf(tab0).detach(), leaf(w0).detach(), leaf(l0).detach(), g, False, False,
+                                         drop_p, 1234)
+        cot = cot * (pre.abs() > 1e-4)
     for table_path in (True, False):
         tab, w, lw = leaf(tab0), leaf(w0), leaf(l0)
         if table_path:
