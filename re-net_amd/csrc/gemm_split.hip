@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
+#include "gemm_skinny.h"
 
 namespace {
 
@@ -1219,6 +1220,15 @@ int renet_gemm_trace_set(unsigned long long* buf) {
 }
 #endif
 
+static bool skinny_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RENET_GEMM_SKINNY");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v != 0;
+}
+
 static int gemm_planes_launch(bool bf16_mode, int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
                               const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                               int split_k, float* workspace, size_t workspace_bytes, void* stream) {
@@ -1228,6 +1238,10 @@ static int gemm_planes_launch(bool bf16_mode, int ta, int tb, int M, int N, int 
     const int kt_total = (K + BK - 1) / BK;
     if (split_k > kt_total) split_k = max(kt_total, 1);
     if (split_k > 1 && workspace_bytes < renet_gemm_workspace(M, N, split_k)) return RENET_ERR_WORKSPACE;
+    // tall activation x small weight (K <= 208, N <= 256): the weight-resident kernel of gemm_skinny.hip
+    // (RENET_GEMM_SKINNY=0 in the environment keeps the general kernels, for A/B runs)
+    if (!bf16_mode && split_k == 1 && skinny_enabled() && renet_gemm_skinny_eligible(ta, M, N, K, A, lda, B, ldb, tb))
+        return renet_gemm_skinny_launch(tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, stream);
     SplitArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha; g.beta = beta;

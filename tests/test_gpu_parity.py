@@ -82,6 +82,36 @@ def test_gemm_both_k_loop_structures(dev, kernel):
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
 
 
+@pytest.mark.parametrize('m,n,k', [(23033, 200, 200), (14001, 200, 200), (257, 256, 208), (300, 64, 16), (4097, 100, 100),
+                                   (1000, 200, 112), (999, 250, 204), (2048, 256, 128)])
+@pytest.mark.parametrize('tb', [0, 1])
+def test_skinny_weight_resident_gemm_matches_fp64_and_the_general_kernel(dev, m, n, k, tb):
+    """gemm_skinny.hip (tall activation x small weight: K <= 208, N <= 256, the RGCN self-loop shapes) -- picked by
+    renet_gemm_f32_split for eligible shapes -- against fp64 with bias, alpha and beta accumulation, row-strided
+    operand views, and against the general kernel (RENET_GEMM_SKINNY=0 in a child process computes the same
+    product; the two agree to fp32-class accuracy, not bit for bit: different summation order)."""
+    import renet_hip as K
+    rng = np.random.RandomState(m + 7 * n + 13 * k + tb)
+    a_full = rng.uniform(-1, 1, (m, k + 8)).astype(np.float32)
+    a = a_full[:, 4:4 + k]                                        # view: lda = k + 8, base 16-byte aligned
+    b = rng.uniform(-1, 1, (n, k) if tb else (k, n)).astype(np.float32)
+    bias = rng.uniform(-1, 1, n).astype(np.float32)
+    c0 = rng.uniform(-1, 1, (m, n)).astype(np.float32)
+    prod = a.astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+    a_dev = _to(a_full, dev)[:, 4:4 + k]
+    out = K.gemm(a_dev, _to(b, dev), tb=bool(tb), bias=_to(bias, dev))
+    np.testing.assert_allclose(out.cpu().numpy(), prod + bias, rtol=1e-5, atol=1e-5 * k ** 0.5)
+    acc = _to(c0, dev).clone()
+    K.gemm(a_dev, _to(b, dev), tb=bool(tb), out=acc, alpha=0.5, beta=1.0)
+    np.testing.assert_allclose(acc.cpu().numpy(), 0.5 * prod + c0, rtol=1e-5, atol=1e-5 * k ** 0.5)
+    wide = torch.zeros(m, n + 40, device=dev)
+    K.gemm(a_dev, _to(b, dev), tb=bool(tb), out=wide[:, 8:8 + n])            # ldc > N: neighbours untouched
+    np.testing.assert_allclose(wide[:, 8:8 + n].cpu().numpy(), prod, rtol=1e-5, atol=1e-5 * k ** 0.5)
+    assert float(wide[:, :8].abs().max()) == 0.0 and float(wide[:, 8 + n:].abs().max()) == 0.0
+    again = K.gemm(a_dev, _to(b, dev), tb=bool(tb), bias=_to(bias, dev))
+    assert torch.equal(out, again), 'deterministic'
+
+
 def test_gemm_splitk_beta_and_strided_views(dev):
     import renet_hip as K
     rng = np.random.RandomState(5)
