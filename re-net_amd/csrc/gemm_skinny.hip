@@ -65,39 +65,49 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_split_skinny_kernel(SkinnyArg
     const bool n_ok = n < g.N;
 
     // ---- B fragments: k-step s, lane (col n, k = 16 s + 8 half + j) -> three planes of 8 bf16 -----------------
+    // Branch-free loads (clamped addresses, zeroed afterwards): with `if (ok) v = *p` hipcc branches around every
+    // load and drains vmcnt at each merge -- 104 serialised L2 latencies at kernel start.  Issued in batches of
+    // BATCH k-steps so that the loads of a batch are in flight together.
     bf16x8 bfr[K16][3];
+    const int nc = min(n, g.N - 1);
+    constexpr int BATCH = 4;
 #pragma unroll
-    for (int s = 0; s < K16; ++s) {
-        float v[8];
-        const int k0 = s * 16 + half * 8;
+    for (int s0 = 0; s0 < K16; s0 += BATCH) {
+        float v[BATCH][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-        if (n_ok) {
-            if constexpr (TB) {                  // B[n][k]: 8 consecutive k of one row
-                const float* p = g.B + (size_t)n * g.ldb + k0;
-                if (k0 + 8 <= g.K) {
-                    const float4 a = *reinterpret_cast<const float4*>(p);
-                    const float4 b = *reinterpret_cast<const float4*>(p + 4);
-                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-                } else {
+        for (int b = 0; b < BATCH; ++b) {
+            const int s = s0 + b;
+            if (s < K16) {
+                const int k0 = s * 16 + half * 8;
+                if constexpr (TB) {              // B[n][k]: 8 consecutive k of one row (K % 4 == 0)
+                    const float* p = g.B + (size_t)nc * g.ldb;
+                    const float4 a = *reinterpret_cast<const float4*>(p + min(k0, g.K - 4));
+                    const float4 c = *reinterpret_cast<const float4*>(p + min(k0 + 4, g.K - 4));
+                    v[b][0] = a.x; v[b][1] = a.y; v[b][2] = a.z; v[b][3] = a.w;
+                    v[b][4] = c.x; v[b][5] = c.y; v[b][6] = c.z; v[b][7] = c.w;
+                } else {                         // B[k][n]: a half-wave reads 32 consecutive n per k
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (k0 + j < g.K) v[j] = p[j];
+                    for (int j = 0; j < 8; ++j) v[b][j] = g.B[(size_t)min(k0 + j, g.K - 1) * g.ldb + nc];
                 }
-            } else {                             // B[k][n]: lanes of a half-wave read 32 consecutive n per k
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (k0 + j < g.K) v[j] = g.B[(size_t)(k0 + j) * g.ldb + n];
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bf16x2 t[3];
-            split2(f32x2{v[2 * q], v[2 * q + 1]}, t);
+        for (int b = 0; b < BATCH; ++b) {
+            const int s = s0 + b;
+            if (s < K16) {
+                const int k0 = s * 16 + half * 8;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                bfr[s][p][2 * q] = t[p][0];
-                bfr[s][p][2 * q + 1] = t[p][1];
+                for (int q = 0; q < 4; ++q) {
+                    // a float4 is either entirely inside K or entirely past it (K % 4 == 0)
+                    const bool ok = n_ok && (k0 + 2 * q) < g.K;
+                    bf16x2 t[3];
+                    split2(f32x2{ok ? v[b][2 * q] : 0.f, ok ? v[b][2 * q + 1] : 0.f}, t);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        bfr[s][p][2 * q] = t[p][0];
+                        bfr[s][p][2 * q + 1] = t[p][1];
+                    }
+                }
             }
         }
     }
@@ -107,22 +117,25 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_split_skinny_kernel(SkinnyArg
         const int row0 = tile * SK_ROWS;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int f = tid + SK_THREADS * i;
+            const int f = min(tid + SK_THREADS * i, ITEMS - 1);
             const int row = f / (KP / 4), k = (f - row * (KP / 4)) * 4;
-            r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < ITEMS && row0 + row < g.M && k < g.K)       // K % 4 == 0 (checked by the launcher)
-                r[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(row0 + row) * g.lda + k);
+            // clamped, branch-free (K % 4 == 0 and M >= 1: checked by the launcher); out-of-range items are zeroed
+            // (zeroed in store_tile_lds, i.e. BEHIND the MFMAs: a select right here would make the compiler wait for
+            // the load before the matrix work it is supposed to hide under)
+            r[i] = *reinterpret_cast<const float4*>(g.A + (size_t)min(row0 + row, g.M - 1) * g.lda + min(k, g.K - 4));
         }
     };
-    auto store_tile_lds = [&](__bf16* S, const float4 (&r)[NI]) {
+    auto store_tile_lds = [&](__bf16* S, int tile, const float4 (&r)[NI]) {
+        const int row0 = tile * SK_ROWS;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int f = tid + SK_THREADS * i;
             if (f < ITEMS) {
                 const int row = f / (KP / 4), k = (f - row * (KP / 4)) * 4;
+                const bool ok = row0 + row < g.M && k < g.K;
                 bf16x2 lo[3], hi[3];
-                split2(f32x2{r[i].x, r[i].y}, lo);
-                split2(f32x2{r[i].z, r[i].w}, hi);
+                split2(f32x2{ok ? r[i].x : 0.f, ok ? r[i].y : 0.f}, lo);
+                split2(f32x2{ok ? r[i].z : 0.f, ok ? r[i].w : 0.f}, hi);
                 __bf16* dst = S + row * SROW + k;
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
@@ -140,14 +153,19 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_split_skinny_kernel(SkinnyArg
     int cur = 0;
     if (tile < g.n_tiles) {
         load_tile(tile, stage);
-        store_tile_lds(smem_sk, stage);
+        store_tile_lds(smem_sk, tile, stage);
     }
     __syncthreads();
     const int aoff = (lane & 31) * SROW + half * 8;
+    const float bv = (g.bias && n_ok) ? g.bias[nc] : 0.f;
     for (; tile < g.n_tiles; tile += gridDim.x) {
         const int nxt = tile + gridDim.x;
         const bool has_next = nxt < g.n_tiles;                  // workgroup-uniform
-        if (has_next) load_tile(nxt, stage);                    // in flight under the MFMAs below
+        // in flight under the MFMAs below.  UNCONDITIONAL (the last iteration re-loads its own tile and drops it): a
+        // load inside `if (has_next)` makes hipcc drain vmcnt at the merge point, i.e. before the matrix work
+        load_tile(has_next ? nxt : tile, stage);
+        __builtin_amdgcn_sched_barrier(0);                      // ... and pinned HERE (the scheduler sinks them to their
+                                                                // first use, behind the MFMAs, otherwise)
         const __bf16* S = smem_sk + cur * BUF;
         f32x16 acc[2];
 #pragma unroll
@@ -165,23 +183,50 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_split_skinny_kernel(SkinnyArg
             for (int q = 0; q < 6; ++q)
                 acc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], bfr[s][PB[q]], acc[s & 1], 0, 0, 0);
         }
-        if (has_next) store_tile_lds(smem_sk + (cur ^ 1) * BUF, stage);
+        if (has_next) store_tile_lds(smem_sk + (cur ^ 1) * BUF, nxt, stage);
         // epilogue of this tile: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 half
-        if (n_ok) {
-            const float bv = g.bias ? g.bias[n] : 0.f;
+        {
             const int row0 = tile * SK_ROWS;
+            float* cp = g.C + (size_t)(row0 + 4 * half) * g.ldc + nc;      // + ((r & 3) + 8 (r >> 2)) * ldc
+            if (row0 + SK_ROWS <= g.M) {                        // interior tile (wave-uniform): ONE exec region
+                if (n_ok) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < g.M) {
-                    float* p = g.C + (size_t)row * g.ldc + n;
-                    float v = g.alpha * (acc[0][r] + acc[1][r]) + bv;
-                    if (g.beta != 0.f) v += g.beta * (*p);
-                    *p = v;
+                    for (int h8 = 0; h8 < 2; ++h8) {            // 8 reads of C in flight together, then 8 stores
+                        float old[8];
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) old[r8] = 0.f;
+                        if (g.beta != 0.f) {
+#pragma unroll
+                            for (int r8 = 0; r8 < 8; ++r8) {
+                                const int r = h8 * 8 + r8;
+                                old[r8] = cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc];
+                            }
+                        }
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int r = h8 * 8 + r8;
+                            cp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldc] =
+                                g.alpha * (acc[0][r] + acc[1][r]) + bv + g.beta * old[r8];
+                        }
+                    }
+                }
+            } else {                                            // the last, partial tile
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (n_ok && row < g.M) {
+                        float* p = g.C + (size_t)row * g.ldc + n;
+                        float v = g.alpha * (acc[0][r] + acc[1][r]) + bv;
+                        if (g.beta != 0.f) v += g.beta * (*p);
+                        *p = v;
+                    }
                 }
             }
         }
-        __syncthreads();                                        // next buffer complete, this one fully consumed
+        // LDS-only barrier (next buffer complete, this one fully consumed): __syncthreads() would also wait for
+        // the C stores above (s_waitcnt vmcnt(0)), one write latency per tile
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         cur ^= 1;
     }
 }
@@ -205,7 +250,7 @@ int launch_skinny(const SkinnyArgs& g, hipStream_t st) {
 }  // namespace
 
 bool renet_gemm_skinny_eligible(int ta, int M, int N, int K, const float* A, int lda, const float* B, int ldb, int tb) {
-    if (ta || N > 256 || K > 208 || K < 16 || (K & 3) || (lda & 3) || M < 256) return false;
+    if (ta || N > 256 || N < 1 || K > 208 || K < 16 || (K & 3) || (lda & 3) || M < 256) return false;
     if (reinterpret_cast<uintptr_t>(A) & 15) return false;
     if (tb && ((ldb & 3) || (reinterpret_cast<uintptr_t>(B) & 15))) return false;
     return true;
