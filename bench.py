@@ -93,7 +93,8 @@ def main():
     import renet_hip as K
     K.lib()
     if args.dtype == 'bf16':
-        K.GEMM_MODE = 'bf16'
+        # bf16 STORAGE mode (renet_gemm_bf16s); RENET_BF16_STORAGE=0 keeps fp32 tensors and rounds inside the GEMMs
+        K.GEMM_MODE = 'bf16' if os.environ.get('RENET_BF16_STORAGE') == '0' else 'bf16s'
     import model as M
     import parallel
     import preprocess as P
@@ -345,9 +346,9 @@ def main():
             # bf16 MFMA products (fp32-class result), so the matrix-pipe ceiling for algorithmic flops is the
             # dense bf16 peak / 6; in f32 mode it is the f32-input MFMA peak.
             ach = st['flops'] / (st['ms'] * 1e-3) / 1e12
-            peak = {'bf16x6': MFMA_BF16_PEAK_TF / 6.0, 'bf16': MFMA_BF16_PEAK_TF}.get(K.GEMM_MODE, MFMA_F32_PEAK_TF)
+            peak = {'bf16x6': MFMA_BF16_PEAK_TF / 6.0, 'bf16': MFMA_BF16_PEAK_TF, 'bf16s': MFMA_BF16_PEAK_TF}.get(K.GEMM_MODE, MFMA_F32_PEAK_TF)
             note = {'bf16x6': 'algorithmic fp32 TFLOP/s; peak = bf16 dense 2500/6 (six bf16 MFMA products per fp32 '
-                              'product)', 'bf16': 'bf16 dense MFMA peak'}.get(K.GEMM_MODE, 'f32-input MFMA peak')
+                              'product)', 'bf16': 'bf16 dense MFMA peak', 'bf16s': 'bf16 dense MFMA peak (bf16 operands in HBM)'}.get(K.GEMM_MODE, 'f32-input MFMA peak')
             roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': peak,
                         'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic_of(dom),
                         'gemm_mode': K.GEMM_MODE, 'note': note}

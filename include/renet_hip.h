@@ -188,6 +188,19 @@ int renet_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const floa
  *     One plane set serves both roles: linear.weight [N_ent, 3D] is op(B) of the logits GEMM (b_tr = 0) and of
  *     dfeat = dlogits W (b_tr = 1); dlogits [B, N_ent] is op(A) of dfeat (a_tr = 0) and of dW = dlogits^T feat
  *     (a_tr = 1).  split_k / workspace as renet_gemm_f32. */
+/* bf16 STORAGE (BASELINE config 5, "n_hidden=400 bf16"): operands live in HBM as bf16 matrices, [Rp][Cp] row-major
+ * with Rp, Cp = R, C rounded up to multiples of 128 and zero padding (one "plane" of the format above).
+ *   renet_pack_bf16  : fp32 X[R, C] (row stride ldx) -> bf16 (RNE), padding written; renet_bf16_bytes(R, C) bytes.
+ *   renet_gemm_bf16s : the GEMM contract of renet_gemm_planes on such matrices: ONE bf16 product per element pair
+ *                      (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 C; operands staged by LDS-DMA, consumed
+ *                      K-contiguous (tr = 0) or K-strided (tr = 1) as there.  Replaces torch.mm / nn.Linear /
+ *                      nn.GRU's input projection at config 5 (RGCN.py:35, model.py:86-99) -- the reference itself
+ *                      has no bf16 path; tolerances in tests/test_gpu_bf16.py. */
+size_t renet_bf16_bytes(int R, int C);
+int renet_pack_bf16(const float* X, int R, int C, int ldx, void* out, void* stream);
+int renet_gemm_bf16s(int a_tr, int b_tr, int M, int N, int K, float alpha, const void* Ap, int lda, const void* Bp,
+                     int ldb, float beta, float* C, int ldc, const float* bias, int split_k, float* workspace,
+                     size_t workspace_bytes, void* stream);
 size_t renet_planes_bytes(int R, int C);
 int renet_pack_planes(const float* X, int R, int C, int ldx, void* planes, void* stream);
 int renet_gemm_planes(int a_tr, int b_tr, int M, int N, int K, float alpha, const void* Ap, int lda, const void* Bp,
@@ -274,6 +287,16 @@ int renet_gru_fwd_layouts(int n, const float* const* Gi, const int32_t* const* s
 int renet_gru_bwd_layouts(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
                           const float* const* Whh, const float* const* saved, float* const* dGi,
                           float* const* dGh, float* workspace, size_t workspace_bytes, void* stream);
+/* The same recurrences in bf16 mode (BASELINE config 5): W_hh and the hidden state / gate gradients are rounded to
+ * bf16 (RNE) as MFMA operands -- ONE v_mfma_f32_16x16x32_bf16 product per fragment pair instead of the six of the
+ * fp32-class split, a third of the W_hh stream -- with fp32 accumulation, fp32 gate math, fp32 state and outputs. */
+int renet_gru_fwd_layouts_bf16(int n, const float* const* Gi, const int32_t* const* step_off, const int* L, int H,
+                               const float* const* Whh, const float* const* bhh, float* const* h_last,
+                               const int* out_rows, float* const* saved, float* workspace, size_t workspace_bytes,
+                               void* stream);
+int renet_gru_bwd_layouts_bf16(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
+                               const float* const* Whh, const float* const* saved, float* const* dGi,
+                               float* const* dGh, float* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Score head (model.py:89-91, 98-100).

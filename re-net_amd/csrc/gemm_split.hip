@@ -1044,6 +1044,205 @@ __global__ __launch_bounds__(P3_THREADS) void gemm_planes_kernel(PlanesArgs pa) 
     store_tile(g, m0, n0, z, wm, wn, lane, acc);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// bf16-STORAGE GEMM (renet_gemm_bf16s, BASELINE config 5 "n_hidden=400 bf16"): both operands are bf16 matrices in
+// HBM ([Rp][Cp], padded with zeros to multiples of 128 like a plane of the planes GEMM), ONE product per fragment
+// pair, fp32 accumulation.  Same LDS-DMA ring, wave specialisation, images and swizzles as gemm_planes_kernel; a
+// ring slot holds TWO 32-wide k sub-tiles per operand (4 x 8 KB = 32 KB per slot, 3 slots) where the planes kernel
+// holds three planes, so a stage is 128 x 128 x 64: 16 MFMAs per MFMA wave and barrier.  With one product per
+// element pair the k-loop moves 16 KB of operands per 1 MFLOP: the kernel is bound by the L2 -> LDS stream, not by
+// the matrix pipe.  Either operand may be consumed K-contiguous or K-strided (ds_read_b64_tr_b16).
+// ------------------------------------------------------------------------------------------------------
+struct Bf16sArgs {
+    const __bf16* A;
+    const __bf16* B;
+    int lda, ldb;               // row stride (elements)
+    SplitArgs out;              // M, N, K, C, ldc, alpha, beta, bias, split-K fields; k_tiles_per_split in 64-wide STAGES
+};
+
+constexpr int B1_SUB = 2;                                 // k sub-tiles per operand and ring slot
+constexpr int B1_BK = 32 * B1_SUB;                        // k per stage
+constexpr int B1_STAGE = 2 * B1_SUB * 8192;
+constexpr int B1_SLOTS = 3;
+constexpr int B1_PER = (2 * B1_SUB * 8) / P3_LOADERS;     // DMA pieces per loader wave and stage (8)
+constexpr size_t B1_LDS = (size_t)B1_STAGE * B1_SLOTS;
+
+template <bool A_TR, bool B_TR>
+__global__ __launch_bounds__(P3_THREADS) void gemm_bf16s_kernel(Bf16sArgs pa) {
+    extern __shared__ __attribute__((aligned(16))) char ring1[];
+    const SplitArgs& g = pa.out;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx, by;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    const int m0 = by * BM, n0 = bx * BN;
+    const int z = blockIdx.z;
+    const int st_total = (g.K + B1_BK - 1) / B1_BK;
+    const int s0 = z * g.k_tiles_per_split;
+    const int s1 = min(st_total, s0 + g.k_tiles_per_split);
+    const int nk = max(s1 - s0, 0);
+
+    if (wave >= 4) {
+        if (nk == 0) return;
+        const int lw = wave - 4;
+        const __bf16* src[B1_PER];
+        int dst[B1_PER];
+#pragma unroll
+        for (int i = 0; i < B1_PER; ++i) {
+            const int id = lw + P3_LOADERS * i;
+            const int opnd = id / (8 * B1_SUB), sub = (id / 8) % B1_SUB, piece = id % 8;
+            const bool tr = opnd ? B_TR : A_TR;
+            const __bf16* base = opnd ? pa.B : pa.A;
+            const int ld = opnd ? pa.ldb : pa.lda;
+            const int r0 = opnd ? n0 : m0;
+            const size_t k0 = (size_t)s0 * B1_BK + sub * 32;
+            size_t off;
+            if (!tr) {
+                const int row = 16 * piece + (lane >> 2);
+                const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+                off = (size_t)(r0 + row) * ld + k0 + chunk * 8;
+            } else {
+                const int kk = 4 * piece + (lane >> 4);
+                const int log16 = (lane & 15) ^ (4 * (kk & 3));
+                off = (k0 + kk) * ld + r0 + log16 * 8;
+            }
+            src[i] = base + off;
+            dst[i] = (opnd * B1_SUB + sub) * 8192 + piece * 1024;
+        }
+        const size_t a_step = A_TR ? (size_t)B1_BK * pa.lda : (size_t)B1_BK;
+        const size_t b_step = B_TR ? (size_t)B1_BK * pa.ldb : (size_t)B1_BK;
+        auto issue_all = [&](int slot) {
+            char* base = ring1 + slot * B1_STAGE;
+#pragma unroll
+            for (int i = 0; i < B1_PER; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                                 (__attribute__((address_space(3))) void*)(base + dst[i]), 16, 0, 0);
+                src[i] += ((lw + P3_LOADERS * i) / (8 * B1_SUB)) ? b_step : a_step;
+            }
+        };
+        static_assert(B1_PER == 8, "the counted waits below assume 8 pieces per loader wave");
+        issue_all(0);
+        if (nk > 1) {
+            issue_all(1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                                     // barrier -1: stage 0 visible
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 2 < nk) {
+                issue_all((kt + 2) % B1_SLOTS);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                                 // barrier kt: stage kt + 1 visible
+        }
+        return;
+    }
+
+    // ---------------- MFMA waves ----------------
+    const int wm = wave >> 1, wn = wave & 1;
+    int offA[2][2], offB[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if constexpr (!A_TR) {
+                const int row = wm * 64 + 32 * t + (lane & 31);
+                offA[t][u] = row * 64 + (((2 * u + (lane >> 5)) ^ ((row >> 2) & 3)) * 16);
+            } else {
+                const int sl = lane & 15;
+                const int col = wm * 64 + 32 * t + 16 * ((lane >> 4) & 1) + 4 * (sl & 3);
+                const int kk = 8 * (lane >> 5) + 4 * u + (sl >> 2);
+                offA[t][u] = kk * 256 + (((col >> 3) ^ (4 * (kk & 3))) * 16) + ((col >> 2) & 1) * 8;
+            }
+            if constexpr (!B_TR) {
+                const int row = wn * 64 + 32 * t + (lane & 31);
+                offB[t][u] = row * 64 + (((2 * u + (lane >> 5)) ^ ((row >> 2) & 3)) * 16);
+            } else {
+                const int sl = lane & 15;
+                const int col = wn * 64 + 32 * t + 16 * ((lane >> 4) & 1) + 4 * (sl & 3);
+                const int kk = 8 * (lane >> 5) + 4 * u + (sl >> 2);
+                offB[t][u] = kk * 256 + (((col >> 3) ^ (4 * (kk & 3))) * 16) + ((col >> 2) & 1) * 8;
+            }
+        }
+    auto frag_tr = [&](const char* img, const int (&off)[2], int slab) {
+        bf16x8 r;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(img + off[q] + slab * 4096));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[4 * q + j] = __builtin_bit_cast(__bf16, (short)v[j]);
+        }
+        return r;
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) __builtin_amdgcn_s_barrier();                             // barrier -1
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* st = ring1 + (kt % B1_SLOTS) * B1_STAGE;
+        bf16x8 fa[B1_SUB][2][2], fb[B1_SUB][2][2];                        // [sub][slab][t]: all 16 reads issued up front
+#pragma unroll
+        for (int sb = 0; sb < B1_SUB; ++sb)
+#pragma unroll
+            for (int slab = 0; slab < 2; ++slab)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const char* ia = st + sb * 8192;
+                    const char* ib = st + (B1_SUB + sb) * 8192;
+                    if constexpr (!A_TR) fa[sb][slab][t] = *reinterpret_cast<const bf16x8*>(ia + offA[t][slab]);
+                    else fa[sb][slab][t] = frag_tr(ia, offA[t], slab);
+                    if constexpr (!B_TR) fb[sb][slab][t] = *reinterpret_cast<const bf16x8*>(ib + offB[t][slab]);
+                    else fb[sb][slab][t] = frag_tr(ib, offB[t], slab);
+                }
+#pragma unroll
+        for (int sb = 0; sb < B1_SUB; ++sb)
+#pragma unroll
+            for (int slab = 0; slab < 2; ++slab)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sb][slab][i], fb[sb][slab][j], acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                     // barrier kt
+    }
+    store_tile(g, m0, n0, z, wm, wn, lane, acc);
+}
+
+// fp32 [R, C] (row stride ldx) -> ONE bf16 matrix [Rp][Cp] (RNE), padding written as zeros
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ X, int R, int C, int ldx, int Rp,
+                                                        int Cp, __bf16* __restrict__ P) {
+    const size_t total = (size_t)Rp * Cp / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / (Cp / 4)), c = (int)(i % (Cp / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < R) {
+            const float* x = X + (size_t)row * ldx + c;
+            if (c + 3 < C && ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0)) {
+                v = *reinterpret_cast<const float4*>(x);
+            } else {
+                if (c < C) v.x = x[0];
+                if (c + 1 < C) v.y = x[1];
+                if (c + 2 < C) v.z = x[2];
+                if (c + 3 < C) v.w = x[3];
+            }
+        }
+        const bf16x2 lo = __builtin_convertvector(f32x2{v.x, v.y}, bf16x2);
+        const bf16x2 hi = __builtin_convertvector(f32x2{v.z, v.w}, bf16x2);
+        *reinterpret_cast<uint2*>(P + (size_t)row * Cp + c) = pack4(lo, hi);
+    }
+}
+
 // fp32 [R, C] (row stride ldx) -> three bf16 planes [Rp][Cp] each (Rp, Cp = R, C rounded up to 128; the padding is
 // written as zeros here, so the destination needs no initialisation).  x = p0 + p1 + p2 as in store_items.
 __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restrict__ X, int R, int C, int ldx, int Rp,
@@ -1210,6 +1409,20 @@ int launch_planes(const PlanesArgs& pa, dim3 grid, hipStream_t st) {
     return RENET_OK;
 }
 
+template <bool A_TR, bool B_TR>
+int launch_bf16s(const Bf16sArgs& pa, dim3 grid, hipStream_t st) {
+    static bool attr_set = false;      // benign race: the attribute is idempotent
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16s_kernel<A_TR, B_TR>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)B1_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    RENET_LAUNCH((gemm_bf16s_kernel<A_TR, B_TR>), grid, dim3(P3_THREADS), B1_LDS, st, pa);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1312,6 +1525,66 @@ int renet_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const floa
                     int split_k, float* workspace, size_t workspace_bytes, void* stream) {
     return gemm_planes_launch(true, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, split_k, workspace,
                               workspace_bytes, stream);
+}
+
+size_t renet_bf16_bytes(int R, int C) {
+    const size_t rp = ((size_t)R + 127) & ~(size_t)127, cp = ((size_t)C + 127) & ~(size_t)127;
+    return rp * cp * sizeof(__bf16);
+}
+
+int renet_pack_bf16(const float* X, int R, int C, int ldx, void* out, void* stream) {
+    if (R < 0 || C < 0 || ldx < C || !out) return RENET_ERR_BADARG;
+    const int Rp = (R + 127) & ~127, Cp = (C + 127) & ~127;
+    if (Rp == 0 || Cp == 0) return RENET_OK;
+    const size_t total = (size_t)Rp * Cp / 4;
+    const int blocks = (int)min((size_t)4096, (total + 255) / 256);
+    RENET_LAUNCH(pack_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, R, C, ldx, Rp, Cp, (__bf16*)out);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_gemm_bf16s(int a_tr, int b_tr, int M, int N, int K, float alpha, const void* Ap, int lda, const void* Bp,
+                     int ldb, float beta, float* C, int ldc, const float* bias, int split_k, float* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (M < 0 || N < 0 || K < 1 || ldc < N || !Ap || !Bp) return RENET_ERR_BADARG;
+    if (M == 0 || N == 0) return RENET_OK;
+    const int Mp = (M + 127) & ~127, Np = (N + 127) & ~127, Kp = (K + 127) & ~127;
+    if (lda < (a_tr ? Mp : Kp) || ldb < (b_tr ? Np : Kp) || (lda & 7) || (ldb & 7)) return RENET_ERR_BADARG;
+    if (split_k < 1) split_k = 1;
+    const int st_total = (K + B1_BK - 1) / B1_BK;
+    if (split_k > st_total) split_k = max(st_total, 1);
+    if (split_k > 1 && workspace_bytes < renet_gemm_workspace(M, N, split_k)) return RENET_ERR_WORKSPACE;
+    Bf16sArgs pa;
+    pa.A = (const __bf16*)Ap; pa.B = (const __bf16*)Bp;
+    pa.lda = lda; pa.ldb = ldb;
+    SplitArgs& g = pa.out;
+    g.A = nullptr; g.B = nullptr; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
+    g.lda = 0; g.ldb = 0; g.ldc = ldc; g.alpha = alpha; g.beta = beta;
+    g.split_k = split_k;
+    g.k_tiles_per_split = max(1, (st_total + split_k - 1) / split_k);
+    g.partial = workspace;
+    g.xcd_order = tile_order();
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, split_k);
+    int e;
+    if (!a_tr && !b_tr) e = launch_bf16s<false, false>(pa, grid, st);
+    else if (!a_tr && b_tr) e = launch_bf16s<false, true>(pa, grid, st);
+    else if (a_tr && !b_tr) e = launch_bf16s<true, false>(pa, grid, st);
+    else e = launch_bf16s<true, true>(pa, grid, st);
+    if (e != RENET_OK) return e;
+    if (split_k > 1) {
+        const size_t total = (size_t)M * N;
+        if (total <= (size_t)256 * 1024 && split_k >= 8) {
+            RENET_LAUNCH(split_reduce4_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, workspace,
+                               split_k, M, N, alpha, beta, bias, C, ldc);
+        } else {
+            int blocks = (int)min((size_t)2048, (total + 255) / 256);
+            RENET_LAUNCH(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, split_k, M, N, alpha,
+                               beta, bias, C, ldc);
+        }
+        RENET_LAUNCH_CHECK();
+    }
+    return RENET_OK;
 }
 
 size_t renet_planes_bytes(int R, int C) {

@@ -318,7 +318,7 @@ struct BCfg {
 // the kernels were bound by the L1's line rate).  Element (unit u, k) of gate g = in[g * sg + u * su + k * sk];
 // units >= U and k >= K are zero.   out index = (((ub * KG + kg) * G + g) * 3 + p) * 64 + lane  (x 8 bf16)
 __global__ __launch_bounds__(256) void split_frag_kernel(const float* __restrict__ in, int U, int K, int G, size_t sg,
-                                                         size_t su, size_t sk, int NUBk, int KGk,
+                                                         size_t su, size_t sk, int NUBk, int KGk, int NPL,
                                                          bf16x8* __restrict__ out) {
     const int total = NUBk * KGk * G * 64;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -335,9 +335,11 @@ __global__ __launch_bounds__(256) void split_frag_kernel(const float* __restrict
 #pragma unroll
             for (int p = 0; p < 3; ++p) o[p][e] = t.p[p];
         }
-        const size_t base = ((size_t)((ub * KGk + kg) * G + g) * 3) * 64 + lane;
+        // NPL = 3: the bf16x6 planes; NPL = 1 (bf16 mode): plane 0 only = rne(x)
+        const size_t base = ((size_t)((ub * KGk + kg) * G + g) * NPL) * 64 + lane;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) out[base + (size_t)p * 64] = o[p];
+        for (int p = 0; p < 3; ++p)
+            if (p < NPL) out[base + (size_t)p * 64] = o[p];
     }
 }
 
@@ -352,13 +354,20 @@ __device__ __forceinline__ f32x4 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3
     return acc;
 }
 
+// NPL = 3: the six leading term pairs (fp32-class); NPL = 1: ONE bf16 product (bf16 mode, BASELINE config 5)
+template <int NPL>
+__device__ __forceinline__ f32x4 mfma_p(const bf16x8 (&a)[NPL], const bf16x8 (&b)[NPL], f32x4 acc) {
+    if constexpr (NPL == 3) return mfma6(a, b, acc);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
 struct FwdProbB { const float* Gi; const bf16x8* Wp; const float* bhh; float* h_last; float* saved; };
 struct FwdProbsB { FwdProbB p[MAXP]; };
 struct BwdProbB { const float* dh_last; const bf16x8* WTp; const float* saved; float* dGi; float* dGh; };
 struct BwdProbsB { BwdProbB p[MAXP]; };
 
 // Wp: bf16 planes of W_hh in fragment order (split_frag_kernel with G = 3 gates)
-template <int H>
+template <int H, int NPL>
 __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly) {
     const int lay = ly.lay_of[blockIdx.y];
     const StepOff& so = ly.so[lay];
@@ -374,11 +383,11 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Hs = smem;                                                    // [MT][LDH] h of the current step (fp32)
     float* Hn = smem + MT * C::LDH;                                      // [MT][LDH] h being produced
-    __bf16* Hp = reinterpret_cast<__bf16*>(smem + 2 * MT * C::LDH);      // [3][MT][LDP] bf16 planes of Hs
+    __bf16* Hp = reinterpret_cast<__bf16*>(smem + 2 * MT * C::LDH);      // [NPL][MT][LDP] bf16 planes of Hs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = blockIdx.x * MT;
     for (int t = tid; t < 2 * MT * C::LDH; t += NT) Hs[t] = 0.f;      // h0 = 0
-    for (int t = tid; t < 3 * MT * Bc::LDP / 2; t += NT) reinterpret_cast<unsigned*>(Hp)[t] = 0u;   // and its planes
+    for (int t = tid; t < NPL * MT * Bc::LDP / 2; t += NT) reinterpret_cast<unsigned*>(Hp)[t] = 0u;   // and its planes
     __syncthreads();
     const int jj = lane & 15, kq = lane >> 4, ai = lane & 15;
     // Every workgroup streams the SAME W_hh planes from L2 every step, and workgroups that start together run the
@@ -420,18 +429,19 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
                 gr[reg] = gi[0]; gz[reg] = gi[H]; gn[reg] = gi[2 * H];
             }
             const float b_r = bhh[uc], b_z = bhh[H + uc], b_n = bhh[2 * H + uc];
-            const bf16x8* wf = Wp + (size_t)ub * Bc::KG * 9 * 64 + lane;       // fragment order (split_frag_kernel)
+            constexpr int NF = 3 * NPL;                                 // fragments per (unit block, k group)
+            const bf16x8* wf = Wp + (size_t)ub * Bc::KG * NF * 64 + lane;       // fragment order (split_frag_kernel)
             const __bf16* ha = Hp + ai * Bc::LDP + kq * 8;
             // W_hh fragments through a register ring, PF k groups ahead of the MFMAs that consume them (left to
             // itself the compiler re-uses four registers quads and keeps 1-3 loads in flight: the loop then runs at
             // one L2 latency per k group, 8.5 k cycles per unit block against 2 k of MFMA time)
             constexpr int PF = Bc::KG > 8 ? 2 : (Bc::KG > 3 ? 3 : Bc::KG - 1);
-            bf16x8 wb[PF + 1][3][3];                                    // [slot][gate][plane]
+            bf16x8 wb[PF + 1][3][NPL];                                  // [slot][gate][plane]
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
                 const int kq_ = q + rot_k >= Bc::KG ? q + rot_k - Bc::KG : q + rot_k;
 #pragma unroll
-                for (int f = 0; f < 9; ++f) wb[q][f / 3][f % 3] = wf[(kq_ * 9 + f) * 64];
+                for (int f = 0; f < NF; ++f) wb[q][f / NPL][f % NPL] = wf[(kq_ * NF + f) * 64];
             }
 #pragma unroll
             for (int kg0 = 0; kg0 < Bc::KG; ++kg0) {
@@ -439,15 +449,15 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
                 if (kg0 + PF < Bc::KG) {
                     const int kn = kg0 + PF + rot_k >= Bc::KG ? kg0 + PF + rot_k - Bc::KG : kg0 + PF + rot_k;
 #pragma unroll
-                    for (int f = 0; f < 9; ++f) wb[(kg0 + PF) % (PF + 1)][f / 3][f % 3] = wf[(kn * 9 + f) * 64];
+                    for (int f = 0; f < NF; ++f) wb[(kg0 + PF) % (PF + 1)][f / NPL][f % NPL] = wf[(kn * NF + f) * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                bf16x8 a[3];
+                bf16x8 a[NPL];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(ha + p * MT * Bc::LDP + kg * 32);
-                ar = mfma6(a, wb[kg0 % (PF + 1)][0], ar);
-                az = mfma6(a, wb[kg0 % (PF + 1)][1], az);
-                an = mfma6(a, wb[kg0 % (PF + 1)][2], an);
+                for (int p = 0; p < NPL; ++p) a[p] = *reinterpret_cast<const bf16x8*>(ha + p * MT * Bc::LDP + kg * 32);
+                ar = mfma_p<NPL>(a, wb[kg0 % (PF + 1)][0], ar);
+                az = mfma_p<NPL>(a, wb[kg0 % (PF + 1)][1], az);
+                an = mfma_p<NPL>(a, wb[kg0 % (PF + 1)][2], an);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // C layout: column = lane & 15 (unit u), row = 4 * (lane >> 4) + reg (sequence)
@@ -488,7 +498,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
             Hs[i * C::LDH + u] = v;
             const Planes3 s = split3(v);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) Hp[p * MT * Bc::LDP + i * Bc::LDP + u] = s.p[p];
+            for (int p = 0; p < NPL; ++p) Hp[p * MT * Bc::LDP + i * Bc::LDP + u] = s.p[p];
         }
         GT_PUT(wave, j, 5, GT_NOW());
         __syncthreads();
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
 }
 
 // WTp: bf16 planes of W_hh^T (unit = hidden unit, k over the 3H gate columns) in fragment order (G = 1)
-template <int H>
+template <int H, int NPL>
 __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly) {
     const int lay = ly.lay_of[blockIdx.y];
     const StepOff& so = ly.so[lay];
@@ -524,7 +534,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
         const int i = t / C::LDH, u = t - i * C::LDH;
         dHs[t] = (u < H && i0 + i < B) ? dh_last[(size_t)(i0 + i) * H + u] : 0.f;
     }
-    for (int t = tid; t < 3 * MT * Bc::LDP3 / 2; t += NT) reinterpret_cast<unsigned*>(Gp)[t] = 0u;
+    for (int t = tid; t < NPL * MT * Bc::LDP3 / 2; t += NT) reinterpret_cast<unsigned*>(Gp)[t] = 0u;
     __syncthreads();
     const int jj = lane & 15, kq = lane >> 4, ai = lane & 15;
     const int rot_id = (int)((blockIdx.x + gridDim.x * blockIdx.y) >> 3);      // see gru_fwd_bf_kernel
@@ -577,7 +587,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
                     const Planes3 sr = split3(gr), sz = split3(gz), sn = split3(gn);
                     __bf16* row = Gp + i * Bc::LDP3;
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
+                    for (int p = 0; p < NPL; ++p) {
                         row[p * PLG + u] = sr.p[p];
                         row[p * PLG + H + u] = sz.p[p];
                         row[p * PLG + 2 * H + u] = sn.p[p];
@@ -598,17 +608,17 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
                     f32x4 acc;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) acc[reg] = dHs[(4 * kq + reg) * C::LDH + (uok ? u : 0)];
-                    const bf16x8* wf = WTp + (size_t)ub * Bc::KG3 * 3 * 64 + lane;
+                    const bf16x8* wf = WTp + (size_t)ub * Bc::KG3 * NPL * 64 + lane;
                     const __bf16* ga = Gp + ai * Bc::LDP3 + kq * 8;
                     f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};                  // two chains: no MFMA waits on the previous one
                     // W_hh^T fragments through a register ring, PFB k groups ahead (see gru_fwd_bf_kernel)
                     constexpr int PFB = 5, RB = PFB + 1;
-                    bf16x8 wb[RB][3];
+                    bf16x8 wb[RB][NPL];
 #pragma unroll
                     for (int q = 0; q < PFB; ++q) {
                         const int kq_ = q + rot_k >= Bc::KG3 ? q + rot_k - Bc::KG3 : q + rot_k;
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) wb[q][p] = wf[(kq_ * 3 + p) * 64];
+                        for (int p = 0; p < NPL; ++p) wb[q][p] = wf[(kq_ * NPL + p) * 64];
                     }
 #pragma unroll 1
                     for (int base = 0; base < Bc::KG3; base += RB) {
@@ -620,14 +630,14 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
                                 if (kg0 + PFB < Bc::KG3) {
                                     const int kn = kg0 + PFB + rot_k >= Bc::KG3 ? kg0 + PFB + rot_k - Bc::KG3 : kg0 + PFB + rot_k;
 #pragma unroll
-                                    for (int p = 0; p < 3; ++p) wb[(r + PFB) % RB][p] = wf[(kn * 3 + p) * 64];
+                                    for (int p = 0; p < NPL; ++p) wb[(r + PFB) % RB][p] = wf[(kn * NPL + p) * 64];
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
-                                bf16x8 a[3];
+                                bf16x8 a[NPL];
 #pragma unroll
-                                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(ga + p * PLG + kg * 32);
-                                if (r & 1) acc2 = mfma6(a, wb[r], acc2);
-                                else acc = mfma6(a, wb[r], acc);
+                                for (int p = 0; p < NPL; ++p) a[p] = *reinterpret_cast<const bf16x8*>(ga + p * PLG + kg * 32);
+                                if (r & 1) acc2 = mfma_p<NPL>(a, wb[r], acc2);
+                                else acc = mfma_p<NPL>(a, wb[r], acc);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
@@ -991,14 +1001,14 @@ int launch_fwd(const FwdProbs& ps, int np, const Layouts& ly, hipStream_t st) {
     return RENET_OK;
 }
 
-template <int H>
+template <int H, int NPL = 3>
 int launch_fwd_bf(const FwdProbsB& ps, int np, const Layouts& ly, hipStream_t st) {
     using C = Cfg<H>;
     const size_t lds = (size_t)2 * MT * C::LDH * sizeof(float) + (size_t)3 * MT * BCfg<H>::LDP * sizeof(__bf16);
     static bool attr_set = false;
-    const int e = set_lds(gru_fwd_bf_kernel<H>, lds, attr_set);
+    const int e = set_lds(gru_fwd_bf_kernel<H, NPL>, lds, attr_set);
     if (e != RENET_OK) return e;
-    RENET_LAUNCH((gru_fwd_bf_kernel<H>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(NT), lds, st, ps, ly);
+    RENET_LAUNCH((gru_fwd_bf_kernel<H, NPL>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(NT), lds, st, ps, ly);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -1015,14 +1025,14 @@ int launch_bwd(const BwdProbs& ps, int np, const Layouts& ly, hipStream_t st) {
     return RENET_OK;
 }
 
-template <int H>
+template <int H, int NPL = 3>
 int launch_bwd_bf(const BwdProbsB& ps, int np, const Layouts& ly, hipStream_t st) {
     using C = Cfg<H>;
     const size_t lds = (size_t)MT * C::LDH * sizeof(float) + (size_t)3 * MT * BCfg<H>::LDP3 * sizeof(__bf16);
     static bool attr_set = false;
-    const int e = set_lds(gru_bwd_bf_kernel<H>, lds, attr_set);
+    const int e = set_lds(gru_bwd_bf_kernel<H, NPL>, lds, attr_set);
     if (e != RENET_OK) return e;
-    RENET_LAUNCH((gru_bwd_bf_kernel<H>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(NT), lds, st, ps, ly);
+    RENET_LAUNCH((gru_bwd_bf_kernel<H, NPL>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(NT), lds, st, ps, ly);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -1146,11 +1156,12 @@ inline size_t fwd_plane_bytes(int H) { return (size_t)nub(H) * ((H + 31) / 32) *
 inline size_t bwd_t_bytes(int H) { return align256((size_t)3 * H * H * sizeof(float)); }
 inline size_t bwd_plane_bytes(int H) { return (size_t)nub(H) * ((3 * H + 31) / 32) * 3 * 1024; }
 
-int split_frag(const float* in, int U, int K, int G, size_t sg, size_t su, size_t sk, bf16x8* out, hipStream_t st) {
+int split_frag(const float* in, int U, int K, int G, size_t sg, size_t su, size_t sk, bf16x8* out, hipStream_t st,
+               int npl = 3) {
     const int NUBk = (U + 15) / 16, KGk = (K + 31) / 32;
     const int total = NUBk * KGk * G * 64;
     RENET_LAUNCH(split_frag_kernel, dim3((total + 255) / 256), dim3(256), 0, st, in, U, K, G, sg, su, sk, NUBk,
-                       KGk, out);
+                       KGk, npl, out);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -1245,10 +1256,29 @@ int plane_slot(int k, const float* const* W) {
 
 extern "C" {
 
+static int gru_fwd_impl(int npl, int n, const float* const* Gi, const int32_t* const* step_off, const int* L, int H,
+                        const float* const* Whh, const float* const* bhh, float* const* h_last,
+                        const int* out_rows, float* const* saved, float* workspace, size_t workspace_bytes,
+                        void* stream);
+
 int renet_gru_fwd_layouts(int n, const float* const* Gi, const int32_t* const* step_off, const int* L, int H,
                           const float* const* Whh, const float* const* bhh, float* const* h_last,
                           const int* out_rows, float* const* saved, float* workspace, size_t workspace_bytes,
                           void* stream) {
+    return gru_fwd_impl(3, n, Gi, step_off, L, H, Whh, bhh, h_last, out_rows, saved, workspace, workspace_bytes, stream);
+}
+
+int renet_gru_fwd_layouts_bf16(int n, const float* const* Gi, const int32_t* const* step_off, const int* L, int H,
+                               const float* const* Whh, const float* const* bhh, float* const* h_last,
+                               const int* out_rows, float* const* saved, float* workspace, size_t workspace_bytes,
+                               void* stream) {
+    return gru_fwd_impl(1, n, Gi, step_off, L, H, Whh, bhh, h_last, out_rows, saved, workspace, workspace_bytes, stream);
+}
+
+static int gru_fwd_impl(int npl, int n, const float* const* Gi, const int32_t* const* step_off, const int* L, int H,
+                        const float* const* Whh, const float* const* bhh, float* const* h_last,
+                        const int* out_rows, float* const* saved, float* workspace, size_t workspace_bytes,
+                        void* stream) {
     if (n < 1 || n > MAXP) return RENET_ERR_BADARG;
     Layouts ly;
     int B_of[MAXP];
@@ -1257,7 +1287,7 @@ int renet_gru_fwd_layouts(int n, const float* const* Gi, const int32_t* const* s
     if (max_rows(ly) == 0) return RENET_OK;
     if (H != 100 && H != 200 && H != 400) return RENET_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (use_f32()) {
+    if (use_f32() && npl == 3) {
         FwdProbs ps;
         for (int i = 0; i < MAXP; ++i) {
             const int k = i < n ? i : 0;
@@ -1270,7 +1300,7 @@ int renet_gru_fwd_layouts(int n, const float* const* Gi, const int32_t* const* s
             default: return launch_fwd<400>(ps, n, ly, st);
         }
     }
-    const bool steps = !use_persistent(H);
+    const bool steps = npl == 3 && !use_persistent(H);
     int Bmax = 0;
     for (int k = 0; k < n; ++k) Bmax = B_of[k] > Bmax ? B_of[k] : Bmax;
     const size_t per = renet_gru_workspace(steps ? Bmax : 0, H);
@@ -1283,7 +1313,7 @@ int renet_gru_fwd_layouts(int n, const float* const* Gi, const int32_t* const* s
         const int slot = plane_slot(k, Whh);
         bf16x8* planes = reinterpret_cast<bf16x8*>(reinterpret_cast<char*>(workspace) + (size_t)slot * per);
         if (i < n && slot == k) {                   // gate g of unit u, input k: W_hh[g*H + u][k]
-            const int e = split_frag(Whh[k], H, H, 3, (size_t)H * H, (size_t)H, 1, planes, st);
+            const int e = split_frag(Whh[k], H, H, 3, (size_t)H * H, (size_t)H, 1, planes, st, npl);
             if (e != RENET_OK) return e;
         }
         ps.p[i].Gi = Gi[k]; ps.p[i].Wp = planes; ps.p[i].bhh = bhh[k]; ps.p[i].h_last = h_last[k];
@@ -1311,6 +1341,13 @@ int renet_gru_fwd_layouts(int n, const float* const* Gi, const int32_t* const* s
             default: return run_steps_fwd<400>(n, ly, sf, stt, st);
         }
     }
+    if (npl == 1) {
+        switch (H) {
+            case 100: return launch_fwd_bf<100, 1>(ps, n, ly, st);
+            case 200: return launch_fwd_bf<200, 1>(ps, n, ly, st);
+            default: return launch_fwd_bf<400, 1>(ps, n, ly, st);
+        }
+    }
     switch (H) {
         case 100: return launch_fwd_bf<100>(ps, n, ly, st);
         case 200: return launch_fwd_bf<200>(ps, n, ly, st);
@@ -1318,9 +1355,25 @@ int renet_gru_fwd_layouts(int n, const float* const* Gi, const int32_t* const* s
     }
 }
 
+static int gru_bwd_impl(int npl, int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
+                        const float* const* Whh, const float* const* saved, float* const* dGi,
+                        float* const* dGh, float* workspace, size_t workspace_bytes, void* stream);
+
 int renet_gru_bwd_layouts(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
                           const float* const* Whh, const float* const* saved, float* const* dGi,
                           float* const* dGh, float* workspace, size_t workspace_bytes, void* stream) {
+    return gru_bwd_impl(3, n, dh_last, step_off, L, H, Whh, saved, dGi, dGh, workspace, workspace_bytes, stream);
+}
+
+int renet_gru_bwd_layouts_bf16(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
+                               const float* const* Whh, const float* const* saved, float* const* dGi,
+                               float* const* dGh, float* workspace, size_t workspace_bytes, void* stream) {
+    return gru_bwd_impl(1, n, dh_last, step_off, L, H, Whh, saved, dGi, dGh, workspace, workspace_bytes, stream);
+}
+
+static int gru_bwd_impl(int npl, int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
+                        const float* const* Whh, const float* const* saved, float* const* dGi,
+                        float* const* dGh, float* workspace, size_t workspace_bytes, void* stream) {
     if (n < 1 || n > MAXP) return RENET_ERR_BADARG;
     Layouts ly;
     int B_of[MAXP];
@@ -1329,8 +1382,8 @@ int renet_gru_bwd_layouts(int n, const float* const* dh_last, const int32_t* con
     if (max_rows(ly) == 0) return RENET_OK;
     if (H != 100 && H != 200 && H != 400) return RENET_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const bool f32 = use_f32();
-    const bool steps = !f32 && !use_persistent(H);
+    const bool f32 = use_f32() && npl == 3;
+    const bool steps = npl == 3 && !f32 && !use_persistent(H);
     int Bmax = 0;
     for (int k = 0; k < n; ++k) Bmax = B_of[k] > Bmax ? B_of[k] : Bmax;
     const size_t per = renet_gru_workspace(steps ? Bmax : 0, H);
@@ -1351,7 +1404,7 @@ int renet_gru_bwd_layouts(int n, const float* const* dh_last, const int32_t* con
                                    3 * H, H, WhhT);
                 RENET_LAUNCH_CHECK();
             } else {                                // W_hh^T: unit u = hidden unit, k = gate column c: W_hh[c][u]
-                const int e = split_frag(Whh[k], H, 3 * H, 1, 0, 1, (size_t)H, planes, st);
+                const int e = split_frag(Whh[k], H, 3 * H, 1, 0, 1, (size_t)H, planes, st, npl);
                 if (e != RENET_OK) return e;
             }
         }
@@ -1389,6 +1442,13 @@ int renet_gru_bwd_layouts(int n, const float* const* dh_last, const int32_t* con
             case 100: return launch_bwd<100>(ps, n, ly, st);
             case 200: return launch_bwd<200>(ps, n, ly, st);
             default: return launch_bwd<400>(ps, n, ly, st);
+        }
+    }
+    if (npl == 1) {
+        switch (H) {
+            case 100: return launch_bwd_bf<100, 1>(pb, n, ly, st);
+            case 200: return launch_bwd_bf<200, 1>(pb, n, ly, st);
+            default: return launch_bwd_bf<400, 1>(pb, n, ly, st);
         }
     }
     switch (H) {

@@ -132,9 +132,11 @@ class RGCNLayerFn(Function):
         n_out = n if (n_out is None or n_out >= n) else int(n_out)
         pruned = n_out < n
         shift = g.num_types // 2 if reverse else 0                     # type_o = type_s +- R (utils.py:75-76)
-        out = K.gemm(h[:n_out], loop_weight)                           # RGCN.py:35
+        h_op = K.operand(h[:n_out])                                    # (bf16 mode: packed once, reused by backward)
+        out = K.gemm(h_op, loop_weight)                                # RGCN.py:35
         K.rgcn_gather_items(h, g, weight, shift, False, out, drop_p, seed, relu, out, use_norm=True, pruned=pruned)
         ctx.g, ctx.relu, ctx.drop_p, ctx.seed, ctx.shift, ctx.n_out = g, relu, drop_p, seed, shift, n_out
+        ctx.h_op = h_op if isinstance(h_op, K.BF16Mat) else None
         ctx.save_for_backward(h, weight, loop_weight, out)
         return out
 
@@ -158,7 +160,9 @@ class RGCNLayerFn(Function):
         pair_shift = (ctx.shift + g.num_types // 2) % g.num_types
         K.rgcn_gather_items(gn, g, weight, pair_shift, True, None, 0.0, 0, False, dh, use_norm=False, pruned=pruned,
                             src_limit=n_out if pruned else 0)
-        K.gemm(g_loop, loop_weight, tb=True, out=dh[:n_out], beta=1.0)     # += g_loop @ W_loop^T (rows < n_out)
+        gl_op = K.operand(g_loop)
+        h_op = ctx.h_op if ctx.h_op is not None else h[:n_out]
+        K.gemm(gl_op, loop_weight, tb=True, out=dh[:n_out], beta=1.0)      # += g_loop @ W_loop^T (rows < n_out)
         acc = tgt_w is not None                                        # straight into weight.grad (beta = 1)
         d_w = tgt_w if acc else torch.empty_like(weight)
         if pruned:
@@ -168,10 +172,10 @@ class RGCNLayerFn(Function):
             K.rgcn_bwd_w(h, gn, g.e_src, g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr,
                          g.num_types, ctx.shift, d_w, beta=1.0 if acc else 0.0)
         if tgt_loop is not None:                                       # h^T @ g_loop (auto split-K), accumulated
-            K.gemm(h[:n_out], g_loop, ta=True, out=tgt_loop, beta=1.0)
+            K.gemm(h_op, gl_op, ta=True, out=tgt_loop, beta=1.0)
             d_loop = None
         else:
-            d_loop = K.gemm(h[:n_out], g_loop, ta=True)
+            d_loop = K.gemm(h_op, gl_op, ta=True)
         return dh, None if acc else d_w, d_loop, None, None, None, None, None, None
 
 
@@ -230,12 +234,13 @@ class RGCNTableLayerFn(Function):
         gs = torch.zeros(table.shape, device=dev, dtype=torch.float32)
         d_tab = tgt_tab if tgt_tab is not None else torch.zeros(table.shape, device=dev, dtype=torch.float32)
         K.segment_add2(dh, g_loop, g.plan_node_ent, d_tab, gs)
-        K.gemm(gs, loop_weight, tb=True, out=d_tab, beta=1.0)             # += segsum(g_loop) @ W_loop^T
+        gs_op = K.operand(gs)
+        K.gemm(gs_op, loop_weight, tb=True, out=d_tab, beta=1.0)          # += segsum(g_loop) @ W_loop^T
         if tgt_loop is not None:
-            K.gemm(table, gs, ta=True, out=tgt_loop, beta=1.0)
+            K.gemm(table, gs_op, ta=True, out=tgt_loop, beta=1.0)
             d_loop = None
         else:
-            d_loop = K.gemm(table, gs, ta=True)
+            d_loop = K.gemm(table, gs_op, ta=True)
         return (None if tgt_tab is not None else d_tab), None if acc else d_w, d_loop, None, None, None, None, None
 
 
@@ -325,7 +330,9 @@ class MultiGRUFn(Function):
         xs, w_ihs, w_hhs = ts[0::5], ts[1::5], ts[2::5]
         b_ihs, b_hhs = ts[3::5], ts[4::5]
         hdim = w_hhs[0].shape[1]
-        gis = [K.gemm(x, w, tb=True, bias=b) for x, w, b in zip(xs, w_ihs, b_ihs)]
+        x_ops = [K.operand(x) for x in xs]                              # (bf16 mode: packed once, reused by dW_ih)
+        gis = [K.gemm(x, w, tb=True, bias=b) for x, w, b in zip(x_ops, w_ihs, b_ihs)]
+        ctx.x_ops = x_ops if any(isinstance(x, K.BF16Mat) for x in x_ops) else None
         hs, svs = K.gru_fwd_layouts(gis, step_offs, hdim, w_hhs, b_hhs, total_rows)     # rows past nnz are zero
         ctx.step_offs, ctx.hdim, ctx.n = step_offs, hdim, n
         ctx.nnz = [int(o[1] - o[0]) if len(o) > 1 else 0 for o in step_offs]
@@ -347,11 +354,13 @@ class MultiGRUFn(Function):
             t_ih, t_hh = (grad_target(t) for t in ctx.src_w[k])
             t_bi, t_bh = (grad_target(t) for t in ctx.src_b[k])
             dgi, dgh, xx, s_ = d_gis[k], d_ghs[k], xs[k], svs[k]
+            x_op = ctx.x_ops[k] if ctx.x_ops is not None else xx
+            dgi_op = K.operand(dgi)                                    # consumed by dW_ih and dX
             dwi = dwh = dbi = dbh = None
             if t_ih is not None:
-                K.gemm(dgi, xx, ta=True, out=t_ih, beta=1.0)
+                K.gemm(dgi_op, x_op, ta=True, out=t_ih, beta=1.0)
             else:
-                dwi = K.gemm(dgi, xx, ta=True)
+                dwi = K.gemm(dgi_op, x_op, ta=True)
             if t_hh is not None:
                 K.gemm(dgh, s_[:, 4 * hdim:], ta=True, out=t_hh, beta=1.0)
             else:
@@ -370,10 +379,10 @@ class MultiGRUFn(Function):
                 # embedding, a constant, Aggregator.py:150-155): contract only the live columns of W_ih; the rest
                 # of dX stays unwritten
                 dxx = torch.empty_like(xx)
-                K.gemm(dgi, w_ihs[k][:, :live], out=dxx[:, :live])
+                K.gemm(dgi_op, w_ihs[k][:, :live], out=dxx[:, :live])
                 dxx[:, live:].zero_()         # defined values for any other consumer (hooks, detect_anomaly): 6 MB
             else:
-                dxx = K.gemm(dgi, w_ihs[k])
+                dxx = K.gemm(dgi_op, w_ihs[k])
             out += [dxx, dwi, dwh, dbi, dbh]
         return tuple(out)
 
@@ -399,7 +408,8 @@ class HeadCEFn(Function):
         c = _c(c) if c is not None else None
         b, d = hmid.shape
         feat = K.concat3_fwd(a, ia, hmid, c, ic, drop_p, seed)
-        logits = K.gemm(feat, weight, tb=True, bias=bias)                # [B, C]
+        feat_op = K.operand(feat)                                        # (bf16 mode: packed once, reused by dW)
+        logits = K.gemm(feat_op, weight, tb=True, bias=bias)             # [B, C]
         if debug_tap is not None:
             debug_tap('logits', logits)
         need_grad = any(ctx.needs_input_grad)
@@ -411,6 +421,7 @@ class HeadCEFn(Function):
         if need_grad:
             ctx.save_for_backward(feat, logits, weight)
             ctx.consumed = False
+            ctx.feat_op = feat_op if isinstance(feat_op, K.BF16Mat) else None
         return row_loss.mean() if loss_scale == 1.0 else row_loss.mean() * float(loss_scale)
 
     @staticmethod
@@ -425,12 +436,14 @@ class HeadCEFn(Function):
         # every gradient below is linear in dlogits: fold the upstream scalar (1 for `loss_s + loss_o`, 0.1 for
         # the relation head) into it ONCE, from device memory, instead of scaling three results
         K.scale_by_device_scalar(dlogits, g)
-        dfeat = K.gemm(dlogits, weight)                                  # [B, parts*D]
+        dl_op = K.operand(dlogits)                                       # consumed by dfeat and dW
+        f_op = ctx.feat_op if ctx.feat_op is not None else feat
+        dfeat = K.gemm(dl_op, weight)                                    # [B, parts*D]
         if t_w is not None:
-            K.gemm(dlogits, feat, ta=True, out=t_w, beta=1.0)
+            K.gemm(dl_op, f_op, ta=True, out=t_w, beta=1.0)
             d_w = None
         else:
-            d_w = K.gemm(dlogits, feat, ta=True)
+            d_w = K.gemm(dl_op, f_op, ta=True)
         if t_b is not None:
             K.colsum(dlogits, out=t_b, beta=1.0)
             d_b = None

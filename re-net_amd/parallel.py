@@ -233,6 +233,9 @@ class HipAdam(object):
         self.norm = torch.zeros(1, device=self.m.device, dtype=torch.float32)
         self.reducer = None
         self._hook = None
+        # bf16-storage mode: the GEMM wrappers may cache bf16 copies of these weights between steps
+        self._weights = [p for p in self.params.params if p.dim() == 2]
+        K.register_weights(self._weights)
         names = [n for n, _ in module.named_parameters()]
         if 'linear.weight' in names and 'linear.bias' in names:       # RENet: overlap the score head's bucket
             early = [p for n, p in module.named_parameters() if n in ('linear.weight', 'linear.bias')]
@@ -248,6 +251,9 @@ class HipAdam(object):
             import ops
             ops.unregister_grad_done_hook(self._hook)
             self._hook = None
+        if getattr(self, '_weights', None):
+            self.K.unregister_weights(self._weights)
+            self._weights = []
 
     def __del__(self):
         try:
@@ -272,6 +278,7 @@ class HipAdam(object):
         self.t += 1
         self.K.adam_step(self.params.flat, self.grads.flat, self.m, self.v, self.lr, self.betas[0], self.betas[1],
                          self.eps, self.wd, self.max_norm, self.t, True, self.norm, grad_scale=scale)
+        self.K.weights_changed()
 
 
 class _StepScope(object):

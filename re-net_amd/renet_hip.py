@@ -53,6 +53,10 @@ _SIGNATURES = {
     'renet_pack_planes': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'renet_gemm_planes': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                   c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'renet_bf16_bytes': (c_size_t, [c_int, c_int]),
+    'renet_pack_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'renet_gemm_bf16s': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
+                                 c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'renet_colsum_workspace': (c_size_t, [c_int, c_int]),
     'renet_colsum': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     'renet_scale_by_device_scalar': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -74,6 +78,10 @@ _SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_gru_bwd_layouts': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    'renet_gru_fwd_layouts_bf16': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'renet_gru_bwd_layouts_bf16': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_concat3_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                                   c_u64, c_void_p, c_void_p]),
     'renet_concat3_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_u64, c_void_p, c_void_p,
@@ -391,6 +399,8 @@ def auto_split_k(m, n, k):
     return best
 
 
+# 'bf16s'  : bf16 STORAGE: operands are (packed to) bf16 matrices in HBM, LDS-DMA staging, one bf16 MFMA product
+#            (gemm_bf16s; BASELINE config 5 -- bench.py --dtype bf16)
 # 'bf16'   : operands rounded to bf16 on the way into LDS, ONE v_mfma_f32_32x32x16_bf16 product, fp32 accumulate
 #            (mixed precision for BASELINE config 5; tensors stay fp32 in memory)
 # 'f32'    : v_mfma_f32_32x32x2_f32, exact fp32 products (gemm.hip)
@@ -399,9 +409,125 @@ def auto_split_k(m, n, k):
 GEMM_MODE = os.environ.get('RENET_GEMM', 'bf16x6')      # RENET_GEMM=f32 selects the exact-fp32 MFMA kernel
 
 
+class BF16Mat(object):
+    """A matrix [R, C] stored as bf16 in a zero-padded [Rp, Cp] buffer (Rp, Cp multiples of 128): the operand format of
+    gemm_bf16s (renet_pack_bf16 / a producer kernel that writes it directly)."""
+    __slots__ = ('p', 'R', 'C')
+
+    def __init__(self, p, R, C):
+        self.p, self.R, self.C = p, R, C
+
+    @property
+    def shape(self):
+        return (self.R, self.C)
+
+
+def pack_bf16(x):
+    """fp32 [R, C] (row-strided views allowed) -> BF16Mat."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
+        raise RenetHipError('pack_bf16 needs a 2-D float32 device tensor with unit inner stride')
+    r, c = x.shape
+    rp, cp = (r + 127) & ~127, (c + 127) & ~127
+    p = torch.empty(rp, cp, device=x.device, dtype=torch.bfloat16)
+    t0 = _timer.begin() if _timer is not None else None
+    _check(lib().renet_pack_bf16(x.data_ptr(), r, c, x.stride(0), p.data_ptr(), _stream()), 'pack_bf16')
+    if t0 is not None:
+        _timer.end('pack_bf16', t0, nbytes=float(r * c * 4 + rp * cp * 2))
+    return BF16Mat(p, r, c)
+
+
+# bf16 copies of WEIGHTS are cached between optimizer steps: parallel.HipAdam registers its parameters (stable
+# addresses inside the flat buffer) and bumps the epoch after every update; any other tensor is packed on every use.
+_weight_ptrs = {}              # data_ptr -> (rows, cols)
+_weight_cache = {}             # data_ptr -> (epoch, BF16Mat)
+_weight_epoch = [0]
+
+
+def register_weights(tensors):
+    for t in tensors:
+        if t.dim() == 2 and t.is_contiguous():
+            _weight_ptrs[t.data_ptr()] = tuple(t.shape)
+
+
+def unregister_weights(tensors):
+    for t in tensors:
+        _weight_ptrs.pop(t.data_ptr(), None)
+        _weight_cache.pop(t.data_ptr(), None)
+
+
+def weights_changed():
+    _weight_epoch[0] += 1
+
+
+def _as_bf16(x):
+    """Operand of gemm_bf16s for tensor / BF16Mat x -> (BF16Mat, rows, cols) of the LOGICAL matrix x."""
+    if isinstance(x, BF16Mat):
+        return x, x.R, x.C
+    ptr = x.data_ptr()
+    shp = _weight_ptrs.get(ptr)
+    if shp is not None and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) == shp[1] and \
+            x.shape[0] <= shp[0] and x.shape[1] <= shp[1]:
+        # a registered weight, or a leading row / column block of it (W_ih[:, :live]): one cached copy serves both
+        ent = _weight_cache.get(ptr)
+        if ent is None or ent[0] != _weight_epoch[0]:
+            full = torch.as_strided(x, shp, (shp[1], 1))
+            ent = (_weight_epoch[0], pack_bf16(full))
+            _weight_cache[ptr] = ent
+        return ent[1], x.shape[0], x.shape[1]
+    m = pack_bf16(x)
+    return m, m.R, m.C
+
+
+def operand(x):
+    """GEMM operand for activation tensor x: in bf16-storage mode its bf16 copy (packed ONCE, to be handed to every
+    GEMM that consumes x), otherwise x itself."""
+    if GEMM_MODE == 'bf16s' and not isinstance(x, BF16Mat):
+        return pack_bf16(x)
+    return x
+
+
+def gemm_bf16s(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, split_k=None):
+    """gemm() on bf16-STORED operands (fp32 tensors are packed first; registered weights come from the cache).
+    A leading block of a cached matrix along the CONTRACTION dimension is only valid when the block ends on a 64-wide
+    k stage (or at the matrix edge, where the padding is zero) -- otherwise it is packed afresh."""
+    def prep(x, k_axis):
+        m, r, c = _as_bf16(x)
+        klen, kfull = (r, m.R) if k_axis == 0 else (c, m.C)
+        if klen != kfull and (klen % 64) != 0:
+            m = pack_bf16(x)
+            r, c = m.R, m.C
+        return m, r, c
+    pa, ar, ac = prep(a, 0 if ta else 1)
+    pb, br, bc = prep(b, 1 if tb else 0)
+    m, k = (ac, ar) if ta else (ar, ac)
+    n, k2 = (br, bc) if tb else (bc, br)
+    if k != k2:
+        raise RenetHipError('gemm inner dimensions differ: %d vs %d' % (k, k2))
+    if out is None:
+        if beta != 0.0:
+            raise RenetHipError('beta != 0 needs an output tensor')
+        out = torch.empty(m, n, device=pa.p.device, dtype=torch.float32)
+    if split_k is None:
+        split_k = auto_split_k(m, n, k)
+    ws_ptr, ws_bytes = None, 0
+    if split_k > 1:
+        ws_bytes = lib().renet_gemm_workspace(m, n, split_k)
+        ws = torch.empty(ws_bytes // 4, device=out.device, dtype=torch.float32)
+        ws_ptr = ws.data_ptr()
+    t0 = _timer.begin() if _timer is not None else None
+    _check(lib().renet_gemm_bf16s(int(ta), int(not tb), m, n, k, float(alpha), pa.p.data_ptr(), pa.p.shape[1],
+                                  pb.p.data_ptr(), pb.p.shape[1], float(beta), out.data_ptr(), _ld(out), _f32(bias),
+                                  split_k, ws_ptr, ws_bytes, _stream()), 'gemm_bf16s')
+    if t0 is not None:
+        _timer.end('gemm_f32', t0, flops=2.0 * m * n * k, tag=(int(ta), int(tb), m, n, k, split_k))
+    return out
+
+
 def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, split_k=None, mode=None):
     """out = alpha * op(a) @ op(b) + bias + beta * out.  a/b may be row-strided views.
     split_k=None picks the deterministic split-K factor automatically."""
+    if (mode or GEMM_MODE) == 'bf16s' or isinstance(a, BF16Mat) or isinstance(b, BF16Mat):
+        return gemm_bf16s(a, b, ta=ta, tb=tb, out=out, bias=bias, alpha=alpha, beta=beta, split_k=split_k)
     if not (a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32):
         raise RenetHipError('gemm operands must be float32 device tensors')
     m, k = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
@@ -528,31 +654,14 @@ def seq_assemble_bwd(dx, dxr, step_off, num_steps, num_seq, d, drop_p, seed_x, s
 
 def gru_fwd(gi, step_off_host, hdim, w_hh, b_hh, out_rows=0):
     """gi [S,3H] packed; step_off_host: ctypes int32 array (L+1).  Returns (h_last[max(B, out_rows), H] with
-    rows >= B zero, saved[S,5H])."""
-    L = len(step_off_host) - 1
-    s = gi.shape[0]
-    b = step_off_host[1] - step_off_host[0] if L > 0 else 0
-    out_rows = max(int(out_rows), b)
-    h_last = torch.empty(out_rows, hdim, device=gi.device, dtype=torch.float32)
-    saved = torch.empty(s, 5 * hdim, device=gi.device, dtype=torch.float32)
-    nbytes = lib().renet_gru_workspace(b, hdim)
-    ws = torch.empty(max(nbytes // 4, 1), device=gi.device, dtype=torch.float32)
-    _check(lib().renet_gru_fwd(_f32(gi), ctypes.cast(step_off_host, c_void_p), L, hdim, _f32(w_hh), _f32(b_hh),
-                               _f32(h_last), out_rows, _f32(saved), ws.data_ptr(), nbytes, _stream()), 'gru_fwd')
-    return h_last, saved
+    rows >= B zero, saved[S,5H]).  (One-problem form of gru_fwd_layouts, which also selects the bf16-mode kernels.)"""
+    hs, svs = gru_fwd_layouts([gi], [step_off_host], hdim, [w_hh], [b_hh], [out_rows])
+    return hs[0], svs[0]
 
 
 def gru_bwd(dh_last, step_off_host, hdim, w_hh, saved):
-    L = len(step_off_host) - 1
-    s = saved.shape[0]
-    b = dh_last.shape[0]
-    d_gi = torch.empty(s, 3 * hdim, device=saved.device, dtype=torch.float32)
-    d_gh = torch.empty(s, 3 * hdim, device=saved.device, dtype=torch.float32)
-    nbytes = lib().renet_gru_workspace(b, hdim)
-    ws = torch.empty(max(nbytes // 4, 1), device=saved.device, dtype=torch.float32)
-    _check(lib().renet_gru_bwd(_f32(dh_last), ctypes.cast(step_off_host, c_void_p), L, hdim, _f32(w_hh),
-                               _f32(saved), _f32(d_gi), _f32(d_gh), ws.data_ptr(), nbytes, _stream()), 'gru_bwd')
-    return d_gi, d_gh
+    d_gis, d_ghs = gru_bwd_layouts([dh_last], [step_off_host], hdim, [w_hh], [saved])
+    return d_gis[0], d_ghs[0]
 
 
 def _ptrs(tensors):
@@ -621,7 +730,8 @@ def gru_fwd_layouts(gis, step_offs, hdim, w_hhs, b_hhs, out_rows):
     ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
     so, ls = _offs(step_offs)
     t0 = _timer.begin() if _timer is not None else None
-    _check(lib().renet_gru_fwd_layouts(n, _ptrs(gis), so, ls, hdim, _ptrs(w_hhs), _ptrs(b_hhs), _ptrs(hs),
+    fn = lib().renet_gru_fwd_layouts_bf16 if GEMM_MODE == 'bf16s' else lib().renet_gru_fwd_layouts
+    _check(fn(n, _ptrs(gis), so, ls, hdim, _ptrs(w_hhs), _ptrs(b_hhs), _ptrs(hs),
                                        (ctypes.c_int * n)(*rows), _ptrs(svs), ws.data_ptr(), nbytes, _stream()),
            'gru_fwd_layouts')
     if t0 is not None:
@@ -641,7 +751,8 @@ def gru_bwd_layouts(dh_lasts, step_offs, hdim, w_hhs, saveds):
     ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
     so, ls = _offs(step_offs)
     t0 = _timer.begin() if _timer is not None else None
-    _check(lib().renet_gru_bwd_layouts(n, _ptrs(dh_lasts), so, ls, hdim, _ptrs(w_hhs), _ptrs(saveds), _ptrs(d_gis),
+    fn = lib().renet_gru_bwd_layouts_bf16 if GEMM_MODE == 'bf16s' else lib().renet_gru_bwd_layouts
+    _check(fn(n, _ptrs(dh_lasts), so, ls, hdim, _ptrs(w_hhs), _ptrs(saveds), _ptrs(d_gis),
                                        _ptrs(d_ghs), ws.data_ptr(), nbytes, _stream()), 'gru_bwd_layouts')
     if t0 is not None:
         _timer.end('gru_recurrence', t0, flops=sum(2.0 * 3 * hdim * hdim * s_.shape[0] for s_ in saveds))

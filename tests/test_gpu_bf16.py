@@ -31,7 +31,8 @@ def dev():
 @pytest.mark.parametrize('m,n,k', [(1, 1, 1), (7, 5, 3), (128, 128, 32), (257, 130, 71), (1024, 777, 600), (333, 400, 4),
                                    (96, 100, 5000)])
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_bf16_gemm_matches_fp64_of_the_rounded_operands(dev, m, n, k, ta, tb):
+@pytest.mark.parametrize('mode', ['bf16', 'bf16s'])
+def test_bf16_gemm_matches_fp64_of_the_rounded_operands(dev, m, n, k, ta, tb, mode):
     import renet_hip as K
     rng = np.random.RandomState(m * 131 + n * 17 + k + ta * 2 + tb)
     a = rng.uniform(-1, 1, (k, m) if ta else (m, k)).astype(np.float32)
@@ -39,7 +40,8 @@ def test_bf16_gemm_matches_fp64_of_the_rounded_operands(dev, m, n, k, ta, tb):
     bias = rng.uniform(-1, 1, n).astype(np.float32)
     ta_, tb_ = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
     sk = 7 if k >= 5000 else None
-    out = K.gemm(ta_, tb_, ta=bool(ta), tb=bool(tb), bias=torch.from_numpy(bias).to(dev), mode='bf16', split_k=sk)
+    # 'bf16': fp32 tensors, rounded inside the kernel; 'bf16s': bf16 STORAGE (packed operands, LDS-DMA kernel)
+    out = K.gemm(ta_, tb_, ta=bool(ta), tb=bool(tb), bias=torch.from_numpy(bias).to(dev), mode=mode, split_k=sk)
     # exact statement: the kernel multiplies the bf16-rounded operands exactly and sums in fp32
     ar = ta_.bfloat16().double().cpu().numpy()
     br = tb_.bfloat16().double().cpu().numpy()
@@ -50,7 +52,48 @@ def test_bf16_gemm_matches_fp64_of_the_rounded_operands(dev, m, n, k, ta, tb):
     assert np.abs(out.cpu().numpy() - full).max() <= 2.0 ** -8 * (3 * np.sqrt(k) + 1) + 1e-6
 
 
-def test_config5_training_step_in_bf16_mode(dev):
+def test_bf16_storage_gemm_on_prepacked_operands_and_sliced_weights(dev):
+    """renet_gemm_bf16s on operands packed ONCE and consumed in both roles (K-contiguous and K-strided), with beta
+    accumulation into a strided output view, and a leading column block of a packed weight (W_ih[:, :live])."""
+    import renet_hip as K
+    rng = np.random.RandomState(3)
+    m, n, k = 700, 1200, 1600
+    a = torch.from_numpy(rng.uniform(-1, 1, (m, k)).astype(np.float32)).to(dev)
+    w = torch.from_numpy(rng.uniform(-1, 1, (n, k)).astype(np.float32)).to(dev)       # nn.Linear layout [N, K]
+    pa, pw = K.pack_bf16(a), K.pack_bf16(w)
+    ar, wr = a.bfloat16().double(), w.bfloat16().double()
+    y = K.gemm(pa, pw, tb=True)                                                       # a @ w^T
+    torch.testing.assert_close(y.double(), ar @ wr.t(), rtol=1e-5, atol=2e-6 * k)
+    gy = torch.from_numpy(rng.uniform(-1, 1, (m, n)).astype(np.float32)).to(dev)
+    pg = K.pack_bf16(gy)
+    gr = gy.bfloat16().double()
+    da = K.gemm(pg, pw)                                                               # gy @ w (w K-strided)
+    torch.testing.assert_close(da.double(), gr @ wr, rtol=1e-5, atol=2e-6 * n)
+    dw0 = torch.from_numpy(rng.uniform(-1, 1, (n, k + 8)).astype(np.float32)).to(dev)
+    dw = dw0.clone()
+    K.gemm(pg, pa, ta=True, out=dw[:, 4:4 + k], beta=1.0)                             # gy^T @ a, both K-strided
+    torch.testing.assert_close(dw[:, 4:4 + k].double(), gr.t() @ ar + dw0[:, 4:4 + k].double(), rtol=1e-5, atol=2e-6 * m)
+    assert torch.equal(dw[:, :4], dw0[:, :4]) and torch.equal(dw[:, 4 + k:], dw0[:, 4 + k:])
+    # registered weight: cached copy, and a leading column block of it (contraction over 1200 of its 1600 columns
+    # would need a 64-aligned end: 1216 is; 1200 is not -> packed afresh, same result)
+    K.register_weights([w])
+    try:
+        for live in (1216, 1200, 640):
+            d = K.gemm(gy, w[:, :live], mode='bf16s')                                 # [m, live] = gy @ w[:, :live]
+            torch.testing.assert_close(d.double(), gr @ wr[:, :live], rtol=1e-5, atol=2e-6 * n)
+            x = torch.from_numpy(rng.uniform(-1, 1, (m, live)).astype(np.float32)).to(dev)
+            z = K.gemm(x, w[:, :live], tb=True, mode='bf16s')                         # contraction over the block
+            torch.testing.assert_close(z.double(), x.bfloat16().double() @ wr[:, :live].t(), rtol=1e-5, atol=2e-6 * live)
+        w.mul_(2.0)
+        K.weights_changed()
+        d = K.gemm(gy, w, mode='bf16s')
+        torch.testing.assert_close(d.double(), gr @ (2 * wr), rtol=1e-5, atol=4e-6 * n)
+    finally:
+        K.unregister_weights([w])
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16s'])
+def test_config5_training_step_in_bf16_mode(dev, mode):
     """ONE eval-mode training step at config 5's sizes (YAGO-shaped, n_hidden 400, seq_len 15, B 1024) with the
     GEMMs in bf16 mode, against the UNMODIFIED reference's fp32 outputs (tests/golden/config_yago_d400_l15.npz)."""
     import renet_hip as K
@@ -62,7 +105,7 @@ def test_config5_training_step_in_bf16_mode(dev):
     fh = {t: P.HistoryIndex(quads, t, history_len=L).take(idx) for t in ('s', 'o')}
     taps = []
     old = K.GEMM_MODE
-    K.GEMM_MODE = 'bf16'
+    K.GEMM_MODE = mode
     try:
         net, loss_s, loss_o = hip_step(case, dev, fh['s'], fh['o'], tap=lambda n, t: taps.append((n, t.detach().clone())))
     finally:
@@ -98,3 +141,47 @@ def test_config5_training_step_in_bf16_mode(dev):
             assert abs(float(np.linalg.norm(g.astype(np.float64))) - nr) <= 5e-2 * nr, k
     report['worst_grad'] = worst
     print('bf16 config-5 deviations from the fp32 reference:', {k: float('%.3g' % v) for k, v in report.items()})
+
+
+@pytest.mark.parametrize('i,h,nseq', [(1600, 400, 45), (800, 200, 31), (300, 100, 20)])
+def test_gru_in_bf16_mode_matches_torch_gru_within_the_bf16_bound(dev, i, h, nseq):
+    """bf16 mode of the recurrence (renet_gru_{fwd,bwd}_layouts_bf16: W_hh and the state rounded to bf16 as MFMA
+    operands, one product per pair; fp32 accumulation, gate math and state) + bf16-storage input projection against
+    torch.nn.GRU in fp32.  Bounds (ours; the reference has no bf16 path): h_n 2e-2 of its max, dX and every parameter
+    gradient 6e-2 of the tensor's max."""
+    import model as M
+    import renet_hip as K
+    torch.manual_seed(11)
+    lens = [10] * (nseq - 11) + [9, 9, 7, 5, 5, 5, 3, 2, 1, 1, 1]
+    b, l = len(lens), 10
+    ref = torch.nn.GRU(i, h, batch_first=True)
+    x = torch.randn(b, l, i) * 0.5
+    for k, n in enumerate(lens):
+        x[k, n:] = 0
+    x.requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x, lens, batch_first=True)
+    _, hn = ref(packed)
+    gout = torch.randn(b, h)
+    (hn[0] * gout).sum().backward()
+    mine = M.GRU(i, h).to(dev)
+    mine.load_state_dict(ref.state_dict())
+    xd = packed.data.detach().to(dev).requires_grad_(True)
+    pk = torch.nn.utils.rnn.PackedSequence(xd, packed.batch_sizes)
+    old = K.GEMM_MODE
+    K.GEMM_MODE = 'bf16s'
+    try:
+        _, hm = mine(pk, total_rows=b)
+        (hm[0, :b] * gout.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        K.GEMM_MODE = old
+
+    def close(a, r, frac, what):
+        a, r = a.detach().cpu().double().numpy(), r.detach().double().numpy()
+        err, scale = np.abs(a - r).max(), np.abs(r).max()
+        assert err <= frac * scale, (what, err, scale)
+    close(hm[0, :b], hn[0], 2e-2, 'h_n')
+    dx_ref = torch.nn.utils.rnn.pack_padded_sequence(x.grad, lens, batch_first=True).data
+    close(xd.grad, dx_ref, 6e-2, 'dX')
+    for name, p in mine.named_parameters():
+        close(p.grad, getattr(ref, name).grad, 6e-2, name)
