@@ -189,7 +189,7 @@ int renet_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const floa
  *     dfeat = dlogits W (b_tr = 1); dlogits [B, N_ent] is op(A) of dfeat (a_tr = 0) and of dW = dlogits^T feat
  *     (a_tr = 1).  split_k / workspace as renet_gemm_f32. */
 /* bf16 STORAGE (BASELINE config 5, "n_hidden=400 bf16"): operands live in HBM as bf16 matrices, [Rp][Cp] row-major
- * with Rp, Cp = R, C rounded up to multiples of 128 and zero padding (one "plane" of the format above).
+ * with Rp, Cp = R, C rounded up to multiples of 256 and zero padding.
  *   renet_pack_bf16  : fp32 X[R, C] (row stride ldx) -> bf16 (RNE), padding written; renet_bf16_bytes(R, C) bytes.
  *   renet_gemm_bf16s : the GEMM contract of renet_gemm_planes on such matrices: ONE bf16 product per element pair
  *                      (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 C; operands staged by LDS-DMA, consumed
@@ -201,6 +201,31 @@ int renet_pack_bf16(const float* X, int R, int C, int ldx, void* out, void* stre
 int renet_gemm_bf16s(int a_tr, int b_tr, int M, int N, int K, float alpha, const void* Ap, int lda, const void* Bp,
                      int ldb, float beta, float* C, int ldc, const float* bias, int split_k, float* workspace,
                      size_t workspace_bytes, void* stream);
+/* Producers that write the bf16 operand format directly (no fp32 copy of the tensor exists in bf16 mode).  A
+ * bf16-storage GEMM reads the contraction dimension in 64-wide stages, so the padding a consumer may touch --
+ * columns [C, ceil64(C)) of the valid rows and rows [rows, ceil64(rows)) -- must be zero: each producer below zeroes
+ * it, renet_bf16_zero_padding does so for a buffer filled by some other kernel.
+ *   renet_seq_assemble_fwd_bf16   : renet_seq_assemble_fwd with X [S, 4D] / Xr [S, 3D] as bf16, row strides ldx / ldxr
+ *   renet_softmax_ce_bf16         : renet_softmax_ce with the gradient (softmax - onehot) * grad_scale as bf16 (the
+ *                                   fp32 logits are left untouched)
+ *   renet_gru_bwd_layouts_bf16out : renet_gru_bwd_layouts_bf16 with dGi / dGh [S, 3H] as bf16, row stride out_ld
+ *   renet_colsum_bf16 / renet_scale_bf16_by_device_scalar : the bias-gradient column sums / upstream-gradient scaling
+ *                                   on such matrices */
+int renet_bf16_zero_padding(void* P, int rows, int C, int ld, int rows_alloc, void* stream);
+int renet_seq_assemble_fwd_bf16(const float* h2, const float* ent, const float* rel, const float* glob,
+                                const int32_t* subj_row, const int32_t* row_ent, const int32_t* row_rel,
+                                const int32_t* glob_row, int S, int D, float drop_p, uint64_t seed_x,
+                                uint64_t seed_xr, void* X, int ldx, void* Xr, int ldxr, int rows_alloc,
+                                void* stream);
+int renet_softmax_ce_bf16(const float* logits, const int32_t* target, int B, int C, int ld, float grad_scale,
+                          float* row_loss, void* dlogits_bf16, int ld16, int rows16, void* stream);
+int renet_gru_bwd_layouts_bf16out(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L,
+                                  int H, const float* const* Whh, const float* const* saved, void* const* dGi16,
+                                  void* const* dGh16, int out_ld, float* workspace, size_t workspace_bytes,
+                                  void* stream);
+int renet_colsum_bf16(const void* X, int M, int N, int ldx, float* out, float beta, float* workspace,
+                      size_t workspace_bytes, void* stream);
+int renet_scale_bf16_by_device_scalar(void* x, size_t n, const float* scale, void* stream);
 size_t renet_planes_bytes(int R, int C);
 int renet_pack_planes(const float* X, int R, int C, int ldx, void* planes, void* stream);
 int renet_gemm_planes(int a_tr, int b_tr, int M, int N, int K, float alpha, const void* Ap, int lda, const void* Bp,

@@ -280,7 +280,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // waves take rows g0+w, g0+w+4, ... (4 independent loads in flight each), then a fixed-order LDS
 // combine => deterministic.  Two launches (row groups, then the groups) keep every CU busy on the
 // tall-skinny bias-gradient shapes ([7.6k, 600], [1024, 23033]).
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, int ldx,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int M, int N, int ldx,
                                                      int rows_per_group, float beta, float* __restrict__ out) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -291,12 +292,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     if (n < N) {
         int m = m0 + wave;
         for (; m + 12 < m1; m += 16) {
-            s0 += X[(size_t)m * ldx + n];
-            s1 += X[(size_t)(m + 4) * ldx + n];
-            s2 += X[(size_t)(m + 8) * ldx + n];
-            s3 += X[(size_t)(m + 12) * ldx + n];
+            s0 += (float)X[(size_t)m * ldx + n];
+            s1 += (float)X[(size_t)(m + 4) * ldx + n];
+            s2 += (float)X[(size_t)(m + 8) * ldx + n];
+            s3 += (float)X[(size_t)(m + 12) * ldx + n];
         }
-        for (; m < m1; m += 4) s0 += X[(size_t)m * ldx + n];
+        for (; m < m1; m += 4) s0 += (float)X[(size_t)m * ldx + n];
     }
     red[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -322,7 +323,38 @@ __global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, s
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) x[(n4 << 2) + threadIdx.x] *= f;
 }
 
+// bf16 matrix (rows x ld elements, contiguous) *= *scale; exactly 1 => nothing to do
+__global__ __launch_bounds__(256) void scale_dev_bf16_kernel(__bf16* __restrict__ x, size_t n,
+                                                             const float* __restrict__ scale) {
+    const float f = *scale;
+    if (f == 1.f) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        x[i] = (__bf16)((float)x[i] * f);
+}
+
 inline int colsum_groups(int M) { return max(1, min(64, (M + 127) / 128)); }
+
+template <typename T>
+int colsum_impl(const T* X, int M, int N, int ldx, float* out, float beta, float* workspace,
+                       size_t workspace_bytes, void* stream) {
+    if (M < 0 || N <= 0 || ldx < N) return RENET_ERR_BADARG;
+    const int G = colsum_groups(M);
+    hipStream_t st = (hipStream_t)stream;
+    if (G == 1) {
+        RENET_LAUNCH((colsum_kernel<T>), dim3((N + 63) / 64, 1), dim3(256), 0, st, X, M, N, ldx, max(M, 1), beta, out);
+        RENET_LAUNCH_CHECK();
+        return RENET_OK;
+    }
+    if (workspace_bytes < (size_t)colsum_groups(M) * N * sizeof(float)) return RENET_ERR_WORKSPACE;
+    const int rpg = (M + G - 1) / G;
+    RENET_LAUNCH((colsum_kernel<T>), dim3((N + 63) / 64, G), dim3(256), 0, st, X, M, N, ldx, rpg, 0.f, workspace);
+    RENET_LAUNCH_CHECK();
+    RENET_LAUNCH((colsum_kernel<float>), dim3((N + 63) / 64, 1), dim3(256), 0, st, (const float*)workspace, G, N, N, G,
+                 beta, out);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
 
 }  // namespace
 
@@ -381,19 +413,18 @@ int renet_scale_by_device_scalar(float* x, size_t n, const float* scale, void* s
 
 int renet_colsum(const float* X, int M, int N, int ldx, float* out, float beta, float* workspace,
                  size_t workspace_bytes, void* stream) {
-    if (M < 0 || N <= 0 || ldx < N) return RENET_ERR_BADARG;
-    const int G = colsum_groups(M);
-    hipStream_t st = (hipStream_t)stream;
-    if (G == 1) {
-        RENET_LAUNCH(colsum_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, st, X, M, N, ldx, max(M, 1), beta, out);
-        RENET_LAUNCH_CHECK();
-        return RENET_OK;
-    }
-    if (workspace_bytes < renet_colsum_workspace(M, N)) return RENET_ERR_WORKSPACE;
-    const int rpg = (M + G - 1) / G;
-    RENET_LAUNCH(colsum_kernel, dim3((N + 63) / 64, G), dim3(256), 0, st, X, M, N, ldx, rpg, 0.f, workspace);
-    RENET_LAUNCH_CHECK();
-    RENET_LAUNCH(colsum_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, st, workspace, G, N, N, G, beta, out);
+    return colsum_impl<float>(X, M, N, ldx, out, beta, workspace, workspace_bytes, stream);
+}
+
+int renet_colsum_bf16(const void* X, int M, int N, int ldx, float* out, float beta, float* workspace,
+                      size_t workspace_bytes, void* stream) {
+    return colsum_impl<__bf16>((const __bf16*)X, M, N, ldx, out, beta, workspace, workspace_bytes, stream);
+}
+
+int renet_scale_bf16_by_device_scalar(void* x, size_t n, const float* scale, void* stream) {
+    if (n == 0) return RENET_OK;
+    const int blocks = (int)min((size_t)2048, (n + 255) / 256);
+    RENET_LAUNCH(scale_dev_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (__bf16*)x, n, scale);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }

@@ -1064,11 +1064,21 @@ constexpr int B1_SUB = 2;                                 // k sub-tiles per ope
 constexpr int B1_BK = 32 * B1_SUB;                        // k per stage
 constexpr int B1_STAGE = 2 * B1_SUB * 8192;
 constexpr int B1_SLOTS = 3;
-constexpr int B1_PER = (2 * B1_SUB * 8) / P3_LOADERS;     // DMA pieces per loader wave and stage (8)
 constexpr size_t B1_LDS = (size_t)B1_STAGE * B1_SLOTS;
+constexpr size_t B1_LDS_TALL = (size_t)B1_SUB * (256 * 64 + 8192) * B1_SLOTS;
 
-template <bool A_TR, bool B_TR>
-__global__ __launch_bounds__(P3_THREADS) void gemm_bf16s_kernel(Bf16sArgs pa) {
+// TALL: 256 x 128 tile, 8 MFMA waves (4 x 2, two per SIMD: one wave's barrier wait is covered by its partner's
+// MFMAs) + 4 loader waves; A images are 16 KB (256 rows K-contiguous / 256 columns K-strided).  0.75x the operand
+// bytes per flop of the 128 x 128 tile.
+template <bool A_TR, bool B_TR, bool TALL>
+__global__ __launch_bounds__(TALL ? 768 : P3_THREADS) void gemm_bf16s_kernel(Bf16sArgs pa) {
+    constexpr int TBM = TALL ? 256 : 128;
+    constexpr int MW = TALL ? 8 : 4;                       // MFMA waves
+    constexpr int AIMG = TBM * 64;                         // bytes of one A sub-tile image
+    constexpr int APIECES = TBM / 16;                      // 1 KB DMA pieces per A image
+    constexpr int STAGE = B1_SUB * (AIMG + 8192);
+    constexpr int NPIECE = B1_SUB * (APIECES + 8);
+    constexpr int PER = NPIECE / P3_LOADERS;               // 8 (128-row tile) or 12 (256-row tile)
     extern __shared__ __attribute__((aligned(16))) char ring1[];
     const SplitArgs& g = pa.out;
     const int tid = threadIdx.x;
@@ -1076,56 +1086,70 @@ __global__ __launch_bounds__(P3_THREADS) void gemm_bf16s_kernel(Bf16sArgs pa) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;
     tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
-    const int m0 = by * BM, n0 = bx * BN;
+    const int m0 = by * TBM, n0 = bx * BN;
     const int z = blockIdx.z;
     const int st_total = (g.K + B1_BK - 1) / B1_BK;
     const int s0 = z * g.k_tiles_per_split;
     const int s1 = min(st_total, s0 + g.k_tiles_per_split);
     const int nk = max(s1 - s0, 0);
 
-    if (wave >= 4) {
+    if (wave >= MW) {
         if (nk == 0) return;
-        const int lw = wave - 4;
-        const __bf16* src[B1_PER];
-        int dst[B1_PER];
+        const int lw = wave - MW;
+        const __bf16* src[PER];
+        int dst[PER];
+        bool is_b[PER];
 #pragma unroll
-        for (int i = 0; i < B1_PER; ++i) {
+        for (int i = 0; i < PER; ++i) {
             const int id = lw + P3_LOADERS * i;
-            const int opnd = id / (8 * B1_SUB), sub = (id / 8) % B1_SUB, piece = id % 8;
+            // pieces 0 .. B1_SUB * APIECES - 1: A (sub-tile major), then B
+            const int opnd = id >= B1_SUB * APIECES ? 1 : 0;
+            const int idl = opnd ? id - B1_SUB * APIECES : id;
+            const int per_sub = opnd ? 8 : APIECES;
+            const int sub = idl / per_sub, piece = idl % per_sub;
+            is_b[i] = opnd != 0;
             const bool tr = opnd ? B_TR : A_TR;
             const __bf16* base = opnd ? pa.B : pa.A;
             const int ld = opnd ? pa.ldb : pa.lda;
             const int r0 = opnd ? n0 : m0;
             const size_t k0 = (size_t)s0 * B1_BK + sub * 32;
             size_t off;
-            if (!tr) {
+            int img_off;
+            if (!tr) {                                   // [rows][32 k]: piece = 16 rows x 64 B
                 const int row = 16 * piece + (lane >> 2);
                 const int chunk = (lane & 3) ^ ((row >> 2) & 3);
                 off = (size_t)(r0 + row) * ld + k0 + chunk * 8;
-            } else {
-                const int kk = 4 * piece + (lane >> 4);
+                img_off = piece * 1024;
+            } else {                                     // [32 k][cols]: 128-column panels of 8 KB, piece = 4 k x 256 B
+                const int panel = piece >> 3, pc = piece & 7;
+                const int kk = 4 * pc + (lane >> 4);
                 const int log16 = (lane & 15) ^ (4 * (kk & 3));
-                off = (k0 + kk) * ld + r0 + log16 * 8;
+                off = (k0 + kk) * ld + r0 + panel * 128 + log16 * 8;
+                img_off = panel * 8192 + pc * 1024;
             }
             src[i] = base + off;
-            dst[i] = (opnd * B1_SUB + sub) * 8192 + piece * 1024;
+            dst[i] = (opnd ? B1_SUB * AIMG + sub * 8192 : sub * AIMG) + img_off;
         }
         const size_t a_step = A_TR ? (size_t)B1_BK * pa.lda : (size_t)B1_BK;
         const size_t b_step = B_TR ? (size_t)B1_BK * pa.ldb : (size_t)B1_BK;
         auto issue_all = [&](int slot) {
-            char* base = ring1 + slot * B1_STAGE;
+            char* base = ring1 + slot * STAGE;
 #pragma unroll
-            for (int i = 0; i < B1_PER; ++i) {
+            for (int i = 0; i < PER; ++i) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
                                                  (__attribute__((address_space(3))) void*)(base + dst[i]), 16, 0, 0);
-                src[i] += ((lw + P3_LOADERS * i) / (8 * B1_SUB)) ? b_step : a_step;
+                src[i] += is_b[i] ? b_step : a_step;
             }
         };
-        static_assert(B1_PER == 8, "the counted waits below assume 8 pieces per loader wave");
+        static_assert(PER == 8 || PER == 12, "counted waits below");
+        auto wait_one_stage = [&]() {
+            if constexpr (PER == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        };
         issue_all(0);
         if (nk > 1) {
             issue_all(1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            wait_one_stage();
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1133,7 +1157,7 @@ __global__ __launch_bounds__(P3_THREADS) void gemm_bf16s_kernel(Bf16sArgs pa) {
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 2 < nk) {
                 issue_all((kt + 2) % B1_SLOTS);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                wait_one_stage();
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1143,7 +1167,7 @@ __global__ __launch_bounds__(P3_THREADS) void gemm_bf16s_kernel(Bf16sArgs pa) {
     }
 
     // ---------------- MFMA waves ----------------
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;               // wm: 0..1 (128-row tile) or 0..3 (256-row tile)
     int offA[2][2], offB[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -1154,9 +1178,10 @@ __global__ __launch_bounds__(P3_THREADS) void gemm_bf16s_kernel(Bf16sArgs pa) {
                 offA[t][u] = row * 64 + (((2 * u + (lane >> 5)) ^ ((row >> 2) & 3)) * 16);
             } else {
                 const int sl = lane & 15;
-                const int col = wm * 64 + 32 * t + 16 * ((lane >> 4) & 1) + 4 * (sl & 3);
+                const int colf = wm * 64 + 32 * t + 16 * ((lane >> 4) & 1) + 4 * (sl & 3);
+                const int col = colf & 127;                  // inside its 128-column panel
                 const int kk = 8 * (lane >> 5) + 4 * u + (sl >> 2);
-                offA[t][u] = kk * 256 + (((col >> 3) ^ (4 * (kk & 3))) * 16) + ((col >> 2) & 1) * 8;
+                offA[t][u] = (colf >> 7) * 8192 + kk * 256 + (((col >> 3) ^ (4 * (kk & 3))) * 16) + ((col >> 2) & 1) * 8;
             }
             if constexpr (!B_TR) {
                 const int row = wn * 64 + 32 * t + (lane & 31);
@@ -1189,7 +1214,7 @@ __global__ __launch_bounds__(P3_THREADS) void gemm_bf16s_kernel(Bf16sArgs pa) {
 
     if (nk > 0) __builtin_amdgcn_s_barrier();                             // barrier -1
     for (int kt = 0; kt < nk; ++kt) {
-        const char* st = ring1 + (kt % B1_SLOTS) * B1_STAGE;
+        const char* st = ring1 + (kt % B1_SLOTS) * STAGE;
         bf16x8 fa[B1_SUB][2][2], fb[B1_SUB][2][2];                        // [sub][slab][t]: all 16 reads issued up front
 #pragma unroll
         for (int sb = 0; sb < B1_SUB; ++sb)
@@ -1197,8 +1222,8 @@ __global__ __launch_bounds__(P3_THREADS) void gemm_bf16s_kernel(Bf16sArgs pa) {
             for (int slab = 0; slab < 2; ++slab)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const char* ia = st + sb * 8192;
-                    const char* ib = st + (B1_SUB + sb) * 8192;
+                    const char* ia = st + sb * AIMG;
+                    const char* ib = st + B1_SUB * AIMG + sb * 8192;
                     if constexpr (!A_TR) fa[sb][slab][t] = *reinterpret_cast<const bf16x8*>(ia + offA[t][slab]);
                     else fa[sb][slab][t] = frag_tr(ia, offA[t], slab);
                     if constexpr (!B_TR) fb[sb][slab][t] = *reinterpret_cast<const bf16x8*>(ib + offB[t][slab]);
@@ -1409,16 +1434,17 @@ int launch_planes(const PlanesArgs& pa, dim3 grid, hipStream_t st) {
     return RENET_OK;
 }
 
-template <bool A_TR, bool B_TR>
+template <bool A_TR, bool B_TR, bool TALL>
 int launch_bf16s(const Bf16sArgs& pa, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = TALL ? B1_LDS_TALL : B1_LDS;
     static bool attr_set = false;      // benign race: the attribute is idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16s_kernel<A_TR, B_TR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)B1_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16s_kernel<A_TR, B_TR, TALL>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    RENET_LAUNCH((gemm_bf16s_kernel<A_TR, B_TR>), grid, dim3(P3_THREADS), B1_LDS, st, pa);
+    RENET_LAUNCH((gemm_bf16s_kernel<A_TR, B_TR, TALL>), grid, dim3(TALL ? 768 : P3_THREADS), lds, st, pa);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -1528,13 +1554,13 @@ int renet_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const floa
 }
 
 size_t renet_bf16_bytes(int R, int C) {
-    const size_t rp = ((size_t)R + 127) & ~(size_t)127, cp = ((size_t)C + 127) & ~(size_t)127;
+    const size_t rp = ((size_t)R + 255) & ~(size_t)255, cp = ((size_t)C + 255) & ~(size_t)255;
     return rp * cp * sizeof(__bf16);
 }
 
 int renet_pack_bf16(const float* X, int R, int C, int ldx, void* out, void* stream) {
     if (R < 0 || C < 0 || ldx < C || !out) return RENET_ERR_BADARG;
-    const int Rp = (R + 127) & ~127, Cp = (C + 127) & ~127;
+    const int Rp = (R + 255) & ~255, Cp = (C + 255) & ~255;
     if (Rp == 0 || Cp == 0) return RENET_OK;
     const size_t total = (size_t)Rp * Cp / 4;
     const int blocks = (int)min((size_t)4096, (total + 255) / 256);
@@ -1543,12 +1569,29 @@ int renet_pack_bf16(const float* X, int R, int C, int ldx, void* out, void* stre
     return RENET_OK;
 }
 
+int renet_bf16_zero_padding(void* P, int rows, int C, int ld, int rows_alloc, void* stream) {
+    if (!P || rows < 0 || C < 0 || ld < C || rows_alloc < rows) return RENET_ERR_BADARG;
+    __bf16* p = (__bf16*)P;
+    hipStream_t st = (hipStream_t)stream;
+    const int c16 = min((C + 63) & ~63, ld), r16 = min((rows + 63) & ~63, rows_alloc);
+    if (c16 > C && rows > 0) {
+        hipError_t e = hipMemset2DAsync(p + C, (size_t)ld * sizeof(__bf16), 0, (size_t)(c16 - C) * sizeof(__bf16),
+                                        (size_t)rows, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (r16 > rows) {
+        hipError_t e = hipMemsetAsync(p + (size_t)rows * ld, 0, (size_t)(r16 - rows) * ld * sizeof(__bf16), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    return RENET_OK;
+}
+
 int renet_gemm_bf16s(int a_tr, int b_tr, int M, int N, int K, float alpha, const void* Ap, int lda, const void* Bp,
                      int ldb, float beta, float* C, int ldc, const float* bias, int split_k, float* workspace,
                      size_t workspace_bytes, void* stream) {
     if (M < 0 || N < 0 || K < 1 || ldc < N || !Ap || !Bp) return RENET_ERR_BADARG;
     if (M == 0 || N == 0) return RENET_OK;
-    const int Mp = (M + 127) & ~127, Np = (N + 127) & ~127, Kp = (K + 127) & ~127;
+    const int Mp = (M + 255) & ~255, Np = (N + 255) & ~255, Kp = (K + 255) & ~255;
     if (lda < (a_tr ? Mp : Kp) || ldb < (b_tr ? Np : Kp) || (lda & 7) || (ldb & 7)) return RENET_ERR_BADARG;
     if (split_k < 1) split_k = 1;
     const int st_total = (K + B1_BK - 1) / B1_BK;
@@ -1565,12 +1608,29 @@ int renet_gemm_bf16s(int a_tr, int b_tr, int M, int N, int K, float alpha, const
     g.partial = workspace;
     g.xcd_order = tile_order();
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, split_k);
+    // 256 x 128 tiles when they still fill the chip (>= 256 workgroups); the matrices are padded to multiples of
+    // 256 in both dimensions, so a 256-row (or, K-strided, 256-column) A image never leaves the buffer --
+    // RENET_BF16S_TALL=0 keeps the 128 x 128 tile
+    const int nbx = (N + BN - 1) / BN;
+    static int tall_ok = -1;
+    if (tall_ok < 0) {
+        const char* e_ = getenv("RENET_BF16S_TALL");
+        tall_ok = (e_ && e_[0] == '0') ? 0 : 1;
+    }
+    const bool tall = tall_ok && (size_t)nbx * (Mp / 256) * split_k >= 256;
+    dim3 grid(nbx, tall ? Mp / 256 : (M + BM - 1) / BM, split_k);
     int e;
-    if (!a_tr && !b_tr) e = launch_bf16s<false, false>(pa, grid, st);
-    else if (!a_tr && b_tr) e = launch_bf16s<false, true>(pa, grid, st);
-    else if (a_tr && !b_tr) e = launch_bf16s<true, false>(pa, grid, st);
-    else e = launch_bf16s<true, true>(pa, grid, st);
+    if (tall) {
+        if (!a_tr && !b_tr) e = launch_bf16s<false, false, true>(pa, grid, st);
+        else if (!a_tr && b_tr) e = launch_bf16s<false, true, true>(pa, grid, st);
+        else if (a_tr && !b_tr) e = launch_bf16s<true, false, true>(pa, grid, st);
+        else e = launch_bf16s<true, true, true>(pa, grid, st);
+    } else {
+        if (!a_tr && !b_tr) e = launch_bf16s<false, false, false>(pa, grid, st);
+        else if (!a_tr && b_tr) e = launch_bf16s<false, true, false>(pa, grid, st);
+        else if (a_tr && !b_tr) e = launch_bf16s<true, false, false>(pa, grid, st);
+        else e = launch_bf16s<true, true, false>(pa, grid, st);
+    }
     if (e != RENET_OK) return e;
     if (split_k > 1) {
         const size_t total = (size_t)M * N;

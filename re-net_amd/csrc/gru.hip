@@ -363,7 +363,7 @@ __device__ __forceinline__ f32x4 mfma_p(const bf16x8 (&a)[NPL], const bf16x8 (&b
 
 struct FwdProbB { const float* Gi; const bf16x8* Wp; const float* bhh; float* h_last; float* saved; };
 struct FwdProbsB { FwdProbB p[MAXP]; };
-struct BwdProbB { const float* dh_last; const bf16x8* WTp; const float* saved; float* dGi; float* dGh; };
+struct BwdProbB { const float* dh_last; const bf16x8* WTp; const float* saved; float* dGi; float* dGh; int out_ld; };
 struct BwdProbsB { BwdProbB p[MAXP]; };
 
 // Wp: bf16 planes of W_hh in fragment order (split_frag_kernel with G = 3 gates)
@@ -511,7 +511,9 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
 }
 
 // WTp: bf16 planes of W_hh^T (unit = hidden unit, k over the 3H gate columns) in fragment order (G = 1)
-template <int H, int NPL>
+// OUT16: dGi / dGh are written as bf16 (RNE) into matrices with row stride out_ld (elements): the operand format of
+// the bf16-storage GEMMs that consume them (dW_ih, dX, dW_hh); the recurrence itself keeps its fp32 values in LDS.
+template <int H, int NPL, bool OUT16 = false>
 __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly) {
     const int lay = ly.lay_of[blockIdx.y];
     const StepOff& so = ly.so[lay];
@@ -576,11 +578,18 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
                     const float dan = g * (1.f - z) * (1.f - n * n);
                     const float daz = g * (hp - n) * z * (1.f - z);
                     const float dar = dan * hn * r * (1.f - r);
-                    float* gi = dGi + p * C::K3;
-                    float* gh = dGh + p * C::K3;
-                    gi[u] = dar; gi[H + u] = daz; gi[2 * H + u] = dan;
                     gr = dar; gz = daz; gn = dan * r;
-                    gh[u] = gr; gh[H + u] = gz; gh[2 * H + u] = gn;
+                    if constexpr (OUT16) {
+                        __bf16* gi = reinterpret_cast<__bf16*>(dGi) + p * ps.p[blockIdx.y].out_ld;
+                        __bf16* gh = reinterpret_cast<__bf16*>(dGh) + p * ps.p[blockIdx.y].out_ld;
+                        gi[u] = (__bf16)dar; gi[H + u] = (__bf16)daz; gi[2 * H + u] = (__bf16)dan;
+                        gh[u] = (__bf16)gr; gh[H + u] = (__bf16)gz; gh[2 * H + u] = (__bf16)gn;
+                    } else {
+                        float* gi = dGi + p * C::K3;
+                        float* gh = dGh + p * C::K3;
+                        gi[u] = dar; gi[H + u] = daz; gi[2 * H + u] = dan;
+                        gh[u] = gr; gh[H + u] = gz; gh[2 * H + u] = gn;
+                    }
                     dHs[i * C::LDH + u] = g * z;                        // direct path h_prev -> h
                 }
                 if (j > 0) {
@@ -1025,14 +1034,14 @@ int launch_bwd(const BwdProbs& ps, int np, const Layouts& ly, hipStream_t st) {
     return RENET_OK;
 }
 
-template <int H, int NPL = 3>
+template <int H, int NPL = 3, bool OUT16 = false>
 int launch_bwd_bf(const BwdProbsB& ps, int np, const Layouts& ly, hipStream_t st) {
     using C = Cfg<H>;
     const size_t lds = (size_t)MT * C::LDH * sizeof(float) + (size_t)3 * MT * BCfg<H>::LDP3 * sizeof(__bf16);
     static bool attr_set = false;
-    const int e = set_lds(gru_bwd_bf_kernel<H, NPL>, lds, attr_set);
+    const int e = set_lds(gru_bwd_bf_kernel<H, NPL, OUT16>, lds, attr_set);
     if (e != RENET_OK) return e;
-    RENET_LAUNCH((gru_bwd_bf_kernel<H, NPL>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(NT), lds, st, ps, ly);
+    RENET_LAUNCH((gru_bwd_bf_kernel<H, NPL, OUT16>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(NT), lds, st, ps, ly);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -1357,7 +1366,7 @@ static int gru_fwd_impl(int npl, int n, const float* const* Gi, const int32_t* c
 
 static int gru_bwd_impl(int npl, int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
                         const float* const* Whh, const float* const* saved, float* const* dGi,
-                        float* const* dGh, float* workspace, size_t workspace_bytes, void* stream);
+                        float* const* dGh, float* workspace, size_t workspace_bytes, void* stream, int out_ld = 0);
 
 int renet_gru_bwd_layouts(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
                           const float* const* Whh, const float* const* saved, float* const* dGi,
@@ -1371,9 +1380,18 @@ int renet_gru_bwd_layouts_bf16(int n, const float* const* dh_last, const int32_t
     return gru_bwd_impl(1, n, dh_last, step_off, L, H, Whh, saved, dGi, dGh, workspace, workspace_bytes, stream);
 }
 
+int renet_gru_bwd_layouts_bf16out(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L,
+                                  int H, const float* const* Whh, const float* const* saved, void* const* dGi16,
+                                  void* const* dGh16, int out_ld, float* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    if (out_ld < 3 * H) return RENET_ERR_BADARG;
+    return gru_bwd_impl(1, n, dh_last, step_off, L, H, Whh, saved, reinterpret_cast<float* const*>(dGi16),
+                        reinterpret_cast<float* const*>(dGh16), workspace, workspace_bytes, stream, out_ld);
+}
+
 static int gru_bwd_impl(int npl, int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
                         const float* const* Whh, const float* const* saved, float* const* dGi,
-                        float* const* dGh, float* workspace, size_t workspace_bytes, void* stream) {
+                        float* const* dGh, float* workspace, size_t workspace_bytes, void* stream, int out_ld) {
     if (n < 1 || n > MAXP) return RENET_ERR_BADARG;
     Layouts ly;
     int B_of[MAXP];
@@ -1411,7 +1429,7 @@ static int gru_bwd_impl(int npl, int n, const float* const* dh_last, const int32
         ps.p[i].dh_last = dh_last[k]; ps.p[i].WhhT = WhhT; ps.p[i].saved = saved[k]; ps.p[i].dGi = dGi[k];
         ps.p[i].dGh = dGh[k];
         pb.p[i].dh_last = dh_last[k]; pb.p[i].WTp = planes; pb.p[i].saved = saved[k]; pb.p[i].dGi = dGi[k];
-        pb.p[i].dGh = dGh[k];
+        pb.p[i].dGh = dGh[k]; pb.p[i].out_ld = out_ld;
         if (steps && i < n) {
             const size_t kp = kp_of(3 * H);
             stt[i] = carve_state(reinterpret_cast<char*>(workspace) + (size_t)i * per, H, Bmax, kp);
@@ -1442,6 +1460,13 @@ static int gru_bwd_impl(int npl, int n, const float* const* dh_last, const int32
             case 100: return launch_bwd<100>(ps, n, ly, st);
             case 200: return launch_bwd<200>(ps, n, ly, st);
             default: return launch_bwd<400>(ps, n, ly, st);
+        }
+    }
+    if (npl == 1 && out_ld > 0) {
+        switch (H) {
+            case 100: return launch_bwd_bf<100, 1, true>(pb, n, ly, st);
+            case 200: return launch_bwd_bf<200, 1, true>(pb, n, ly, st);
+            default: return launch_bwd_bf<400, 1, true>(pb, n, ly, st);
         }
     }
     if (npl == 1) {

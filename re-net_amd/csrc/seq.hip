@@ -31,6 +31,46 @@ __global__ __launch_bounds__(256) void seq_assemble_fwd_kernel(
     }
 }
 
+// The same rows written as bf16 (RNE) straight into the zero-padded matrices the bf16-storage GEMMs consume (row
+// strides ldx / ldxr in elements): no fp32 X / Xr exists in bf16 mode.  A thread converts one float4 -> 8 bytes.
+typedef float sq_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sq_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 sq_pack4(float4 v) {
+    const sq_bf16x2 lo = __builtin_convertvector(sq_f32x2{v.x, v.y}, sq_bf16x2);
+    const sq_bf16x2 hi = __builtin_convertvector(sq_f32x2{v.z, v.w}, sq_bf16x2);
+    uint2 u;
+    u.x = __builtin_bit_cast(unsigned, lo);
+    u.y = __builtin_bit_cast(unsigned, hi);
+    return u;
+}
+__global__ __launch_bounds__(256) void seq_assemble_fwd_bf16_kernel(
+    const float4* __restrict__ h2, const float4* __restrict__ ent, const float4* __restrict__ rel,
+    const float4* __restrict__ glob, const int32_t* __restrict__ subj_row,
+    const int32_t* __restrict__ row_ent, const int32_t* __restrict__ row_rel,
+    const int32_t* __restrict__ glob_row, int S, int CH, DropCfg dx, DropCfg dxr,
+    __bf16* __restrict__ X, int ldx, __bf16* __restrict__ Xr, int ldxr) {
+    const size_t total = (size_t)S * 4 * CH;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i / (4 * CH));
+        const int c = (int)(i - (size_t)p * 4 * CH);
+        const int part = c / CH, cc = c - part * CH;
+        float4 v;
+        if (part == 0) v = h2[(size_t)subj_row[p] * CH + cc];
+        else if (part == 1) v = ent[(size_t)row_ent[p] * CH + cc];
+        else if (part == 2) v = rel[(size_t)row_rel[p] * CH + cc];
+        else v = glob[(size_t)glob_row[p] * CH + cc];
+        // the dropout mask is keyed by the float4-group index of the UNPADDED [S, 4D] / [S, 3D] layouts, exactly as in
+        // the fp32 kernel (the backward kernels regenerate it from the same index)
+        *reinterpret_cast<uint2*>(X + (size_t)p * ldx + c * 4) = sq_pack4(f4_mul(v, renet_drop4(dx, i)));
+        if (part != 2) {
+            const int cr = (part == 3 ? 2 : part) * CH + cc;
+            const size_t ir = (size_t)p * 3 * CH + cr;
+            *reinterpret_cast<uint2*>(Xr + (size_t)p * ldxr + cr * 4) = sq_pack4(f4_mul(v, renet_drop4(dxr, ir)));
+        }
+    }
+}
+
 // backward, part 1: gradient wrt the gathered h2 row of every packed row (X and Xr segments)
 __global__ __launch_bounds__(256) void seq_assemble_bwd_rows_kernel(const float4* __restrict__ dX,
                                                                     const float4* __restrict__ dXr, int S,
@@ -128,10 +168,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 // `dlogits` may ALIAS `logits` (the training path turns the logits into their gradient in place): neither pointer
 // may be __restrict__ -- with it hipcc is free to sink thread 0's read of x[target] below the barrier, past other
 // waves' stores to the same row (seen as a rare wrong LOSS with correct gradients).
+// dl16 (optional, instead of dlogits): the gradient as bf16 (RNE) into a matrix with row stride ld16 (elements), the
+// columns [C, C16) of every row written as zeros (C16 = C rounded up to 64: the k padding a bf16-storage GEMM reads).
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* logits,
                                                          const int32_t* __restrict__ target, int C, int ld,
                                                          float grad_scale, float* __restrict__ row_loss,
-                                                         float* dlogits) {
+                                                         float* dlogits, __bf16* __restrict__ dl16, int ld16) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -165,6 +207,13 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* logits,
             dx[c] = (p - (c == t ? 1.f : 0.f)) * grad_scale;
         }
     }
+    if (dl16) {
+        __bf16* dx = dl16 + (size_t)b * ld16;
+        const float inv = 1.f / s;
+        const int C16 = min((C + 63) & ~63, ld16);
+        for (int c = threadIdx.x; c < C16; c += 256)
+            dx[c] = c < C ? (__bf16)((expf(x[c] - m) * inv - (c == t ? 1.f : 0.f)) * grad_scale) : (__bf16)0.f;
+    }
 }
 
 // Same, with the row staged in LDS (C * 4 <= 128 KB: 23 033 entities = 92 KB): the three passes of the kernel above
@@ -174,7 +223,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* logits,
 __global__ __launch_bounds__(1024) void softmax_ce_lds_kernel(const float* logits,
                                                               const int32_t* __restrict__ target, int C, int ld,
                                                               float grad_scale, float* __restrict__ row_loss,
-                                                              float* dlogits) {
+                                                              float* dlogits, __bf16* __restrict__ dl16, int ld16) {
     extern __shared__ float row[];
     __shared__ float red[16];
     const int b = blockIdx.x;
@@ -226,6 +275,19 @@ __global__ __launch_bounds__(1024) void softmax_ce_lds_kernel(const float* logit
         float* dx = dlogits + (size_t)b * ld;
         const float inv = 1.f / s;
         for (int c = threadIdx.x; c < C; c += 1024) dx[c] = (row[c] * inv - (c == t ? 1.f : 0.f)) * grad_scale;
+    }
+    if (dl16) {                                      // two columns per thread: 4-byte stores
+        unsigned* dx = reinterpret_cast<unsigned*>(dl16 + (size_t)b * ld16);
+        const float inv = 1.f / s;
+        const int C16 = min((C + 63) & ~63, ld16);
+        for (int c = 2 * threadIdx.x; c < C16; c += 2048) {
+            const float v0 = c < C ? (row[c] * inv - (c == t ? 1.f : 0.f)) * grad_scale : 0.f;
+            const float v1 = c + 1 < C ? (row[c + 1] * inv - (c + 1 == t ? 1.f : 0.f)) * grad_scale : 0.f;
+            typedef float f32x2_ __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+            const bf16x2_ pk = __builtin_convertvector(f32x2_{v0, v1}, bf16x2_);
+            dx[c >> 1] = __builtin_bit_cast(unsigned, pk);
+        }
     }
 }
 
@@ -312,6 +374,44 @@ int renet_seq_assemble_fwd(const float* h2, const float* ent, const float* rel, 
     return RENET_OK;
 }
 
+// zero the padding a bf16-storage GEMM may read: columns [C, ceil64(C)) of the first `rows` rows and rows
+// [rows, ceil64(rows)) entirely
+static int zero_bf16_padding(__bf16* P, int rows, int C, int ld, int rows_alloc, hipStream_t st) {
+    const int c16 = min((C + 63) & ~63, ld), r16 = min((rows + 63) & ~63, rows_alloc);
+    if (c16 > C && rows > 0) {
+        hipError_t e = hipMemset2DAsync(P + C, (size_t)ld * sizeof(__bf16), 0, (size_t)(c16 - C) * sizeof(__bf16),
+                                        (size_t)rows, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (r16 > rows) {
+        hipError_t e = hipMemsetAsync(P + (size_t)rows * ld, 0, (size_t)(r16 - rows) * ld * sizeof(__bf16), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    return RENET_OK;
+}
+
+int renet_seq_assemble_fwd_bf16(const float* h2, const float* ent, const float* rel, const float* glob,
+                                const int32_t* subj_row, const int32_t* row_ent, const int32_t* row_rel,
+                                const int32_t* glob_row, int S, int D, float drop_p, uint64_t seed_x,
+                                uint64_t seed_xr, void* X, int ldx, void* Xr, int ldxr, int rows_alloc,
+                                void* stream) {
+    if (S < 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f || ldx < 4 * D || ldxr < 3 * D || (ldx & 3) ||
+        (ldxr & 3) || rows_alloc < S) return RENET_ERR_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    int e = zero_bf16_padding((__bf16*)X, S, 4 * D, ldx, rows_alloc, st);
+    if (e != RENET_OK) return e;
+    e = zero_bf16_padding((__bf16*)Xr, S, 3 * D, ldxr, rows_alloc, st);
+    if (e != RENET_OK) return e;
+    if (S == 0) return RENET_OK;
+    const int CH = D / 4;
+    RENET_LAUNCH(seq_assemble_fwd_bf16_kernel, dim3(grid_for((size_t)S * 4 * CH)), dim3(256), 0, st,
+                       (const float4*)h2, (const float4*)ent, (const float4*)rel, (const float4*)glob, subj_row,
+                       row_ent, row_rel, glob_row, S, CH, make_drop(drop_p, seed_x), make_drop(drop_p, seed_xr),
+                       (__bf16*)X, ldx, (__bf16*)Xr, ldxr);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
 int renet_seq_assemble_bwd(const float* dX, const float* dXr, const int32_t* step_off, int L, int S,
                            int B, int D, float drop_p, uint64_t seed_x, uint64_t seed_xr, float* dRows,
                            float* dEntSeq, float* dRelSeq, void* stream) {
@@ -368,8 +468,28 @@ int renet_dropout(const float* x, size_t n, float drop_p, uint64_t seed, float* 
     return RENET_OK;
 }
 
+static int softmax_ce_impl(const float* logits, const int32_t* target, int B, int C, int ld, float grad_scale,
+                           float* row_loss, float* dlogits, __bf16* dl16, int ld16, void* stream);
+
 int renet_softmax_ce(const float* logits, const int32_t* target, int B, int C, int ld,
                      float grad_scale, float* row_loss, float* dlogits, void* stream) {
+    return softmax_ce_impl(logits, target, B, C, ld, grad_scale, row_loss, dlogits, nullptr, 0, stream);
+}
+
+int renet_softmax_ce_bf16(const float* logits, const int32_t* target, int B, int C, int ld, float grad_scale,
+                          float* row_loss, void* dlogits_bf16, int ld16, int rows16, void* stream) {
+    if (!dlogits_bf16 || ld16 < C || (ld16 & 1) || rows16 < B) return RENET_ERR_BADARG;
+    // rows [B, rows16) of the padded matrix: the k padding of dW = dlogits^T feat (contraction over the rows)
+    if (rows16 > B) {
+        hipError_t e = hipMemsetAsync((__bf16*)dlogits_bf16 + (size_t)B * ld16, 0,
+                                      (size_t)(rows16 - B) * ld16 * sizeof(__bf16), (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return softmax_ce_impl(logits, target, B, C, ld, grad_scale, row_loss, nullptr, (__bf16*)dlogits_bf16, ld16, stream);
+}
+
+static int softmax_ce_impl(const float* logits, const int32_t* target, int B, int C, int ld, float grad_scale,
+                           float* row_loss, float* dlogits, __bf16* dl16, int ld16, void* stream) {
     if (B < 0 || C <= 0 || ld < C) return RENET_ERR_BADARG;
     if (B == 0) return RENET_OK;
     const size_t lds = (size_t)C * sizeof(float);
@@ -382,10 +502,10 @@ int renet_softmax_ce(const float* logits, const int32_t* target, int B, int C, i
             attr_set = true;
         }
         RENET_LAUNCH(softmax_ce_lds_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, logits, target, C, ld,
-                     grad_scale, row_loss, dlogits);
+                     grad_scale, row_loss, dlogits, dl16, ld16);
     } else {
         RENET_LAUNCH(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, target, C, ld,
-                     grad_scale, row_loss, dlogits);
+                     grad_scale, row_loss, dlogits, dl16, ld16);
     }
     RENET_LAUNCH_CHECK();
     return RENET_OK;

@@ -248,11 +248,19 @@ class SeqAssembleFn(Function):
     """Aggregator.py:139-165: packed GRU inputs X [S,4D], Xr [S,3D] with fused dropout."""
 
     @staticmethod
-    def forward(ctx, h2, ent, rel, glob, g, drop_p, seed_x, seed_xr):
+    def forward(ctx, h2, ent, rel, glob, g, drop_p, seed_x, seed_xr, lazy_bf16=False):
         ctx.src_ent, ctx.src_rel = ent, rel
         h2, ent, rel, glob = _c(h2), _c(ent), _c(rel), _c(glob)
-        x, xr = K.seq_assemble_fwd(h2, ent, rel, glob, g.subj_row, g.row_ent, g.row_rel, g.glob_row,
-                                   drop_p, seed_x, seed_xr)
+        if lazy_bf16 and K.GEMM_MODE == 'bf16s':
+            # bf16-storage mode, internal callers only (RENet.loss_prepared*): X / Xr exist ONLY as bf16 operand
+            # matrices; the fp32 tensors returned to autograd are uninitialised shells that carry them (K.operand
+            # picks the attribute up) -- their values must never be read
+            mx, mxr = K.seq_assemble_fwd_bf16(h2, ent, rel, glob, g.subj_row, g.row_ent, g.row_rel, g.glob_row,
+                                              drop_p, seed_x, seed_xr)
+            x, xr = K.lazy_shell(mx, h2.device), K.lazy_shell(mxr, h2.device)
+        else:
+            x, xr = K.seq_assemble_fwd(h2, ent, rel, glob, g.subj_row, g.row_ent, g.row_rel, g.glob_row,
+                                       drop_p, seed_x, seed_xr)
         ctx.g, ctx.drop_p, ctx.seeds = g, drop_p, (seed_x, seed_xr)
         ctx.shapes = (h2.shape, ent.shape, rel.shape)
         return x, xr
@@ -278,7 +286,7 @@ class SeqAssembleFn(Function):
         else:
             d_rel = torch.zeros(ctx.shapes[2], device=dev, dtype=torch.float32)
             K.segment_add(d_rel_seq, g.plan_r, d_rel)
-        return d_h2, d_ent, d_rel, None, None, None, None, None
+        return d_h2, d_ent, d_rel, None, None, None, None, None, None
 
 
 class GRUFn(Function):
@@ -348,7 +356,7 @@ class MultiGRUFn(Function):
         sv_ = ctx.saved_tensors
         xs, w_ihs, w_hhs, svs = sv_[:n], sv_[n:2 * n], sv_[2 * n:3 * n], sv_[3 * n:4 * n]
         d_gis, d_ghs = K.gru_bwd_layouts([_c(dh[0, :nz]) for dh, nz in zip(dhs, ctx.nnz)], ctx.step_offs, hdim,
-                                         list(w_hhs), list(svs))
+                                         list(w_hhs), list(svs), out_bf16=(K.GEMM_MODE == 'bf16s'))
         out = [None, None, None]
         for k in range(n):
             t_ih, t_hh = (grad_target(t) for t in ctx.src_w[k])
@@ -415,7 +423,13 @@ class HeadCEFn(Function):
         need_grad = any(ctx.needs_input_grad)
         # loss_scale (2 for the merged batch of both passes: sum of two B-row means = 2 x the 2B-row mean) goes into
         # the gradient the CE kernel writes, so that the upstream scalar stays 1 and the 188 MB are not rescaled
-        row_loss = K.softmax_ce(logits, target, float(loss_scale) / b, need_grad)
+        ctx.dl_bf16 = None
+        if need_grad and K.GEMM_MODE == 'bf16s':
+            # bf16-storage mode: the gradient is written as a bf16 operand matrix, the fp32 logits are dropped
+            row_loss, ctx.dl_bf16 = K.softmax_ce_bf16(logits, target, float(loss_scale) / b)
+            logits = feat.new_empty(0)
+        else:
+            row_loss = K.softmax_ce(logits, target, float(loss_scale) / b, need_grad)
         ctx.meta = (d, 3 if c is not None else 2, drop_p, seed, plan_a, plan_c, a.shape,
                     c.shape if c is not None else None)
         if need_grad:
@@ -435,6 +449,8 @@ class HeadCEFn(Function):
         ctx.consumed = True
         # every gradient below is linear in dlogits: fold the upstream scalar (1 for `loss_s + loss_o`, 0.1 for
         # the relation head) into it ONCE, from device memory, instead of scaling three results
+        if ctx.dl_bf16 is not None:
+            dlogits = ctx.dl_bf16
         K.scale_by_device_scalar(dlogits, g)
         dl_op = K.operand(dlogits)                                       # consumed by dfeat and dW
         f_op = ctx.feat_op if ctx.feat_op is not None else feat

@@ -57,6 +57,16 @@ _SIGNATURES = {
     'renet_pack_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'renet_gemm_bf16s': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                  c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'renet_bf16_zero_padding': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'renet_seq_assemble_fwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_int, c_void_p,
+                                            c_int, c_int, c_void_p]),
+    'renet_softmax_ce_bf16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_int,
+                                      c_void_p]),
+    'renet_gru_bwd_layouts_bf16out': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'renet_colsum_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    'renet_scale_bf16_by_device_scalar': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     'renet_colsum_workspace': (c_size_t, [c_int, c_int]),
     'renet_colsum': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     'renet_scale_by_device_scalar': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -410,7 +420,7 @@ GEMM_MODE = os.environ.get('RENET_GEMM', 'bf16x6')      # RENET_GEMM=f32 selects
 
 
 class BF16Mat(object):
-    """A matrix [R, C] stored as bf16 in a zero-padded [Rp, Cp] buffer (Rp, Cp multiples of 128): the operand format of
+    """A matrix [R, C] stored as bf16 in a zero-padded [Rp, Cp] buffer (Rp, Cp multiples of 256): the operand format of
     gemm_bf16s (renet_pack_bf16 / a producer kernel that writes it directly)."""
     __slots__ = ('p', 'R', 'C')
 
@@ -422,12 +432,17 @@ class BF16Mat(object):
         return (self.R, self.C)
 
 
+def bf16_empty(r, c, device):
+    """Uninitialised BF16Mat for a producer kernel that writes the bf16 format directly."""
+    return BF16Mat(torch.empty((r + 255) & ~255, (c + 255) & ~255, device=device, dtype=torch.bfloat16), r, c)
+
+
 def pack_bf16(x):
     """fp32 [R, C] (row-strided views allowed) -> BF16Mat."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
         raise RenetHipError('pack_bf16 needs a 2-D float32 device tensor with unit inner stride')
     r, c = x.shape
-    rp, cp = (r + 127) & ~127, (c + 127) & ~127
+    rp, cp = (r + 255) & ~255, (c + 255) & ~255
     p = torch.empty(rp, cp, device=x.device, dtype=torch.bfloat16)
     t0 = _timer.begin() if _timer is not None else None
     _check(lib().renet_pack_bf16(x.data_ptr(), r, c, x.stride(0), p.data_ptr(), _stream()), 'pack_bf16')
@@ -478,10 +493,35 @@ def _as_bf16(x):
     return m, m.R, m.C
 
 
+_lazy_shells = {}          # (data_ptr, shape) of an uninitialised fp32 shell -> the BF16Mat it stands for
+
+
+def lazy_shell(mat, device):
+    """fp32 tensor of mat's logical shape whose VALUES ARE NEVER WRITTEN: the autograd-visible stand-in of a tensor
+    that exists only as a bf16 operand matrix (bf16-storage mode); operand() resolves it to `mat`."""
+    x = torch.empty(mat.R, mat.C, device=device, dtype=torch.float32)
+    x._renet_bf16 = mat
+    if len(_lazy_shells) > 64:
+        _lazy_shells.clear()
+    _lazy_shells[(x.data_ptr(), (mat.R, mat.C))] = mat
+    return x
+
+
 def operand(x):
     """GEMM operand for activation tensor x: in bf16-storage mode its bf16 copy (packed ONCE, to be handed to every
     GEMM that consumes x), otherwise x itself."""
-    if GEMM_MODE == 'bf16s' and not isinstance(x, BF16Mat):
+    if isinstance(x, BF16Mat):
+        return x
+    lazy = getattr(x, '_renet_bf16', None)          # a producer already wrote the bf16 form (ops.SeqAssembleFn)
+    if lazy is None:
+        # the attribute rides on the Python object; should autograd ever hand over a re-wrapped tensor, the shell is
+        # still recognised by its storage -- an uninitialised shell must never be packed
+        lazy = _lazy_shells.pop((x.data_ptr(), tuple(x.shape)), None)
+    else:
+        _lazy_shells.pop((x.data_ptr(), tuple(x.shape)), None)
+    if lazy is not None:
+        return lazy
+    if GEMM_MODE == 'bf16s':
         return pack_bf16(x)
     return x
 
@@ -608,7 +648,18 @@ def gemm_planes(pa, a_tr, pb, b_tr, out=None, bias=None, alpha=1.0, beta=0.0, sp
 
 
 def colsum(x, out=None, beta=0.0):
-    """out = beta * out + column sums of x."""
+    """out = beta * out + column sums of x (fp32 tensor or BF16Mat)."""
+    if isinstance(x, BF16Mat):
+        m, n = x.R, x.C
+        if out is None:
+            if beta != 0.0:
+                raise RenetHipError('beta != 0 needs an output tensor')
+            out = torch.empty(n, device=x.p.device, dtype=torch.float32)
+        nbytes = lib().renet_colsum_workspace(m, n)
+        ws = torch.empty(nbytes // 4, device=x.p.device, dtype=torch.float32) if nbytes else None
+        _check(lib().renet_colsum_bf16(x.p.data_ptr(), m, n, x.p.shape[1], _f32(out), float(beta),
+                                       ws.data_ptr() if nbytes else None, nbytes, _stream()), 'colsum_bf16')
+        return out
     m, n = x.shape
     if out is None:
         if beta != 0.0:
@@ -623,6 +674,10 @@ def colsum(x, out=None, beta=0.0):
 
 def scale_by_device_scalar(x, g):
     """x *= g in place, g a 0-dim / 1-element DEVICE tensor (no host sync; g == 1 leaves x untouched)."""
+    if isinstance(x, BF16Mat):
+        _check(lib().renet_scale_bf16_by_device_scalar(x.p.data_ptr(), x.p.numel(), _f32(g), _stream()),
+               'scale_bf16_by_device_scalar')
+        return x
     if not x.is_contiguous():
         raise RenetHipError('scale_by_device_scalar needs a contiguous tensor')
     _check(lib().renet_scale_by_device_scalar(_f32(x), x.numel(), _f32(g), _stream()), 'scale_by_device_scalar')
@@ -638,6 +693,28 @@ def seq_assemble_fwd(h2, ent, rel, glob, subj_row, row_ent, row_rel, glob_row, d
                                         int(seed_x), int(seed_xr), _f32(x), _f32(xr), _stream()),
            'seq_assemble_fwd')
     return x, xr
+
+
+def seq_assemble_fwd_bf16(h2, ent, rel, glob, subj_row, row_ent, row_rel, glob_row, drop_p, seed_x, seed_xr):
+    """seq_assemble_fwd with X / Xr written as bf16 operand matrices (-> BF16Mat, BF16Mat); no fp32 copy exists."""
+    s, d = subj_row.numel(), h2.shape[1]
+    x, xr = bf16_empty(s, 4 * d, h2.device), bf16_empty(s, 3 * d, h2.device)
+    _check(lib().renet_seq_assemble_fwd_bf16(_f32(h2), _f32(ent), _f32(rel), _f32(glob), _i32(subj_row), _i32(row_ent),
+                                             _i32(row_rel), _i32(glob_row), s, d, float(drop_p), int(seed_x),
+                                             int(seed_xr), x.p.data_ptr(), x.p.shape[1], xr.p.data_ptr(),
+                                             xr.p.shape[1], x.p.shape[0], _stream()), 'seq_assemble_fwd_bf16')
+    return x, xr
+
+
+def softmax_ce_bf16(logits, target, grad_scale):
+    """-> (row_loss[B], BF16Mat (softmax - onehot) * grad_scale); the fp32 logits are not modified."""
+    b, c = logits.shape
+    row_loss = torch.empty(b, device=logits.device, dtype=torch.float32)
+    dl = bf16_empty(b, c, logits.device)
+    _check(lib().renet_softmax_ce_bf16(logits.data_ptr(), _i32(target), b, c, _ld(logits), float(grad_scale),
+                                       _f32(row_loss), dl.p.data_ptr(), dl.p.shape[1], min((b + 63) & ~63, dl.p.shape[0]),
+                                       _stream()), 'softmax_ce_bf16')
+    return row_loss, dl
 
 
 def seq_assemble_bwd(dx, dxr, step_off, num_steps, num_seq, d, drop_p, seed_x, seed_xr):
@@ -739,9 +816,33 @@ def gru_fwd_layouts(gis, step_offs, hdim, w_hhs, b_hhs, out_rows):
     return hs, svs
 
 
-def gru_bwd_layouts(dh_lasts, step_offs, hdim, w_hhs, saveds):
+def gru_bwd_layouts(dh_lasts, step_offs, hdim, w_hhs, saveds, out_bf16=False):
+    """out_bf16 (bf16-storage mode only): d_gi / d_gh come back as BF16Mat operand matrices instead of fp32 tensors."""
     n = len(dh_lasts)
     dev = saveds[0].device
+    if out_bf16:
+        if GEMM_MODE != 'bf16s':
+            raise RenetHipError('bf16 GRU gradients exist in bf16-storage mode only')
+        d_gis = [bf16_empty(s_.shape[0], 3 * hdim, dev) for s_ in saveds]
+        d_ghs = [bf16_empty(s_.shape[0], 3 * hdim, dev) for s_ in saveds]
+        lds = {m.p.shape[1] for m in d_gis + d_ghs}
+        assert len(lds) == 1
+        for m in d_gis + d_ghs:
+            _check(lib().renet_bf16_zero_padding(m.p.data_ptr(), m.R, m.C, m.p.shape[1], m.p.shape[0], _stream()),
+                   'bf16_zero_padding')
+        for t in list(dh_lasts) + list(w_hhs) + list(saveds):
+            _f32(t)
+        bmax = max([(o[1] - o[0]) if len(o) > 1 else 0 for o in step_offs] + [0])
+        nbytes = n * lib().renet_gru_workspace(int(bmax), hdim)
+        ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
+        so, ls = _offs(step_offs)
+        t0 = _timer.begin() if _timer is not None else None
+        _check(lib().renet_gru_bwd_layouts_bf16out(n, _ptrs(dh_lasts), so, ls, hdim, _ptrs(w_hhs), _ptrs(saveds),
+                                                   _ptrs([m.p for m in d_gis]), _ptrs([m.p for m in d_ghs]),
+                                                   lds.pop(), ws.data_ptr(), nbytes, _stream()), 'gru_bwd_layouts_bf16out')
+        if t0 is not None:
+            _timer.end('gru_recurrence', t0, flops=sum(2.0 * 3 * hdim * hdim * s_.shape[0] for s_ in saveds))
+        return d_gis, d_ghs
     d_gis = [torch.empty(s.shape[0], 3 * hdim, device=dev, dtype=torch.float32) for s in saveds]
     d_ghs = [torch.empty(s.shape[0], 3 * hdim, device=dev, dtype=torch.float32) for s in saveds]
     for t in list(dh_lasts) + list(w_hhs) + list(saveds):

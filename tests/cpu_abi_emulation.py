@@ -218,7 +218,8 @@ def gru_fwd_layouts(gis, step_offs, hdim, w_hhs, b_hhs, out_rows):
     return [r[0] for r in res], [r[1] for r in res]
 
 
-def gru_bwd_layouts(dh_lasts, step_offs, hdim, w_hhs, saveds):
+def gru_bwd_layouts(dh_lasts, step_offs, hdim, w_hhs, saveds, out_bf16=False):
+    assert not out_bf16, 'the CPU emulation has no bf16-storage mode'
     res = [_gru_bwd_one(d, _off(o), hdim, w, s) for d, o, w, s in zip(dh_lasts, step_offs, w_hhs, saveds)]
     return [r[0] for r in res], [r[1] for r in res]
 

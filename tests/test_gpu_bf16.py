@@ -29,7 +29,8 @@ def dev():
 
 
 @pytest.mark.parametrize('m,n,k', [(1, 1, 1), (7, 5, 3), (128, 128, 32), (257, 130, 71), (1024, 777, 600), (333, 400, 4),
-                                   (96, 100, 5000)])
+                                   (96, 100, 5000),
+                                   (6000, 2000, 130)])      # >= 256 tiles of 256 x 128: the tall bf16s kernel
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize('mode', ['bf16', 'bf16s'])
 def test_bf16_gemm_matches_fp64_of_the_rounded_operands(dev, m, n, k, ta, tb, mode):
