@@ -368,6 +368,21 @@ int renet_adam_step_scaled(float* p, float* g, float* m, float* v, size_t n, flo
                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Inference: the joint (relation, object) distribution of pred_r_rank2 and its top-k (model.py:205-209,239).
+ *   renet_joint_softmax : logits [n * R, N] (row stride ld) is overwritten, row (e, r) with
+ *                           softmax(logits[e, r, :]) * softmax(logits_r[e, :])[r] * prob_e[e]
+ *                         (the reference: torch.softmax x2 + two broadcast multiplies); N * 4 <= 128 KB, R <= 1024.
+ *   renet_topk_positive : the k largest elements of every row of x [n, M] (row stride ldx), x >= 0: values and int64
+ *                         column indices, in NO particular order (torch.topk(..., sorted=False)); exact (radix select
+ *                         on the bit pattern); ties at the threshold are broken arbitrarily.
+ *                         workspace: renet_topk_workspace(n) bytes. */
+int renet_joint_softmax(float* logits, int ld, int n, int R, int N, const float* logits_r, int ld_r,
+                        const float* prob_e, void* stream);
+size_t renet_topk_workspace(int n);
+int renet_topk_positive(const float* x, size_t ldx, int n, int M, int k, float* out_val, int64_t* out_idx,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HOST-side batch-graph builder passes (no device work; pointers are HOST arrays): the native form of
  * graph.build_batch's heavy middle, replacing the reference's per-batch DGL subgraph/batch calls
  * (utils.py:115-131,158-170,236-241).  See csrc/host_builder.cpp for the contracts. */

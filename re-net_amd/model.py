@@ -7,6 +7,7 @@ encoder.{weight,bias}_{ih,hh}_l0, encoder_r.*, aggregator.rgcn{1,2}.{weight,loop
 linear.{weight,bias}, linear_r.{weight,bias}.
 """
 import math
+import os
 from collections import defaultdict
 
 import numpy as np
@@ -445,11 +446,22 @@ def _joint_topk_many(self, ents, prob, subject=True):
             s_q[torch.as_tensor(have, device=dev)] = q_seq[::R]                      # the R copies are identical
         ent_rows = self.ent_embeds[torch.as_tensor(es, device=dev)]                   # [n, H]
         feat = torch.cat((ent_rows.repeat_interleave(R, dim=0), s_h, rel_embeds.repeat(n, 1)), dim=1)
-        p_o = torch.softmax(_linear_eval(self.linear, feat), dim=1)                  # [n*R, N_ent]
-        p_r = torch.softmax(_linear_eval(self.linear_r, torch.cat((ent_rows, s_q), dim=1)), dim=1)   # [n, R]
-        joint = (p_o * p_r.reshape(n * R, 1)).view(n, R * self.in_dim)
-        joint = joint * prob[torch.as_tensor(es, device=dev)].view(n, 1)
-        vals, idx = torch.topk(joint, self.num_k, dim=1, sorted=False)
+        logits = _linear_eval(self.linear, feat)                                     # [n*R, N_ent]
+        logits_r = _linear_eval(self.linear_r, torch.cat((ent_rows, s_q), dim=1))    # [n, R]
+        prob_e = prob[torch.as_tensor(es, device=dev)].contiguous()
+        if self.reference_shadowing or self.in_dim * 4 > 128 * 1024 or R > 1024 or not logits.is_cuda or \
+                os.environ.get('RENET_TOPK') == 'torch':
+            # the ORDER of an unsorted torch.topk result is observable through the shadowing quirk: keep
+            # the reference's op sequence there
+            p_o = torch.softmax(logits, dim=1)
+            p_r = torch.softmax(logits_r, dim=1)
+            joint = (p_o * p_r.reshape(n * R, 1)).view(n, R * self.in_dim)
+            joint = joint * prob_e.view(n, 1)
+            vals, idx = torch.topk(joint, self.num_k, dim=1, sorted=False)
+        else:
+            # fused: softmax x softmax x prob in ONE pass over the block, then an exact radix-select top-k
+            K.joint_softmax(logits, R, logits_r, prob_e)
+            vals, idx = K.topk_positive(logits.view(n, R * self.in_dim), self.num_k)
         for i, e in enumerate(es):
             out[e] = (vals[i], idx[i])
     return out

@@ -99,6 +99,10 @@ _SIGNATURES = {
     'renet_dropout': (c_int, [c_void_p, c_size_t, c_float, c_u64, c_void_p, c_void_p]),
     'renet_softmax_ce': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                  c_void_p]),
+    'renet_joint_softmax': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    'renet_topk_workspace': (c_size_t, [c_int]),
+    'renet_topk_positive': (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                                    c_void_p]),
     'renet_adam_workspace': (c_size_t, [c_size_t]),
     'renet_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,
                                 c_float, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -893,6 +897,31 @@ def softmax_ce(logits, target, grad_scale, want_grad):
                                   _f32(row_loss), logits.data_ptr() if want_grad else None, _stream()),
            'softmax_ce')
     return row_loss
+
+
+def joint_softmax(logits, num_rels, logits_r, prob_e):
+    """logits [n * R, N] -> IN PLACE softmax(row) * softmax(logits_r[e])[r] * prob_e[e]  (model.py:205-209)."""
+    nr, n_ent = logits.shape
+    n = nr // num_rels
+    if nr != n * num_rels or tuple(logits_r.shape) != (n, num_rels) or prob_e.numel() != n:
+        raise RenetHipError('joint_softmax: shape mismatch')
+    _check(lib().renet_joint_softmax(logits.data_ptr(), _ld(logits), n, num_rels, n_ent, logits_r.data_ptr(),
+                                     _ld(logits_r), _f32(prob_e), _stream()), 'joint_softmax')
+    return logits
+
+
+def topk_positive(x, k):
+    """Top-k of every row of a non-negative fp32 matrix [n, M] -> (values [n, k], int64 indices [n, k]), unsorted."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
+        raise RenetHipError('topk_positive needs a 2-D float32 device tensor with unit inner stride')
+    n, m = x.shape
+    vals = torch.empty(n, k, device=x.device, dtype=torch.float32)
+    idx = torch.empty(n, k, device=x.device, dtype=torch.int64)
+    nbytes = lib().renet_topk_workspace(n)
+    ws = torch.empty(nbytes // 4 + 1, device=x.device, dtype=torch.int32)
+    _check(lib().renet_topk_positive(x.data_ptr(), x.stride(0) if n > 1 else m, n, m, int(k), vals.data_ptr(),
+                                     idx.data_ptr(), ws.data_ptr(), nbytes, _stream()), 'topk_positive')
+    return vals, idx
 
 
 def segment_pool_fwd(h, seg_ptr, num_graphs, is_max):

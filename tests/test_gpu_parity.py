@@ -892,3 +892,50 @@ def test_edge_case_batches_match_oracle(dev):
         else:
             ref = float(O.renet_forward_loss(params, batch, h[0], h[1], ogd, ge, cfg['num_rels'], c['seq_len'], subject=True))
         assert abs(mine - ref) < 2e-4 * max(1.0, abs(ref)), (name, mine, ref)
+
+
+# ---------------------------------------------------------------------------------------------
+# inference selection kernels (model.py:205-209,239): fused joint softmax + radix-select top-k
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n,m,k', [(1, 5000, 1), (3, 70001, 10), (11, 256 * 23033, 1000), (2, 4097, 4097), (5, 100000, 999)])
+def test_topk_positive_equals_torch_topk(dev, n, m, k):
+    import renet_hip as K
+    g = torch.Generator(device='cpu').manual_seed(n * 7 + k)
+    x = torch.rand(n, m, generator=g).pow(8.0)                   # skewed, many tiny values
+    if m >= 70001:
+        x[:, ::7] = x[:, 3:4]                                    # blocks of exact ties, some at the threshold
+    x = x.to(dev)
+    x[0, :3] = 0.0
+    vals, idx = K.topk_positive(x, k)
+    ref_v, _ = torch.topk(x, k, dim=1, sorted=True)
+    got_v, order = torch.sort(vals, dim=1, descending=True)
+    assert torch.equal(got_v, ref_v)                             # exact multiset of values
+    assert torch.equal(torch.gather(x, 1, idx), vals)            # indices address those values
+    srt = torch.sort(idx, dim=1)[0]
+    assert bool((srt[:, 1:] != srt[:, :-1]).all()) if k > 1 else True    # no index twice
+    assert int(idx.min()) >= 0 and int(idx.max()) < m
+    # row-strided view: the joint block of the inference path is a view [n, R * N] of a [n * R, N] matrix
+    wide = torch.zeros(n, m + 13, device=dev)
+    wide[:, :m] = x
+    v2, i2 = K.topk_positive(wide[:, :m], k)
+    assert torch.equal(torch.sort(v2, dim=1, descending=True)[0], ref_v)
+
+
+def test_joint_softmax_matches_the_reference_expression(dev):
+    """renet_joint_softmax == softmax(logits) * softmax(logits_r)[r] * prob[e] (model.py:205-209 + 239), and the
+    fused top-k of the block picks the same (relation, object) continuations as torch.topk on the reference expression."""
+    import renet_hip as K
+    n, R, N, k = 5, 24, 12554, 100
+    g = torch.Generator().manual_seed(4)
+    logits = (torch.randn(n * R, N, generator=g) * 3).to(dev)
+    lr = (torch.randn(n, R, generator=g) * 2).to(dev)
+    prob = torch.rand(n, generator=g).to(dev) * 1e-3
+    ref = (torch.softmax(logits, dim=1) * torch.softmax(lr, dim=1).reshape(n * R, 1)).view(n, R * N) * prob.view(n, 1)
+    mine = logits.clone()
+    K.joint_softmax(mine, R, lr, prob)
+    torch.testing.assert_close(mine.view(n, R * N), ref, rtol=5e-6, atol=0.0)      # (different reduction order of the row sums)
+    vals, idx = K.topk_positive(mine.view(n, R * N), k)
+    rv, ri = torch.topk(ref, k, dim=1)
+    same = [len(set(idx[i].tolist()) & set(ri[i].tolist())) for i in range(n)]
+    assert min(same) >= k - 1, same                              # identical sets up to a near-tie at the boundary
+    torch.testing.assert_close(torch.sort(vals, dim=1, descending=True)[0], rv, rtol=5e-6, atol=0.0)

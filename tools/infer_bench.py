@@ -18,14 +18,14 @@ import synth
 import utils as U
 
 
-def setup(shape, n_eval_t, hidden, dev, seed=7):
+def setup(shape, n_eval_t, hidden, dev, seed=7, num_k=10):
     quads, ne, nr, _ = synth.make_stream(shape, seed=999, num_t=40 + n_eval_t)
     times = np.unique(quads[:, 3])
     cut = times[-n_eval_t]
     tr, te = quads[quads[:, 3] < cut], quads[quads[:, 3] >= cut]
     torch.manual_seed(seed)
-    net = M.RENet(ne, hidden, nr, dropout=0.0, seq_len=10, num_k=10).to(dev).eval()
-    gnet = GM.RENet_global(ne, hidden, nr, dropout=0.0, seq_len=10, num_k=10, maxpool=1).to(dev).eval()
+    net = M.RENet(ne, hidden, nr, dropout=0.0, seq_len=10, num_k=num_k).to(dev).eval()
+    gnet = GM.RENet_global(ne, hidden, nr, dropout=0.0, seq_len=10, num_k=num_k, maxpool=1).to(dev).eval()
     hs, ho = P.HistoryIndex(quads, 's', 10), P.HistoryIndex(quads, 'o', 10)
     r_tr, r_te = np.arange(len(tr)), np.arange(len(tr), len(quads))
     gd = U.build_graph_dict(tr, nr)
@@ -67,5 +67,29 @@ def main():
                                                                   res['sequential'][0] / res['stream'][0]))
 
 
+def advance_bench(shape='ICEWS18', hidden=200, num_k=1000, n_t=3):
+    """Time of ONE timestamp advance (model.py:222-328: 2 x num_k sampled entities, a [R, N_ent] joint distribution and
+    its top-k for each) at test.py's default num_k = 1000, with the fused selection kernels and with the reference's
+    torch op sequence (RENET_TOPK=torch)."""
+    dev = torch.device('cuda:0')
+    for mode in ('fused', 'torch'):
+        os.environ['RENET_TOPK'] = 'torch' if mode == 'torch' else ''
+        net, gnet, te, tes, teo, total = setup(shape, n_t, hidden, dev, num_k=num_k)
+        ts = np.unique(te[:, 3])
+        times = []
+        with torch.no_grad():
+            for t in ts[1:]:
+                torch.cuda.synchronize()
+                t0 = time.time()
+                net._advance_time(torch.tensor(int(t)), gnet)
+                torch.cuda.synchronize()
+                times.append(time.time() - t0)
+        print('advance (%s selection), num_k %d: %s s per timestamp' % (mode, num_k, ['%.2f' % x for x in times]))
+    os.environ['RENET_TOPK'] = ''
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'advance':
+        advance_bench(*(sys.argv[2:3] or ['ICEWS18']))
+    else:
+        main()
