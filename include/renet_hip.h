@@ -383,6 +383,60 @@ int renet_topk_positive(const float* x, size_t ldx, int n, int M, int k, float* 
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * DEVICE batch-graph builder for the merged training batch (both directions of train.py:136-137 as one batch of 2B
+ * sequences: graph.build_batch_both; replaces utils.py:209-244 + 115-131 + dgl.batch and this library's own HOST
+ * builder for that case).  The dataset is resident in HBM (RenetStoreDev: quadruples, the per-role history index of
+ * preprocess.HistoryIndex, the per-timestamp fact lists of graph.GraphStore); one call takes the B quadruple indices of
+ * a batch (device int32) and fills the caller's output arrays with EXACTLY the arrays the host builder produces
+ * (graph.HostBatch; tests/test_gpu_builder.py compares them bit for bit).  No host synchronisation inside: every stage
+ * launches over the capacities and guards on the device-side counts, which the caller copies back (RENET_BB_NCOUNTS
+ * int32) when it needs the sizes.  counts[RENET_BB_ERR] != 0 => a capacity was exceeded (or a timestamp was not in the
+ * store): the outputs are invalid, rebuild with larger capacities / on the host. */
+typedef struct {
+    const int32_t *q_s, *q_r, *q_o;            /* [n_quads] the stream's quadruples */
+    const int32_t* h_first[2];                 /* role 0 = subject histories, 1 = object histories: per quadruple the */
+    const int32_t* h_count[2];                 /*   first snapshot of its window and the number of snapshots in it    */
+    const int32_t* snap_t[2];                  /* [n_snap] timestamp of every snapshot                                */
+    const int32_t* snap_ptr[2];                /* [n_snap + 1] neighbour range of every snapshot                      */
+    const int32_t* nbr_o[2];                   /* [n_quads] neighbour entities                                        */
+    const int32_t* times;                      /* [T] sorted timestamps of graph_dict                                 */
+    const int32_t* trip_ptr;                   /* [T + 1] fact range of every timestamp                               */
+    const int32_t *trip_s, *trip_r, *trip_o;   /* [n_facts]                                                           */
+    const int32_t* glob_times;                 /* [n_glob] sorted timestamps of the global-embedding table            */
+    int T, n_glob, n_facts, num_ent, num_rels;
+} RenetStoreDev;
+
+typedef struct {
+    int32_t *node_ent, *node_slot, *row_ptr, *col, *etype;
+    float* norm;
+    int32_t *heavy_rows, *e_src, *e_dst, *chunk_ptr, *chunk_type, *type_chunk_ptr;
+    int32_t *e_src2, *e_dst2, *chunk_ptr2, *chunk_type2, *type_chunk_ptr2;
+    int32_t *it_src, *it_type, *grp_ptr;
+    int32_t *subj_row, *row_seq, *row_ent, *row_rel, *glob_row;
+    int32_t *s_sorted, *r_sorted, *rel_label, *ent_label, *perm, *step_off;
+    int32_t* plan_order[4];                    /* 0: node_ent, 1: subj_row, 2: s_sorted, 3: r_sorted */
+    int32_t* plan_seg[4];
+    int32_t* plan_target[4];
+    int32_t* counts;                           /* [RENET_BB_NCOUNTS] */
+    int cap_nodes, cap_edges;
+} RenetBatchOut;
+
+enum {
+    RENET_BB_NNZ = 0, RENET_BB_S, RENET_BB_L, RENET_BB_TB, RENET_BB_FACTS, RENET_BB_N, RENET_BB_NA, RENET_BB_E2,
+    RENET_BB_E, RENET_BB_NHEAVY, RENET_BB_NHEAVY_OUT, RENET_BB_NCHUNKS, RENET_BB_NCHUNKS2, RENET_BB_NITEMS,
+    RENET_BB_NGROUPS, RENET_BB_NGROUPS_OUT, RENET_BB_NSEG0, RENET_BB_NSEG1, RENET_BB_NSEG2, RENET_BB_NSEG3,
+    RENET_BB_ERR, RENET_BB_EOUT,             /* E_out = edges into the row prefix [0, nA) */
+    RENET_BB_STEP_OFF = 24,                  /* counts[24 .. 56]: copy of step_off[0 .. 32] (the GRU launches need it on the host) */
+    RENET_BB_NCOUNTS = 64
+};
+enum { RENET_BB_ERR_TIME = 1, RENET_BB_ERR_GLOB = 2, RENET_BB_ERR_NODES = 4, RENET_BB_ERR_EDGES = 8 };
+
+size_t renet_build_batch_workspace(const RenetStoreDev* store, int B, int cap_nodes, int cap_edges);
+int renet_build_batch_both(const RenetStoreDev* store, const int32_t* idx_dev, int B, int seq_len, int heavy_thresh,
+                           int group_budget, int chunk, const RenetBatchOut* out, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HOST-side batch-graph builder passes (no device work; pointers are HOST arrays): the native form of
  * graph.build_batch's heavy middle, replacing the reference's per-batch DGL subgraph/batch calls
  * (utils.py:115-131,158-170,236-241).  See csrc/host_builder.cpp for the contracts. */

@@ -192,6 +192,33 @@ class RENet(nn.Module):
         prep.step_off = ops.host_offsets(g.host.step_off)
         return prep
 
+    def prepare_both_device(self, idx, dstore, stream=None):
+        """prepare_both() with the batch graph built ON THE DEVICE from the quadruple indices `idx` of a resident dataset
+        (gpu_builder.DeviceStore): enqueues the builder kernels (on `stream`, default the current one) and returns the
+        pending gpu_builder.DeviceBatch at once; finish_prepare_device() turns it into a PreparedBatch."""
+        import gpu_builder
+        return gpu_builder.DeviceBatch(dstore, idx, self.seq_len, stream=stream)
+
+    def finish_prepare_device(self, pending):
+        """Waits for the pending batch's counts (~256 bytes D2H).  Returns the PreparedBatch, or None if a capacity of the
+        device builder was exceeded (the store's capacities have been raised: call prepare_both_device again)."""
+        if not pending.finalize():
+            return None
+        g = pending
+        if g.L > self.seq_len:
+            raise ValueError('history longer than seq_len (%d > %d)' % (g.L, self.seq_len))
+        dev = self.ent_embeds.device
+        prep = PreparedBatch()
+        prep.subject, prep.b, prep.share = None, g.B, 1.0
+        g.glob = self.aggregator.glob_table.get(self.global_emb, self.h_dim, dev).mat
+        prep.g = g
+        prep.perm = None                     # (g.host.perm fetches it on demand)
+        prep.s_idx, prep.r_idx, prep.plan_s, prep.plan_r = g.s_sorted, g.r_sorted, g.plan_s, g.plan_r
+        prep.o_idx, prep.r_label = g.ent_label, g.rel_label
+        prep.batch_sizes = torch.from_numpy(g.host.batch_sizes)
+        prep.step_off = ops.host_offsets(g.host.step_off)
+        return prep
+
     def prepare_both(self, triplets, s_hist, o_hist, graph_dict, shard=None):
         """prepare() for the merged batch of both passes; None -> use prepare() twice.
         shard = (rank, world): keep this rank's share of the batch's sequences (exact data-parallel split: the
