@@ -240,7 +240,7 @@ def main():
     #  e2e_inline : builder on the training thread (one batch at a time)
     #  e2e_value  : builder in forked worker processes (pipeline.BatchPrefetcher), uploads on this thread
     #  e2e_threads8 : builder in 8 threads of THIS process (no fork; the native passes and numpy release the GIL)
-    e2e = e2e_inline = e2e_threads = None
+    e2e = e2e_inline = e2e_threads = e2e_device_builder = device_build_ms = None
     e2e_workers = 0
     if args.e2e_steps > 0 and world == 1:      # single-GPU extra; multi-GPU runs time the device path only
         sync_all()
@@ -249,6 +249,48 @@ def main():
             train_step(*prepare(n_total + k))
         sync_all()
         e2e_inline = args.batch * world * args.e2e_steps / (time.perf_counter() - t0)
+        # the same loop with the DEVICE batch builder (csrc/builder.hip): no worker processes, no builder threads; the
+        # builder kernels of batch k + 1 run on a side stream while step k runs, the training thread only launches
+        if args.passes == 'merged':
+            import gpu_builder
+            dstore = gpu_builder.DeviceStore(quads, hist_s, hist_o, graph_dict, net.global_emb, num_ent, num_rels, dev)
+            side = torch.cuda.Stream()
+
+            def dev_pending(step):
+                return net.prepare_both_device(parallel.shard_indices(perm, step, rank, world, rank_batch), dstore,
+                                               stream=side)
+
+            def dev_finish(pend, step):
+                prep_ = net.finish_prepare_device(pend)
+                while prep_ is None:                             # a capacity grew: rebuild (first batches only)
+                    prep_ = net.finish_prepare_device(dev_pending(step))
+                return prep_
+            n_dev = max(30, 6 * args.e2e_steps)
+            base = n_total + 2000
+            pend = dev_pending(base)
+            for k in range(3):                                   # warm-up (capacities, allocator)
+                nxt = dev_pending(base + k + 1)
+                train_step(dev_finish(pend, base + k))
+                pend = nxt
+            sync_all()
+            t0 = time.perf_counter()
+            for k in range(3, 3 + n_dev):
+                nxt = dev_pending(base + k + 1)
+                train_step(dev_finish(pend, base + k))
+                pend = nxt
+            sync_all()
+            e2e_device_builder = args.batch * world * n_dev / (time.perf_counter() - t0)
+            dev_finish(pend, base + 3 + n_dev)
+            # the builder alone on an idle GPU
+            sync_all()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            pends = [net.prepare_both_device(parallel.shard_indices(perm, base + 100 + k, rank, world, rank_batch), dstore)
+                     for k in range(10)]
+            ev1.record()
+            torch.cuda.synchronize()
+            device_build_ms = ev0.elapsed_time(ev1) / 10
+            del pends
         import pipeline
 
         def host_step(step):
@@ -450,6 +492,7 @@ def main():
         'value_exact_f32': exact, 'pmc_source': pmc_file,
         'traffic_source': ('%s: rocprofv3 --pmc passes of this command (tools/pmc_traffic.py), NOT measured in this run' % pmc_file) if pmc_file else None, 'kernels': kernels, 'gemm_shapes': gemm_shapes, 'cpu_baseline': cpu,
         'host_build_ms': host_build_ms, 'e2e_value': e2e, 'e2e_workers': e2e_workers, 'e2e_inline': e2e_inline, 'e2e_threads8': e2e_threads,
+        'e2e_device_builder': e2e_device_builder, 'device_build_ms': device_build_ms,
         'last_loss': last_loss,
     }
     out.update(companions)

@@ -414,26 +414,37 @@ __global__ __launch_bounds__(256) void bb_expand_kernel(const int32_t* __restric
                                                         uint32_t* __restrict__ key_t, uint32_t* __restrict__ key_t2,
                                                         int32_t* __restrict__ iota, int32_t* __restrict__ deg,
                                                         int32_t* __restrict__ tc, int32_t* __restrict__ tc2) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= cap_edges) return;
-    const int E2 = counts[RENET_BB_E2], E = 2 * E2, nA = counts[RENET_BB_NA], T2 = 2 * num_rels;
-    iota[e] = e;
-    if (e >= E) {                                         // sentinels: sorted behind every valid key
-        key_dt[e] = 1u << key_bits;
-        key_t[e] = (uint32_t)T2;
-        key_t2[e] = (uint32_t)T2;
-        return;
+    // relation frequencies are Zipf-like (the hottest type owns a third of the edges): global atomics on the 2R-bin
+    // histograms serialise (1.3 ms of a 2.2 ms build); workgroup-local LDS histograms, flushed once, instead
+    __shared__ int h1[1024], h2[1024];
+    const int T2 = 2 * num_rels;
+    for (int i = threadIdx.x; i < T2; i += blockDim.x) { h1[i] = 0; h2[i] = 0; }
+    __syncthreads();
+    const int E2 = counts[RENET_BB_E2], E = 2 * E2, nA = counts[RENET_BB_NA];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < cap_edges; e += gridDim.x * blockDim.x) {
+        iota[e] = e;
+        if (e >= E) {                                     // sentinels: sorted behind every valid key
+            key_dt[e] = 1u << key_bits;
+            key_t[e] = (uint32_t)T2;
+            key_t2[e] = (uint32_t)T2;
+            continue;
+        }
+        const int m = e < E2 ? e : e - E2;
+        int s = half_src[m], d = half_dst[m], t = half_et[m];
+        if (e >= E2) { const int tmp = s; s = d; d = tmp; t = t + num_rels >= T2 ? t + num_rels - T2 : t + num_rels; }
+        src[e] = s; dst[e] = d; et[e] = t;
+        key_dt[e] = (uint32_t)d * (uint32_t)T2 + (uint32_t)t;
+        key_t[e] = (uint32_t)t;
+        key_t2[e] = d < nA ? (uint32_t)t : (uint32_t)T2;
+        atomicAdd(&deg[d], 1);
+        atomicAdd(&h1[t], 1);
+        if (d < nA) atomicAdd(&h2[t], 1);
     }
-    const int m = e < E2 ? e : e - E2;
-    int s = half_src[m], d = half_dst[m], t = half_et[m];
-    if (e >= E2) { const int tmp = s; s = d; d = tmp; t = t + num_rels >= T2 ? t + num_rels - T2 : t + num_rels; }
-    src[e] = s; dst[e] = d; et[e] = t;
-    key_dt[e] = (uint32_t)d * (uint32_t)T2 + (uint32_t)t;
-    key_t[e] = (uint32_t)t;
-    key_t2[e] = d < nA ? (uint32_t)t : (uint32_t)T2;
-    atomicAdd(&deg[d], 1);
-    atomicAdd(&tc[t], 1);
-    if (d < nA) atomicAdd(&tc2[t], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < T2; i += blockDim.x) {
+        if (h1[i]) atomicAdd(&tc[i], h1[i]);
+        if (h2[i]) atomicAdd(&tc2[i], h2[i]);
+    }
 }
 
 __global__ void bb_set_e2_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ pos,
@@ -841,7 +852,7 @@ int renet_build_batch_both(const RenetStoreDev* sd, const int32_t* idx_dev, int 
     RENET_LAUNCH(bb_edges_kernel, dim3((cap_facts + 255) / 256), dim3(256), 0, st, S, counts, bf.fact_off, bf.slot_ti,
                  bf.slot_group, bf.flag, bf.pos, bf.fslot, bf.new_id, cap_facts, cap_edges, bf.half_src, bf.half_dst, bf.half_et, err);
     RENET_LAUNCH_CHECK();
-    RENET_LAUNCH(bb_expand_kernel, dim3((cap_edges + 255) / 256), dim3(256), 0, st, counts, sd->num_rels, cap_edges,
+    RENET_LAUNCH(bb_expand_kernel, dim3(min((cap_edges + 255) / 256, 1024)), dim3(256), 0, st, counts, sd->num_rels, cap_edges,
                  key_bits, bf.half_src, bf.half_dst, bf.half_et, bf.src, bf.dst, bf.et, bf.key_dt, bf.key_t, bf.key_t2, bf.iota, bf.deg, bf.tc, bf.tc2);
     RENET_LAUNCH_CHECK();
     tb = bf.tmp_bytes;

@@ -94,6 +94,8 @@ class DeviceStore(object):
         self.c = sd
         # capacities: grown on demand (an overflow is reported in the counts and the batch rebuilt)
         self.cap_nodes, self.cap_edges = 1 << 17, 1 << 19
+        self._pinned = [torch.empty(NCOUNTS, dtype=torch.int32, pin_memory=True) for _ in range(8)]
+        self._pin_next = 0
 
 
 class _Host(object):
@@ -136,9 +138,11 @@ class DeviceBatch(object):
         for n, m in sizes.items():
             offs[n] = tot
             tot += (m + 63) & ~63
-        self._buf = torch.empty(tot, device=dev, dtype=torch.int32)
+        st = stream if stream is not None else torch.cuda.current_stream()
+        with torch.cuda.stream(st):              # the buffers belong to the stream the builder runs on
+            self._buf = torch.empty(tot, device=dev, dtype=torch.int32)
+            self._norm = torch.empty(cn, device=dev, dtype=torch.float32)
         self._v = {n: self._buf[o:o + sizes[n]] for n, o in offs.items()}
-        self._norm = torch.empty(cn, device=dev, dtype=torch.float32)
         out = _BatchOut()
         for n, _ in _BatchOut._fields_:
             if n in self._v:
@@ -150,15 +154,17 @@ class DeviceBatch(object):
         out.cap_nodes, out.cap_edges = cn, ce
         self._caps = (cn, ce)
         nbytes = L.renet_build_batch_workspace(ctypes.byref(store.c), self.B, cn, ce)
-        ws = torch.empty(nbytes // 4 + 64, device=dev, dtype=torch.int32)
-        self._idx = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(dev, non_blocking=True)
-        st = stream if stream is not None else torch.cuda.current_stream()
+        with torch.cuda.stream(st):
+            ws = torch.empty(nbytes // 4 + 64, device=dev, dtype=torch.int32)
+            self._idx = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(dev, non_blocking=True)
         rc = L.renet_build_batch_both(ctypes.byref(store.c), self._idx.data_ptr(), self.B, int(seq_len), G.HEAVY,
                                       G.GROUP_ITEMS, G.CHUNK, ctypes.byref(out), ws.data_ptr(), nbytes, st.cuda_stream)
         if rc != 0:
             raise K.RenetHipError('renet_build_batch_both failed with code %d' % rc)
         self._ws = ws                       # stays alive until the kernels have run (freed in finalize)
-        self._counts_host = torch.empty(NCOUNTS, dtype=torch.int32, pin_memory=True)
+        self._counts_host = store._pinned[store._pin_next % len(store._pinned)]      # (pinned ring: no allocation per batch)
+        store._pin_next += 1
+        self._stream = st
         with torch.cuda.stream(st):
             self._counts_host.copy_(self._v['counts'], non_blocking=True)
             self._done = torch.cuda.Event()
@@ -173,6 +179,10 @@ class DeviceBatch(object):
         self._done.synchronize()
         c = self._counts_host.numpy().astype(np.int64)
         self._ws = None
+        cur = torch.cuda.current_stream()
+        if cur != self._stream:                  # built on a side stream, consumed on this one
+            self._buf.record_stream(cur)
+            self._norm.record_stream(cur)
         if c[C_ERR] != 0:
             if c[C_ERR] & 4:
                 self.store.cap_nodes *= 2
