@@ -41,15 +41,7 @@ class _BatchOut(ctypes.Structure):
 
 
 def _bind():
-    L = K.lib()._cdll
-    if not getattr(L, '_renet_builder_bound', False):
-        L.renet_build_batch_workspace.restype = ctypes.c_size_t
-        L.renet_build_batch_workspace.argtypes = [ctypes.POINTER(_StoreDev), ctypes.c_int, ctypes.c_int, ctypes.c_int]
-        L.renet_build_batch_both.restype = ctypes.c_int
-        L.renet_build_batch_both.argtypes = [ctypes.POINTER(_StoreDev), _P, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                             ctypes.c_int, ctypes.c_int, ctypes.POINTER(_BatchOut), _P, ctypes.c_size_t, _P]
-        L._renet_builder_bound = True
-    return L
+    return K.lib()          # renet_build_batch_workspace / renet_build_batch_both are bound with the rest of the C ABI
 
 
 def _i32(a, dev):
@@ -153,12 +145,13 @@ class DeviceBatch(object):
         out.counts = self._v['counts'].data_ptr()
         out.cap_nodes, out.cap_edges = cn, ce
         self._caps = (cn, ce)
-        nbytes = L.renet_build_batch_workspace(ctypes.byref(store.c), self.B, cn, ce)
+        nbytes = L.renet_build_batch_workspace(ctypes.addressof(store.c), self.B, cn, ce)
         with torch.cuda.stream(st):
             ws = torch.empty(nbytes // 4 + 64, device=dev, dtype=torch.int32)
             self._idx = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(dev, non_blocking=True)
-        rc = L.renet_build_batch_both(ctypes.byref(store.c), self._idx.data_ptr(), self.B, int(seq_len), G.HEAVY,
-                                      G.GROUP_ITEMS, G.CHUNK, ctypes.byref(out), ws.data_ptr(), nbytes, st.cuda_stream)
+        self._out = out                      # (kept alive: the call reads the struct through its address)
+        rc = L.renet_build_batch_both(ctypes.addressof(store.c), self._idx.data_ptr(), self.B, int(seq_len), G.HEAVY,
+                                      G.GROUP_ITEMS, G.CHUNK, ctypes.addressof(out), ws.data_ptr(), nbytes, st.cuda_stream)
         if rc != 0:
             raise K.RenetHipError('renet_build_batch_both failed with code %d' % rc)
         self._ws = ws                       # stays alive until the kernels have run (freed in finalize)

@@ -103,6 +103,9 @@ _SIGNATURES = {
     'renet_topk_workspace': (c_size_t, [c_int]),
     'renet_topk_positive': (c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                     c_void_p]),
+    'renet_build_batch_workspace': (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    'renet_build_batch_both': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                       c_void_p]),
     'renet_adam_workspace': (c_size_t, [c_size_t]),
     'renet_adam_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,
                                 c_float, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
