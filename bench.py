@@ -125,6 +125,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import ops as ops_mod_
+
     class Mode(object):
         """One scaling mode of the data-parallel step: which quadruples a rank takes and how gradients combine."""
 
@@ -156,6 +158,7 @@ def main():
             return net.loss_prepared_pair(*preps)       # the four GRU recurrences of the two passes share one launch
 
         def train_step(self, *preps):
+            ops_mod_.SHARED_GRAPH_SEEDS = self.exact         # one replicated graph: same RGCN dropout masks on every rank
             with opt.step_scope(head_passes=1 if len(preps) == 1 else 2, average=not self.exact):
                 loss = self.step_loss(*preps)
                 loss.backward()

@@ -58,12 +58,12 @@ class RGCNBlockLayer(RGCNLayer):
                     max(g.N, h_in.table.shape[0]) * h_in.table.shape[1] * 4 < (1 << 31):
                 g.ndata['h'] = ops.RGCNTableLayerFn.apply(h_in.table, self.weight, self.loop_weight, g, bool(reverse),
                                                           self.activation is not None, p,
-                                                          ops.next_seed() if p > 0 else 0)
+                                                          ops.next_seed(graph_site=True) if p > 0 else 0)
                 return g
             g.ndata['h'] = h_in.materialise()
         # g.out_rows (set by the aggregator for the LAST layer) = evaluate only the first out_rows rows
         h = ops.RGCNLayerFn.apply(g.ndata['h'], self.weight, self.loop_weight, g, bool(reverse),
-                                  self.activation is not None, p, ops.next_seed() if p > 0 else 0,
+                                  self.activation is not None, p, ops.next_seed(graph_site=True) if p > 0 else 0,
                                   getattr(g, 'out_rows', None))
         g.ndata['h'] = h
         return g

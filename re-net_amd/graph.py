@@ -718,7 +718,9 @@ def shard_sequences(hb, rank, world):
     keeps only its share of the SEQUENCES: sorted sequences rank, rank + world, rank + 2 world, ... (lengths stay
     non-increasing and balanced across the ranks).  The graph arrays are shared with `hb`; the packed sequence layout,
     labels and scatter plans are re-derived for the subset.  Summing the ranks' losses (each weighted b_rank / B, see
-    RENet.loss_prepared_both(share=...)) and gradients reproduces the single-process batch up to fp32 summation order.
+    RENet.loss_prepared_both(share=...)) and gradients reproduces the single-process batch up to fp32 summation order
+    (in train mode: with ops.SHARED_GRAPH_SEEDS = True, so that the replicated RGCN layers draw the same dropout masks on
+    every rank; the per-sequence sites differ by construction -- each rank owns different rows).
     The RGCN layers still run on the whole batch graph on every rank: this option trades scaling of the graph part
     for bit-comparable semantics; `parallel.shard_indices` (per-rank reference batches) is the scalable default."""
     import copy

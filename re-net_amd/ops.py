@@ -17,12 +17,21 @@ def _rank():
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
 
-def next_seed():
+# Exact data-parallel split of ONE batch (graph.shard_sequences, bench --scaling exact): every rank evaluates the SAME
+# batch graph, so the dropout masks of the graph-side sites (the RGCN layers' self-loop dropout) must be the same on
+# every rank for the N-rank step to equal the 1-rank step; the per-sequence sites (sequence assembly, score heads) act
+# on rows only this rank owns and keep rank-dependent seeds.  Set by the caller that shards a batch that way.
+SHARED_GRAPH_SEEDS = False
+
+
+def next_seed(graph_site=False):
     """Fresh 63-bit seed for one dropout site, derived from torch's global seed (train.py:31 seeds it), the
     data-parallel rank (every rank runs with the same torch seed, and identical masks on every rank would
-    correlate the ranks' dropout noise) and a per-process site counter."""
+    correlate the ranks' dropout noise) and a per-process site counter.  graph_site: a site on the batch GRAPH --
+    rank-independent when the ranks replicate one graph (SHARED_GRAPH_SEEDS)."""
     _seed_state['counter'] += 1
-    x = torch.initial_seed() * 0x9E3779B1 + (_rank() + 1) * 0xC2B2AE3D27D4EB4F + _seed_state['counter'] * 0x85EBCA77
+    rank = 0 if (graph_site and SHARED_GRAPH_SEEDS) else _rank()
+    x = torch.initial_seed() * 0x9E3779B1 + (rank + 1) * 0xC2B2AE3D27D4EB4F + _seed_state['counter'] * 0x85EBCA77
     return x & 0x7FFFFFFFFFFFFFFF
 
 

@@ -304,3 +304,22 @@ def test_eight_ranks_with_prefetch_workers_stay_within_the_cores(tmp_path):
         for w in (1, 2, 4, 8):
             n = pipeline.worker_budget(w, cpus=cpus)
             assert n >= 1 and (n == 1 or w * (n + 1) <= cpus)
+
+
+def test_exact_split_shares_graph_site_dropout_seeds_across_ranks(monkeypatch):
+    """in the exact split every rank evaluates the SAME batch graph -- its RGCN dropout masks must be the
+    same on every rank (rank-independent seeds for graph sites), while the per-sequence sites keep rank-dependent
+    seeds; without the switch every site is rank dependent."""
+    import ops
+
+    def seeds(rank, shared):
+        monkeypatch.setattr(ops, '_rank', lambda: rank)
+        monkeypatch.setattr(ops, 'SHARED_GRAPH_SEEDS', shared)
+        ops.reset_seed_counter(0)
+        return [ops.next_seed(graph_site=True), ops.next_seed(graph_site=True), ops.next_seed(), ops.next_seed()]
+    a, b = seeds(0, True), seeds(3, True)
+    assert a[:2] == b[:2] and a[2] != b[2] and a[3] != b[3]
+    c, d = seeds(0, False), seeds(3, False)
+    assert all(x != y for x, y in zip(c, d))
+    assert len(set(a)) == 4
+    ops.reset_seed_counter(0)
