@@ -367,8 +367,11 @@ struct BwdProbB { const float* dh_last; const bf16x8* WTp; const float* saved; f
 struct BwdProbsB { BwdProbB p[MAXP]; };
 
 // Wp: bf16 planes of W_hh in fragment order (split_frag_kernel with G = 3 gates)
-template <int H, int NPL>
-__global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly) {
+// WV: waves per workgroup (default NW = 8; the one-plane bf16 kernels run 16: their steps are latency-, not
+// register-bound, and a 256-workgroup launch has ONE workgroup per CU)
+template <int H, int NPL, int WV = NW>
+__global__ __launch_bounds__(WV * 64) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly) {
+    constexpr int NTW = WV * 64;
     const int lay = ly.lay_of[blockIdx.y];
     const StepOff& so = ly.so[lay];
     const int L = ly.L[lay], out_rows = ly.rows[lay];
@@ -386,8 +389,8 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
     __bf16* Hp = reinterpret_cast<__bf16*>(smem + 2 * MT * C::LDH);      // [NPL][MT][LDP] bf16 planes of Hs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = blockIdx.x * MT;
-    for (int t = tid; t < 2 * MT * C::LDH; t += NT) Hs[t] = 0.f;      // h0 = 0
-    for (int t = tid; t < NPL * MT * Bc::LDP / 2; t += NT) reinterpret_cast<unsigned*>(Hp)[t] = 0u;   // and its planes
+    for (int t = tid; t < 2 * MT * C::LDH; t += NTW) Hs[t] = 0.f;      // h0 = 0
+    for (int t = tid; t < NPL * MT * Bc::LDP / 2; t += NTW) reinterpret_cast<unsigned*>(Hp)[t] = 0u;   // and its planes
     __syncthreads();
     const int jj = lane & 15, kq = lane >> 4, ai = lane & 15;
     // Every workgroup streams the SAME W_hh planes from L2 every step, and workgroups that start together run the
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
         unsigned long long gt_mfma = 0, gt_epi = 0;
         (void)gt_mfma; (void)gt_epi;
 #pragma unroll 1
-        for (int ub0 = wave; ub0 < C::NUB; ub0 += NW) {
+        for (int ub0 = wave; ub0 < C::NUB; ub0 += WV) {
             const unsigned long long gt_a = GT_NOW();
             const int ub = ub0 + rot_u >= C::NUB ? ub0 + rot_u - C::NUB : ub0 + rot_u;
             const int u = ub * 16 + jj;                                 // this lane's hidden unit
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
         GT_PUT(wave, j, 3, GT_NOW());
         __syncthreads();                                                // every wave is done reading Hs / Hp
         GT_PUT(wave, j, 4, GT_NOW());
-        for (int t = tid; t < MT * H; t += NT) {
+        for (int t = tid; t < MT * H; t += NTW) {
             const int i = t / H, u = t - i * H;
             const float v = Hn[i * C::LDH + u];
             Hs[i * C::LDH + u] = v;
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
         __syncthreads();
         GT_PUT(wave, j, 6, GT_NOW());
     }
-    for (int t = tid; t < MT * H; t += NT) {                  // rows >= B were never touched: still h0 = 0
+    for (int t = tid; t < MT * H; t += NTW) {                  // rows >= B were never touched: still h0 = 0
         const int i = t / H, u = t - i * H;
         if (i0 + i < out_rows) h_last[(size_t)(i0 + i) * H + u] = Hs[i * C::LDH + u];
     }
@@ -513,8 +516,9 @@ __global__ __launch_bounds__(NT) void gru_fwd_bf_kernel(FwdProbsB ps, Layouts ly
 // WTp: bf16 planes of W_hh^T (unit = hidden unit, k over the 3H gate columns) in fragment order (G = 1)
 // OUT16: dGi / dGh are written as bf16 (RNE) into matrices with row stride out_ld (elements): the operand format of
 // the bf16-storage GEMMs that consume them (dW_ih, dX, dW_hh); the recurrence itself keeps its fp32 values in LDS.
-template <int H, int NPL, bool OUT16 = false>
-__global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly) {
+template <int H, int NPL, bool OUT16 = false, int WV = NW>
+__global__ __launch_bounds__(WV * 64) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly) {
+    constexpr int NTW = WV * 64;
     const int lay = ly.lay_of[blockIdx.y];
     const StepOff& so = ly.so[lay];
     const int L = ly.L[lay];
@@ -532,11 +536,11 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i0 = blockIdx.x * MT;
     const int B = so.off[1] - so.off[0];
-    for (int t = tid; t < MT * C::LDH; t += NT) {
+    for (int t = tid; t < MT * C::LDH; t += NTW) {
         const int i = t / C::LDH, u = t - i * C::LDH;
         dHs[t] = (u < H && i0 + i < B) ? dh_last[(size_t)(i0 + i) * H + u] : 0.f;
     }
-    for (int t = tid; t < NPL * MT * Bc::LDP3 / 2; t += NT) reinterpret_cast<unsigned*>(Gp)[t] = 0u;
+    for (int t = tid; t < NPL * MT * Bc::LDP3 / 2; t += NTW) reinterpret_cast<unsigned*>(Gp)[t] = 0u;
     __syncthreads();
     const int jj = lane & 15, kq = lane >> 4, ai = lane & 15;
     const int rot_id = (int)((blockIdx.x + gridDim.x * blockIdx.y) >> 3);      // see gru_fwd_bf_kernel
@@ -553,21 +557,21 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
         // phase 1: gate gradients of the live rows.  The saved activations are requested for ALL of this thread's
         // elements first, unconditionally (dead rows read the tile's last live row): inside the `row is alive` branch
         // every element paid its own memory latency (7 in a row per thread and step)
-        constexpr int P1 = (MT * H + NT - 1) / NT;
+        constexpr int P1 = (MT * H + NTW - 1) / NTW;
         constexpr int PC = P1 > 7 ? 7 : P1;                             // elements requested together (35 registers)
 #pragma unroll 1
         for (int q0 = 0; q0 < P1; q0 += PC) {
         float s_r[PC], s_z[PC], s_n[PC], s_hn[PC], s_hp[PC];
 #pragma unroll
         for (int q = 0; q < PC; ++q) {
-            const int t = min(tid + NT * (q0 + q), MT * H - 1);
+            const int t = min(tid + NTW * (q0 + q), MT * H - 1);
             const int i = t / H, u = t - i * H;
             const float* sv = saved + (size_t)(p0 + min(i0 + i, bs - 1)) * 5 * H + u;
             s_r[q] = sv[0]; s_z[q] = sv[H]; s_n[q] = sv[2 * H]; s_hn[q] = sv[3 * H]; s_hp[q] = sv[4 * H];
         }
 #pragma unroll
         for (int q = 0; q < PC; ++q) {
-            const int t = tid + NT * (q0 + q);
+            const int t = tid + NTW * (q0 + q);
             if (q0 + q < P1 && t < MT * H) {
                 const int i = t / H, u = t - i * H;
                 float gr = 0.f, gz = 0.f, gn = 0.f;
@@ -609,7 +613,7 @@ __global__ __launch_bounds__(NT) void gru_bwd_bf_kernel(BwdProbsB ps, Layouts ly
         if (j > 0) {
             // phase 2: dh_prev += dGh W_hh  (rows of dead sequences have dGh = 0 and keep their dh)
 #pragma unroll 1
-            for (int ub0 = wave; ub0 < C::NUB; ub0 += NW) {
+            for (int ub0 = wave; ub0 < C::NUB; ub0 += WV) {
                 {
                     const int ub = ub0 + rot_u >= C::NUB ? ub0 + rot_u - C::NUB : ub0 + rot_u;
                     const int u = ub * 16 + jj;
@@ -1010,14 +1014,19 @@ int launch_fwd(const FwdProbs& ps, int np, const Layouts& ly, hipStream_t st) {
     return RENET_OK;
 }
 
+// waves per workgroup of the one-plane (bf16 mode) recurrences: 16 (128 VGPRs) up to H = 200; 12 (170 VGPRs) at H = 400,
+// where 16 waves spill 17-39 registers
+template <int H> constexpr int nw1() { return H > 200 ? 12 : 16; }
+
 template <int H, int NPL = 3>
 int launch_fwd_bf(const FwdProbsB& ps, int np, const Layouts& ly, hipStream_t st) {
     using C = Cfg<H>;
+    constexpr int WV = NPL == 1 ? nw1<H>() : NW;
     const size_t lds = (size_t)2 * MT * C::LDH * sizeof(float) + (size_t)3 * MT * BCfg<H>::LDP * sizeof(__bf16);
     static bool attr_set = false;
-    const int e = set_lds(gru_fwd_bf_kernel<H, NPL>, lds, attr_set);
+    const int e = set_lds(gru_fwd_bf_kernel<H, NPL, WV>, lds, attr_set);
     if (e != RENET_OK) return e;
-    RENET_LAUNCH((gru_fwd_bf_kernel<H, NPL>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(NT), lds, st, ps, ly);
+    RENET_LAUNCH((gru_fwd_bf_kernel<H, NPL, WV>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(WV * 64), lds, st, ps, ly);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -1039,9 +1048,10 @@ int launch_bwd_bf(const BwdProbsB& ps, int np, const Layouts& ly, hipStream_t st
     using C = Cfg<H>;
     const size_t lds = (size_t)MT * C::LDH * sizeof(float) + (size_t)3 * MT * BCfg<H>::LDP3 * sizeof(__bf16);
     static bool attr_set = false;
-    const int e = set_lds(gru_bwd_bf_kernel<H, NPL, OUT16>, lds, attr_set);
+    constexpr int WV = NPL == 1 ? nw1<H>() : NW;
+    const int e = set_lds(gru_bwd_bf_kernel<H, NPL, OUT16, WV>, lds, attr_set);
     if (e != RENET_OK) return e;
-    RENET_LAUNCH((gru_bwd_bf_kernel<H, NPL, OUT16>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(NT), lds, st, ps, ly);
+    RENET_LAUNCH((gru_bwd_bf_kernel<H, NPL, OUT16, WV>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(WV * 64), lds, st, ps, ly);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
