@@ -286,6 +286,7 @@ __device__ __forceinline__ void store_tile(const SplitArgs& g, int m0, int n0, i
     float* Cout = split ? g.partial + (size_t)z * g.M * g.N : g.C;
     const int ldo = split ? g.N : g.ldc;
     const int half = lane >> 5;
+    const bool accumulate = !split && g.beta != 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -293,17 +294,27 @@ __device__ __forceinline__ void store_tile(const SplitArgs& g, int m0, int n0, i
             const int col = n0 + wn * 64 + j * 32 + (lane & 31);
             if (col >= g.N) continue;
             const float bv = (!split && g.bias) ? g.bias[col] : 0.f;
+            const int row_base = m0 + wm * 64 + i * 32 + 4 * half;
+            // beta != 0 (in-place gradient accumulation): ALL 16 reads of C first, then the 16 stores.  Written as
+            // load / fma / store per element the compiler must assume that a store aliases the next load and chains
+            // 64 memory round trips per lane at the end of every tile.
+            float old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = 0.f;
+            if (accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(row_base + (r & 3) + 8 * (r >> 2), g.M - 1);
+                    old[r] = Cout[(size_t)row * ldo + col];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int row = row_base + (r & 3) + 8 * (r >> 2);
                 if (row < g.M) {
                     float* p = Cout + (size_t)row * ldo + col;
                     if (split) *p = acc[i][j][r];
-                    else {
-                        float v = g.alpha * acc[i][j][r] + bv;
-                        if (g.beta != 0.f) v += g.beta * (*p);
-                        *p = v;
-                    }
+                    else *p = g.alpha * acc[i][j][r] + bv + (accumulate ? g.beta * old[r] : 0.f);
                 }
             }
         }
