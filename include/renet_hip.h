@@ -117,6 +117,25 @@ int renet_rgcn_gather_items_table(const float* table, int table_rows, int D, con
                                   const int32_t* row_map, const float* scale, const float* W, int T, int type_shift,
                                   const float* addend_table, float drop_p, uint64_t seed, int relu, float* out, int N,
                                   const int32_t* heavy_rows, int n_heavy, void* stream);
+
+/* bf16-STORAGE forms of the two item-stream gathers (BASELINE config 5, bench.py --dtype bf16): the relation-block
+ * table W_bf16 [T, w_ld] (row stride w_ld >= D * D/100 bf16 elements; a renet_pack_bf16 matrix) and -- table form --
+ * the entity table table_bf16 [table_rows, table_ld] are read as bf16 and widened in registers; x / the gradient rows,
+ * the addend and the output stay fp32, accumulation is fp32.  Same arguments and results otherwise (the product
+ * rounds W / the table to bf16 exactly as the bf16 GEMMs of this mode do with their operands).
+ * Replaces, like the fp32 forms: RGCN.py:53-77,79-94 (msg_func / bmm + fn.sum + apply_func). */
+int renet_rgcn_gather_items_bf16(const float* x, int D, const int32_t* it_src, const int32_t* it_type,
+                                 const int32_t* grp_ptr, int n_groups, const int32_t* row_ptr, const int32_t* col,
+                                 const int32_t* etype, const float* scale, const void* W_bf16, int w_ld, int T,
+                                 int type_shift, int transpose_w, const float* addend, float drop_p, uint64_t seed,
+                                 int relu, float* out, int N, const int32_t* heavy_rows, int n_heavy, int src_limit,
+                                 int addend_rows, int pruned, void* stream);
+int renet_rgcn_gather_items_table_bf16(const void* table_bf16, int table_ld, int table_rows, int D,
+                                       const int32_t* it_src_t, const int32_t* it_type_t, const int32_t* grp_ptr,
+                                       int n_groups, const int32_t* row_ptr, const int32_t* col_t, const int32_t* etype,
+                                       const int32_t* row_map, const float* scale, const void* W_bf16, int w_ld, int T,
+                                       int type_shift, const float* addend_table, float drop_p, uint64_t seed, int relu,
+                                       float* out, int N, const int32_t* heavy_rows, int n_heavy, void* stream);
 /* Composes the per-batch index arrays of the table-addressed layer on the device (once per batch):
  * it_src_t / it_type_t [n_items], col_t [E] (CSR columns), e_src_t [E] (relation-bucketed edge list of
  * renet_rgcn_bwd_w) = the plain arrays with every SOURCE row u replaced by row_map[u]. */

@@ -65,6 +65,7 @@ struct GatherArgs {
     int n_heavy, heavy_thresh;
     int src_limit;              // edges whose source row is >= src_limit are skipped (pruned layer-2 backward)
     int addend_rows;            // rows >= addend_rows have no addend
+    uint32_t x_rowb, w_rowb;    // item kernels: row stride in BYTES of x (fp32: 4 D; bf16: 2 ld) and of the relation table
     const int32_t* row_map;     // layer 1 on the entity table: addend row of output row v = row_map[v] (hub rows; the
                                 // item stream carries it inside its flush items); nullptr = v
     int N, T, shift, relu;
@@ -351,6 +352,35 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, uint32_t vo
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, 0, 0);
 }
 
+// bf16 STORAGE of the gather operands (BASELINE config 5; MX = 1: relation blocks bf16, MX = 2: source rows too):
+// 8-byte loads of 4 bf16 per lane instead of 16-byte loads of 4 floats, widened to fp32 in registers (exact), fp32
+// accumulation and fp32 addend / output as before.  At D = 400 the 6.4 KB relation block per edge is the stream that
+// bounds the kernel: bf16 blocks halve it.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float4 buf_load4s_bf16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+    return make_float4(bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y));
+}
+// the WCH float4 of one lane's relation-block slice: fp32 (16 WCH bytes at wo) or bf16 (8 WCH bytes at wo)
+template <int WCH, bool B16>
+__device__ __forceinline__ void load_wblock(__amdgpu_buffer_rsrc_t rw, uint32_t wo, uint32_t ws, float4 (&w)[WCH]) {
+    if constexpr (!B16) {
+#pragma unroll
+        for (int q = 0; q < WCH; ++q) w[q] = buf_load4s(rw, wo + 16u * q, ws);
+    } else if constexpr (WCH == 1) {
+        w[0] = buf_load4s_bf16(rw, wo, ws);
+    } else {
+#pragma unroll
+        for (int q = 0; q < WCH / 2; ++q) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)(wo + 16u * q), (int)ws, 0);
+            w[2 * q] = make_float4(bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y));
+            w[2 * q + 1] = make_float4(bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w));
+        }
+    }
+}
+
 constexpr int kItemFlush = -1;   // it_type of a flush item
 constexpr int kItemNop = -2;     // lanes past the end of a group
 // it_type <= kItemFlushMap: a flush item whose self-loop addend lives in row (kItemFlushMap - it_type) of the addend
@@ -374,13 +404,15 @@ __device__ __forceinline__ void row_epilogue(const GatherArgs& g, int row, bool 
     }
 }
 
-template <int SI, int NCH, int UNR, bool TR>
+template <int SI, int NCH, int UNR, bool TR, int MX>
 __device__ __forceinline__ void gather_item_group(const ItemArgs& a, int grp) {
+    constexpr bool XB = MX == 2, WB = MX >= 1;
     constexpr int D = 100 * SI;
     constexpr int CH = D / 4;
     constexpr int WCH = SI;
-    constexpr uint32_t ROWB = D * 4;                     // bytes of one feature row
-    constexpr uint32_t WROWB = D * SI * 4;               // bytes of one relation's blocks
+    constexpr uint32_t ROWB = D * 4;                     // bytes of one fp32 feature row (addend, output)
+    const uint32_t XROWB = a.g.x_rowb;                   // bytes of one row of x (fp32: ROWB; bf16: 2 * its row stride)
+    const uint32_t WROWB = a.g.w_rowb;                   // bytes of one relation's blocks
     const int lane = threadIdx.x & 63;
     const GatherArgs& g = a.g;
     const int i0 = a.grp_ptr[grp];
@@ -396,12 +428,13 @@ __device__ __forceinline__ void gather_item_group(const ItemArgs& a, int grp) {
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(g.x, kBufSpan);
     const __amdgpu_buffer_rsrc_t rad = make_rsrc(g.addend ? g.addend : g.x, kBufSpan);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(g.W, kBufSpan);
-    uint32_t xoff[NCH], woff[NCH];
+    uint32_t xoff[NCH], woff[NCH], aoff[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const uint32_t ch = (uint32_t)(lane + 64 * c);
-        xoff[c] = ch < (uint32_t)CH ? ch * 16u : kOob;
-        woff[c] = ch < (uint32_t)CH ? ch * (16u * WCH) : kOob;
+        xoff[c] = ch < (uint32_t)CH ? ch * (XB ? 8u : 16u) : kOob;
+        aoff[c] = ch < (uint32_t)CH ? ch * 16u : kOob;                 // the addend is always fp32
+        woff[c] = ch < (uint32_t)CH ? ch * ((WB ? 8u : 16u) * WCH) : kOob;
     }
     float4 acc[NCH];
 #pragma unroll
@@ -422,7 +455,7 @@ __device__ __forceinline__ void gather_item_group(const ItemArgs& a, int grp) {
             int tt = t + g.shift;
             if (tt >= g.T) tt -= g.T;
             const int ldrow = t <= kItemFlushMap ? kItemFlushMap - t : src;      // row the x / addend load reads
-            const uint32_t xs = (edge || flush_ad) ? (uint32_t)ldrow * ROWB : 0u;
+            const uint32_t xs = edge ? (uint32_t)ldrow * XROWB : flush_ad ? (uint32_t)ldrow * ROWB : 0u;
             const uint32_t ws = edge ? (uint32_t)tt * WROWB : 0u;
             scv[u] = sp[flush ? src : 0];
 #pragma unroll
@@ -430,11 +463,18 @@ __device__ __forceinline__ void gather_item_group(const ItemArgs& a, int grp) {
                 // an item that loads nothing gets the out-of-range vector offset (a per-item descriptor with
                 // num_records = 0 would do the same in SGPRs, but costs 4 SGPRs per load in flight: > 96 SGPRs
                 // and one wave per SIMD less)
-                const uint32_t xo = (edge || flush_ad) ? xoff[c] : kOob;
                 const uint32_t wo = edge ? woff[c] : kOob;
-                xv[u][c] = flush_ad ? buf_load4s(rad, xo, xs) : buf_load4s(rx, xo, xs);
-#pragma unroll
-                for (int q = 0; q < WCH; ++q) wv[u][c][q] = buf_load4s(rw, wo + 16u * q, ws);
+                if constexpr (!XB) {
+                    const uint32_t xo = (edge || flush_ad) ? xoff[c] : kOob;
+                    xv[u][c] = flush_ad ? buf_load4s(rad, xo, xs) : buf_load4s(rx, xo, xs);
+                } else {
+                    // bf16 source rows and fp32 addend rows differ in load width: two unconditional loads, the one that
+                    // does not apply gets the out-of-range offset (no memory access); exactly one of them is non-zero
+                    const float4 xe = buf_load4s_bf16(rx, edge ? xoff[c] : kOob, xs);
+                    const float4 xa = buf_load4s(rad, flush_ad ? aoff[c] : kOob, xs);
+                    xv[u][c] = f4_add(xe, xa);
+                }
+                load_wblock<WCH, WB>(rw, wo, ws, wv[u][c]);
             }
         }
 #pragma unroll
@@ -458,13 +498,14 @@ __device__ __forceinline__ void gather_item_group(const ItemArgs& a, int grp) {
 // One workgroup per hub row: 64 edge indices per coalesced fetch, wave w takes entries w, w + WAVES, ... of
 // the window UNR at a time (unconditional buffer loads as above); wave 0 prefetches the row's addend;
 // fixed-order LDS combine => deterministic.
-template <int SI, int NCH, int UNR, bool TR, int WAVES>
+template <int SI, int NCH, int UNR, bool TR, int WAVES, int MX>
 __device__ __forceinline__ void gather_hub_row(const GatherArgs& a, int v) {
+    constexpr bool XB = MX == 2, WB = MX >= 1;
     constexpr int D = 100 * SI;
     constexpr int CH = D / 4;
     constexpr int WCH = SI;
     constexpr uint32_t ROWB = D * 4;
-    constexpr uint32_t WROWB = D * SI * 4;
+    const uint32_t XROWB = a.x_rowb, WROWB = a.w_rowb;
     __shared__ float4 red[WAVES][CH];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -480,10 +521,11 @@ __device__ __forceinline__ void gather_hub_row(const GatherArgs& a, int v) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const uint32_t ch = (uint32_t)(lane + 64 * c);
-        xoff[c] = ch < (uint32_t)CH ? ch * 16u : kOob;
-        woff[c] = ch < (uint32_t)CH ? ch * (16u * WCH) : kOob;
+        xoff[c] = ch < (uint32_t)CH ? ch * (XB ? 8u : 16u) : kOob;
+        woff[c] = ch < (uint32_t)CH ? ch * ((WB ? 8u : 16u) * WCH) : kOob;
         acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        adv[c] = buf_load4s(rad, (has_ad && wave == 0) ? xoff[c] : kOob, has_ad ? (uint32_t)adrow * ROWB : 0u);
+        adv[c] = buf_load4s(rad, (has_ad && wave == 0 && ch < (uint32_t)CH) ? ch * 16u : kOob,
+                            has_ad ? (uint32_t)adrow * ROWB : 0u);
     }
     for (int base = e0; base < e1; base += 64) {
         const int cnt = min(64, e1 - base);
@@ -502,13 +544,13 @@ __device__ __forceinline__ void gather_hub_row(const GatherArgs& a, int v) {
                 const int src = __builtin_amdgcn_readlane(my_col, kk);      // lanes >= cnt hold INT_MAX => skipped
                 const int t = __builtin_amdgcn_readlane(my_t, kk);
                 const bool ok = (k + u * WAVES) < cnt && src < a.src_limit;
-                const uint32_t xs = ok ? (uint32_t)src * ROWB : 0u;
+                const uint32_t xs = ok ? (uint32_t)src * XROWB : 0u;
                 const uint32_t ws = ok ? (uint32_t)t * WROWB : 0u;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    xv[u][c] = buf_load4s(rx, ok ? xoff[c] : kOob, xs);
-#pragma unroll
-                    for (int q = 0; q < WCH; ++q) wv[u][c][q] = buf_load4s(rw, (ok ? woff[c] : kOob) + 16u * q, ws);
+                    if constexpr (XB) xv[u][c] = buf_load4s_bf16(rx, ok ? xoff[c] : kOob, xs);
+                    else xv[u][c] = buf_load4s(rx, ok ? xoff[c] : kOob, xs);
+                    load_wblock<WCH, WB>(rw, ok ? woff[c] : kOob, ws, wv[u][c]);
                 }
             }
 #pragma unroll
@@ -538,39 +580,39 @@ __device__ __forceinline__ void gather_hub_row(const GatherArgs& a, int v) {
     }
 }
 
-template <int SI, int NCH, int UNR, bool TR>
+template <int SI, int NCH, int UNR, bool TR, int MX>
 __device__ __forceinline__ void gather_items_body(const ItemArgs& a) {
     if ((int)blockIdx.x < a.g.n_heavy) {
-        gather_hub_row<SI, NCH, UNR, TR, kWaves>(a.g, a.g.heavy[blockIdx.x]);
+        gather_hub_row<SI, NCH, UNR, TR, kWaves, MX>(a.g, a.g.heavy[blockIdx.x]);
         return;
     }
     const int nb = gridDim.x - a.g.n_heavy;
     const int vb = renet_xcd_block(blockIdx.x - a.g.n_heavy, nb);
     const int grp = vb * kWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // neighbouring rows share an XCD
-    if (grp < a.n_groups) gather_item_group<SI, NCH, UNR, TR>(a, grp);
+    if (grp < a.n_groups) gather_item_group<SI, NCH, UNR, TR, MX>(a, grp);
 }
 
 // Four entry kernels with distinct names so that a rocprof kernel trace separates the launch classes of a
 // training step: forward over the full batch graph (layer 1), forward over the subject-row prefix (layer 2),
 // and their backward-wrt-h counterparts (transposed relation blocks).
 #define RENET_GATHER_KERNEL(NAME, TRV)                                                                  \
-    template <int SI, int NCH, int UNR>                                                                 \
-    __global__ __launch_bounds__(kThreads) void NAME(ItemArgs a) { gather_items_body<SI, NCH, UNR, TRV>(a); }
+    template <int SI, int NCH, int UNR, int MX = 0>                                                     \
+    __global__ __launch_bounds__(kThreads) void NAME(ItemArgs a) { gather_items_body<SI, NCH, UNR, TRV, MX>(a); }
 RENET_GATHER_KERNEL(rgcn_gather_fwd_full, false)
 RENET_GATHER_KERNEL(rgcn_gather_fwd_pruned, false)
 RENET_GATHER_KERNEL(rgcn_gather_bwdh_full, true)
 RENET_GATHER_KERNEL(rgcn_gather_bwdh_pruned, true)
 #undef RENET_GATHER_KERNEL
 
-template <int SI, int NCH, int UNR>
+template <int SI, int NCH, int UNR, int MX = 0>
 int launch_gather_items(const ItemArgs& a, bool tr, bool pruned, hipStream_t st) {
     int blocks = (a.n_groups + kWaves - 1) / kWaves;
     blocks = max(8, (blocks + 7) & ~7);                    // multiple of 8 for the XCD remap
     const dim3 grid(blocks + a.g.n_heavy), blk(kThreads);  // hub rows first, then the groups, in ONE launch
-    if (!tr && !pruned) RENET_LAUNCH((rgcn_gather_fwd_full<SI, NCH, UNR>), grid, blk, 0, st, a);
-    else if (!tr) RENET_LAUNCH((rgcn_gather_fwd_pruned<SI, NCH, UNR>), grid, blk, 0, st, a);
-    else if (!pruned) RENET_LAUNCH((rgcn_gather_bwdh_full<SI, NCH, UNR>), grid, blk, 0, st, a);
-    else RENET_LAUNCH((rgcn_gather_bwdh_pruned<SI, NCH, UNR>), grid, blk, 0, st, a);
+    if (!tr && !pruned) RENET_LAUNCH((rgcn_gather_fwd_full<SI, NCH, UNR, MX>), grid, blk, 0, st, a);
+    else if (!tr) RENET_LAUNCH((rgcn_gather_fwd_pruned<SI, NCH, UNR, MX>), grid, blk, 0, st, a);
+    else if (!pruned) RENET_LAUNCH((rgcn_gather_bwdh_full<SI, NCH, UNR, MX>), grid, blk, 0, st, a);
+    else RENET_LAUNCH((rgcn_gather_bwdh_pruned<SI, NCH, UNR, MX>), grid, blk, 0, st, a);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -908,7 +950,7 @@ int renet_rgcn_gather(const float* x, int D, const int32_t* row_ptr, const int32
     }
 }
 
-static int gather_items_impl(const float* x, int x_rows, int D, const int32_t* it_src, const int32_t* it_type,
+static int gather_items_impl(int mx, int x_ld, int w_ld, const float* x, int x_rows, int D, const int32_t* it_src, const int32_t* it_type,
                              const int32_t* grp_ptr, int n_groups, const int32_t* row_ptr, const int32_t* col,
                              const int32_t* etype, const float* scale, const float* W, int T, int type_shift,
                              int transpose_w, const float* addend, float drop_p, uint64_t seed, int relu,
@@ -934,6 +976,24 @@ static int gather_items_impl(const float* x, int x_rows, int D, const int32_t* i
     a.it_src = it_src; a.it_type = it_type; a.grp_ptr = grp_ptr; a.n_groups = n_groups;
     hipStream_t st = (hipStream_t)stream;
     const bool tr = transpose_w != 0, pr = pruned != 0;
+    // bf16 storage: mx = 1: W is a bf16 matrix with row stride w_ld elements; mx = 2: x (a table) too, row stride x_ld
+    a.g.x_rowb = mx == 2 ? (uint32_t)x_ld * 2u : (uint32_t)D * 4u;
+    a.g.w_rowb = mx >= 1 ? (uint32_t)w_ld * 2u : (uint32_t)D * (D / 100) * 4u;
+    if (mx < 0 || mx > 2 || (mx >= 1 && w_ld < D * (D / 100)) || (mx == 2 && x_ld < D)) return RENET_ERR_BADARG;
+    if (mx == 1) {
+        switch (D) {
+            case 100: return launch_gather_items<1, 1, 6, 1>(a, tr, pr, st);
+            case 200: return launch_gather_items<2, 1, 3, 1>(a, tr, pr, st);
+            default: return launch_gather_items<4, 2, 2, 1>(a, tr, pr, st);
+        }
+    }
+    if (mx == 2) {
+        switch (D) {
+            case 100: return launch_gather_items<1, 1, 6, 2>(a, tr, pr, st);
+            case 200: return launch_gather_items<2, 1, 3, 2>(a, tr, pr, st);
+            default: return launch_gather_items<4, 2, 2, 2>(a, tr, pr, st);
+        }
+    }
     const int unr = gather_unr();
     switch (D) {
         case 100:
@@ -959,9 +1019,20 @@ int renet_rgcn_gather_items(const float* x, int D, const int32_t* it_src, const 
                             int transpose_w, const float* addend, float drop_p, uint64_t seed, int relu,
                             float* out, int N, const int32_t* heavy_rows, int n_heavy, int src_limit,
                             int addend_rows, int pruned, void* stream) {
-    return gather_items_impl(x, N, D, it_src, it_type, grp_ptr, n_groups, row_ptr, col, etype, scale, W, T, type_shift,
-                             transpose_w, addend, drop_p, seed, relu, out, N, heavy_rows, n_heavy, src_limit,
+    return gather_items_impl(0, 0, 0, x, N, D, it_src, it_type, grp_ptr, n_groups, row_ptr, col, etype, scale, W, T,
+                             type_shift, transpose_w, addend, drop_p, seed, relu, out, N, heavy_rows, n_heavy, src_limit,
                              addend_rows, pruned, nullptr, stream);
+}
+
+int renet_rgcn_gather_items_bf16(const float* x, int D, const int32_t* it_src, const int32_t* it_type,
+                                 const int32_t* grp_ptr, int n_groups, const int32_t* row_ptr, const int32_t* col,
+                                 const int32_t* etype, const float* scale, const void* W_bf16, int w_ld, int T,
+                                 int type_shift, int transpose_w, const float* addend, float drop_p, uint64_t seed,
+                                 int relu, float* out, int N, const int32_t* heavy_rows, int n_heavy, int src_limit,
+                                 int addend_rows, int pruned, void* stream) {
+    return gather_items_impl(1, 0, w_ld, x, N, D, it_src, it_type, grp_ptr, n_groups, row_ptr, col, etype, scale,
+                             (const float*)W_bf16, T, type_shift, transpose_w, addend, drop_p, seed, relu, out, N,
+                             heavy_rows, n_heavy, src_limit, addend_rows, pruned, nullptr, stream);
 }
 
 int renet_rgcn_gather_items_table(const float* table, int table_rows, int D, const int32_t* it_src_t,
@@ -971,9 +1042,21 @@ int renet_rgcn_gather_items_table(const float* table, int table_rows, int D, con
                                   const float* addend_table, float drop_p, uint64_t seed, int relu, float* out, int N,
                                   const int32_t* heavy_rows, int n_heavy, void* stream) {
     if (!row_map || table_rows <= 0) return RENET_ERR_BADARG;
-    return gather_items_impl(table, table_rows, D, it_src_t, it_type_t, grp_ptr, n_groups, row_ptr, col_t, etype, scale,
-                             W, T, type_shift, 0, addend_table, drop_p, seed, relu, out, N, heavy_rows, n_heavy, 0, 0, 0,
-                             row_map, stream);
+    return gather_items_impl(0, 0, 0, table, table_rows, D, it_src_t, it_type_t, grp_ptr, n_groups, row_ptr, col_t, etype,
+                             scale, W, T, type_shift, 0, addend_table, drop_p, seed, relu, out, N, heavy_rows, n_heavy, 0, 0,
+                             0, row_map, stream);
+}
+
+int renet_rgcn_gather_items_table_bf16(const void* table_bf16, int table_ld, int table_rows, int D,
+                                       const int32_t* it_src_t, const int32_t* it_type_t, const int32_t* grp_ptr,
+                                       int n_groups, const int32_t* row_ptr, const int32_t* col_t, const int32_t* etype,
+                                       const int32_t* row_map, const float* scale, const void* W_bf16, int w_ld, int T,
+                                       int type_shift, const float* addend_table, float drop_p, uint64_t seed, int relu,
+                                       float* out, int N, const int32_t* heavy_rows, int n_heavy, void* stream) {
+    if (!row_map || table_rows <= 0) return RENET_ERR_BADARG;
+    return gather_items_impl(2, table_ld, w_ld, (const float*)table_bf16, table_rows, D, it_src_t, it_type_t, grp_ptr,
+                             n_groups, row_ptr, col_t, etype, scale, (const float*)W_bf16, T, type_shift, 0, addend_table,
+                             drop_p, seed, relu, out, N, heavy_rows, n_heavy, 0, 0, 0, row_map, stream);
 }
 
 int renet_compose_table_items(const int32_t* row_map, const int32_t* it_src, const int32_t* it_type, int n_items,

@@ -143,7 +143,8 @@ class RGCNLayerFn(Function):
         shift = g.num_types // 2 if reverse else 0                     # type_o = type_s +- R (utils.py:75-76)
         h_op = K.operand(h[:n_out])                                    # (bf16 mode: packed once, reused by backward)
         out = K.gemm(h_op, loop_weight)                                # RGCN.py:35
-        K.rgcn_gather_items(h, g, weight, shift, False, out, drop_p, seed, relu, out, use_norm=True, pruned=pruned)
+        K.rgcn_gather_items(h, g, weight, shift, False, out, drop_p, seed, relu, out, use_norm=True, pruned=pruned,
+                            w16=K.gather_weight_bf16(weight))
         ctx.g, ctx.relu, ctx.drop_p, ctx.seed, ctx.shift, ctx.n_out = g, relu, drop_p, seed, shift, n_out
         ctx.h_op = h_op if isinstance(h_op, K.BF16Mat) else None
         ctx.save_for_backward(h, weight, loop_weight, out)
@@ -168,7 +169,7 @@ class RGCNLayerFn(Function):
         # would otherwise pay for as an addend (64 -> 76 us per launch on the merged batch).
         pair_shift = (ctx.shift + g.num_types // 2) % g.num_types
         K.rgcn_gather_items(gn, g, weight, pair_shift, True, None, 0.0, 0, False, dh, use_norm=False, pruned=pruned,
-                            src_limit=n_out if pruned else 0)
+                            src_limit=n_out if pruned else 0, w16=K.gather_weight_bf16(weight))
         gl_op = K.operand(g_loop)
         h_op = ctx.h_op if ctx.h_op is not None else h[:n_out]
         K.gemm(gl_op, loop_weight, tb=True, out=dh[:n_out], beta=1.0)      # += g_loop @ W_loop^T (rows < n_out)
@@ -216,7 +217,8 @@ class RGCNTableLayerFn(Function):
         shift = g.num_types // 2 if reverse else 0
         ew = K.gemm(table, loop_weight)                               # RGCN.py:35 on the entity table
         out = torch.empty(g.N, table.shape[1], device=table.device, dtype=torch.float32)
-        K.rgcn_gather_items_table(table, g, weight, shift, ew, drop_p, seed, relu, out)
+        K.rgcn_gather_items_table(table, g, weight, shift, ew, drop_p, seed, relu, out,
+                                  table16=K.gather_weight_bf16(table), w16=K.gather_weight_bf16(weight))
         ctx.g, ctx.relu, ctx.drop_p, ctx.seed, ctx.shift = g, relu, drop_p, seed, shift
         ctx.save_for_backward(table, weight, loop_weight, out)
         return out
@@ -234,7 +236,8 @@ class RGCNTableLayerFn(Function):
         K.rgcn_bwd_prep(g_out, out, g.norm, ctx.relu, ctx.drop_p, ctx.seed, gn, g_loop)
         dh = torch.empty(n, d, device=dev, dtype=torch.float32)
         pair_shift = (ctx.shift + g.num_types // 2) % g.num_types
-        K.rgcn_gather_items(gn, g, weight, pair_shift, True, None, 0.0, 0, False, dh, use_norm=False)
+        K.rgcn_gather_items(gn, g, weight, pair_shift, True, None, 0.0, 0, False, dh, use_norm=False,
+                            w16=K.gather_weight_bf16(weight))
         acc = tgt_w is not None
         d_w = tgt_w if acc else torch.empty_like(weight)
         K.rgcn_bwd_w(table, gn, g.table_items()[3], g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr,

@@ -32,6 +32,14 @@ _SIGNATURES = {
     'renet_rgcn_gather_items': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_u64,
                                         c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'renet_rgcn_gather_items_bf16': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                             c_float, c_u64, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                                             c_int, c_void_p]),
+    'renet_rgcn_gather_items_table_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                                   c_int, c_int, c_void_p, c_float, c_u64, c_int, c_void_p, c_int,
+                                                   c_void_p, c_int, c_void_p]),
     'renet_rgcn_gather_items_table': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                               c_float, c_u64, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
@@ -290,18 +298,21 @@ def rgcn_gather(x, row_ptr, col, etype, scale, weight, type_shift, transpose_w, 
     return out
 
 
-def gather_bytes(n_edges, n_rows, d, weight_numel, has_addend):
+def gather_bytes(n_edges, n_rows, d, weight_numel, has_addend, x_bytes=4, w_bytes=4):
     """Algorithmic bytes of one gather-SpMM launch: per edge one source row + its source and type
     index; per output row the row itself + row_ptr + norm (+ the fused self-loop addend row, which the formula
-    allows to count when the epilogue is fused); the relation weight table once."""
-    return (n_edges * (d * 4 + 8) + n_rows * (d * 4 + 8) + weight_numel * 4 + (n_rows * d * 4 if has_addend else 0))
+    allows to count when the epilogue is fused); the relation weight table once.  x_bytes / w_bytes: element size
+    of the source rows / the relation table as STORED (2 in the bf16-storage forms)."""
+    return (n_edges * (d * x_bytes + 8) + n_rows * (d * 4 + 8) + weight_numel * w_bytes +
+            (n_rows * d * 4 if has_addend else 0))
 
 
 def rgcn_gather_items(x, g, weight, type_shift, transpose_w, addend, drop_p, seed, relu, out, use_norm=True,
-                      pruned=False, src_limit=0, addend_rows=0):
+                      pruned=False, src_limit=0, addend_rows=0, w16=None):
     """renet_rgcn_gather_items on the planned item stream of DeviceGraph `g` (graph.plan_gather_items).
     pruned: the launch covers the row prefix [0, out.shape[0]) = g.nA (groups / hub rows of that prefix) in the
-    forward, or all rows with the edges whose source is >= src_limit skipped in the backward."""
+    forward, or all rows with the edges whose source is >= src_limit skipped in the backward.
+    w16: the bf16 copy of `weight` (gather_weight_bf16; bf16-storage mode) -- the relation blocks are then read as bf16."""
     d = x.shape[1]
     n_rows = out.shape[0]
     prefix = n_rows < g.N
@@ -314,19 +325,37 @@ def rgcn_gather_items(x, g, weight, type_shift, transpose_w, addend, drop_p, see
                            transpose_w, addend, drop_p, seed, relu, out, heavy, g.heavy_thresh, src_limit,
                            addend_rows, n_edges=g.E_out if pruned else None)
     t0 = _timer.begin() if _timer is not None else None
-    _check(lib().renet_rgcn_gather_items(_f32(x), d, _i32(g.it_src), _i32(g.it_type), _i32(g.grp_ptr), int(n_groups),
-                                         _i32(g.row_ptr), _i32(g.col), _i32(g.etype),
-                                         _f32(g.norm) if use_norm else None, _f32(weight), weight.shape[0],
-                                         int(type_shift), int(transpose_w), _f32(addend), float(drop_p), int(seed),
-                                         int(relu), _f32(out), n_rows, _i32(heavy) if heavy is not None else None,
-                                         heavy.numel() if heavy is not None else 0, int(src_limit),
-                                         int(addend_rows), int(pruned), _stream()), 'rgcn_gather_items')
+    hv, nhv = (_i32(heavy), heavy.numel()) if heavy is not None else (None, 0)
+    if w16 is not None:
+        _check(lib().renet_rgcn_gather_items_bf16(
+            _f32(x), d, _i32(g.it_src), _i32(g.it_type), _i32(g.grp_ptr), int(n_groups), _i32(g.row_ptr), _i32(g.col),
+            _i32(g.etype), _f32(g.norm) if use_norm else None, w16.p.data_ptr(), w16.p.shape[1], weight.shape[0],
+            int(type_shift), int(transpose_w), _f32(addend), float(drop_p), int(seed), int(relu), _f32(out), n_rows,
+            hv, nhv, int(src_limit), int(addend_rows), int(pruned), _stream()), 'rgcn_gather_items_bf16')
+    else:
+        _check(lib().renet_rgcn_gather_items(
+            _f32(x), d, _i32(g.it_src), _i32(g.it_type), _i32(g.grp_ptr), int(n_groups), _i32(g.row_ptr), _i32(g.col),
+            _i32(g.etype), _f32(g.norm) if use_norm else None, _f32(weight), weight.shape[0], int(type_shift),
+            int(transpose_w), _f32(addend), float(drop_p), int(seed), int(relu), _f32(out), n_rows, hv, nhv,
+            int(src_limit), int(addend_rows), int(pruned), _stream()), 'rgcn_gather_items')
     if t0 is not None:
         e = g.E_out if pruned else g.E
         name = 'rgcn_gather_%s_%s' % ('bwdh' if transpose_w else 'fwd', 'pruned' if pruned else 'full')
-        _timer.end(name, t0, nbytes=float(gather_bytes(e, n_rows, d, weight.numel(), addend is not None)),
-                   tag=float(gather_bytes(e, n_rows, d, weight.numel(), False)))       # tag: the strict bytes
+        wb = 2 if w16 is not None else 4
+        _timer.end(name, t0, nbytes=float(gather_bytes(e, n_rows, d, weight.numel(), addend is not None, 4, wb)),
+                   tag=float(gather_bytes(e, n_rows, d, weight.numel(), False, 4, wb)))       # tag: the strict bytes
     return out
+
+
+def gather_weight_bf16(weight):
+    """bf16 copy of an fp32 matrix the gather kernels read (the relation-block table, the entity table) in
+    bf16-storage mode, else None.  Registered weights come from the per-optimizer-step cache (_as_bf16).
+    RENET_BF16_GATHER=0 keeps the gathers on fp32 operands."""
+    if GEMM_MODE != 'bf16s' or os.environ.get('RENET_BF16_GATHER', '1') == '0':
+        return None
+    if weight.numel() * 2 >= (1 << 31):
+        return None
+    return _as_bf16(weight)[0]
 
 
 def compose_table_items(g):
@@ -342,26 +371,35 @@ def compose_table_items(g):
     return it_src_t, it_type_t, col_t, e_src_t
 
 
-def rgcn_gather_items_table(table, g, weight, type_shift, addend_table, drop_p, seed, relu, out):
+def rgcn_gather_items_table(table, g, weight, type_shift, addend_table, drop_p, seed, relu, out, table16=None,
+                            w16=None):
     """renet_rgcn_gather_items_table: the first RGCN layer reading source rows and the self-loop addend through
-    g.node_ent from [N_ent, D] tables (forward, full graph)."""
+    g.node_ent from [N_ent, D] tables (forward, full graph).  table16 + w16 (gather_weight_bf16): source rows and
+    relation blocks are read from the bf16 copies (the addend table stays fp32)."""
     d = table.shape[1]
     n_rows = out.shape[0]
     it_src_t, it_type_t, col_t, _ = g.table_items()
     heavy = g.heavy_rows
     t0 = _timer.begin() if _timer is not None else None
-    _check(lib().renet_rgcn_gather_items_table(_f32(table), table.shape[0], d, _i32(it_src_t), _i32(it_type_t),
-                                               _i32(g.grp_ptr), int(g.n_groups), _i32(g.row_ptr), _i32(col_t),
-                                               _i32(g.etype), _i32(g.node_ent), _f32(g.norm), _f32(weight),
-                                               weight.shape[0], int(type_shift), _f32(addend_table), float(drop_p),
-                                               int(seed), int(relu), _f32(out), n_rows,
-                                               _i32(heavy) if heavy is not None else None,
-                                               heavy.numel() if heavy is not None else 0, _stream()),
-           'rgcn_gather_items_table')
+    if table16 is not None and w16 is not None:
+        _check(lib().renet_rgcn_gather_items_table_bf16(
+            table16.p.data_ptr(), table16.p.shape[1], table.shape[0], d, _i32(it_src_t), _i32(it_type_t),
+            _i32(g.grp_ptr), int(g.n_groups), _i32(g.row_ptr), _i32(col_t), _i32(g.etype), _i32(g.node_ent),
+            _f32(g.norm), w16.p.data_ptr(), w16.p.shape[1], weight.shape[0], int(type_shift), _f32(addend_table),
+            float(drop_p), int(seed), int(relu), _f32(out), n_rows, _i32(heavy) if heavy is not None else None,
+            heavy.numel() if heavy is not None else 0, _stream()), 'rgcn_gather_items_table_bf16')
+    else:
+        _check(lib().renet_rgcn_gather_items_table(
+            _f32(table), table.shape[0], d, _i32(it_src_t), _i32(it_type_t), _i32(g.grp_ptr), int(g.n_groups),
+            _i32(g.row_ptr), _i32(col_t), _i32(g.etype), _i32(g.node_ent), _f32(g.norm), _f32(weight), weight.shape[0],
+            int(type_shift), _f32(addend_table), float(drop_p), int(seed), int(relu), _f32(out), n_rows,
+            _i32(heavy) if heavy is not None else None, heavy.numel() if heavy is not None else 0, _stream()),
+            'rgcn_gather_items_table')
     if t0 is not None:          # SURVEY 8d's ALGORITHMIC bytes: one source row per edge, one output (+ addend) row per node
+        eb = 2 if (table16 is not None and w16 is not None) else 4
         _timer.end('rgcn_gather_fwd_full', t0,
-                   nbytes=float(gather_bytes(g.E, n_rows, d, weight.numel(), addend_table is not None)),
-                   tag=float(gather_bytes(g.E, n_rows, d, weight.numel(), False)))
+                   nbytes=float(gather_bytes(g.E, n_rows, d, weight.numel(), addend_table is not None, eb, eb)),
+                   tag=float(gather_bytes(g.E, n_rows, d, weight.numel(), False, eb, eb)))
     return out
 
 

@@ -38,7 +38,8 @@ def segment_add2(src0, src1, plan, dst0, dst1):
     segment_add(src1, plan, dst1)
 
 
-def rgcn_gather_items_table(table, g, weight, type_shift, addend_table, drop_p, seed, relu, out):
+def rgcn_gather_items_table(table, g, weight, type_shift, addend_table, drop_p, seed, relu, out, table16=None,
+                            w16=None):
     ent = g.node_ent.long()
     return rgcn_gather_items(table[ent], g, weight, type_shift, False, addend_table[ent] if addend_table is not None
                              else None, drop_p, seed, relu, out, use_norm=True)
@@ -62,7 +63,7 @@ def _blockmul(x, w, d, tr):
 
 
 def rgcn_gather_items(x, g, weight, type_shift, transpose_w, addend, drop_p, seed, relu, out, use_norm=True,
-                      pruned=False, src_limit=0, addend_rows=0):
+                      pruned=False, src_limit=0, addend_rows=0, w16=None):
     _no_drop(drop_p)
     d, n_rows, T = x.shape[1], out.shape[0], weight.shape[0]
     rp = g.row_ptr.long()

@@ -239,3 +239,49 @@ def test_table_addressed_first_layer_equals_materialised_layer(dev, d, drop_p):
         h0 = tab0[hb.node_ent]
         want = reference(h0, src, dst, et, w0, d, T, 0, False, norm, h0 @ l0, True, n, 0, 0)
         assert np.abs(res[0][0] - want).max() <= 2e-5 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('d', [100, 200, 400])
+def test_bf16_stored_operands_equal_fp32_kernels_on_rounded_operands(dev, d):
+    """renet_rgcn_gather_items_bf16 / _table_bf16 widen bf16 relation blocks (and table rows) in registers and run the
+    same fp32 arithmetic in the same order: BIT-identical to the fp32 kernels fed the bf16-rounded values."""
+    import graph as G
+    import renet_hip as K
+    n, n_ent, num_rels = 3000, 700, 9
+    T = 2 * num_rels
+    rng = np.random.RandomState(5 + d)
+    m = 6000
+    a, b, r = rng.randint(0, n, m), rng.randint(0, n, m), rng.randint(0, num_rels, m)
+    hubs = rng.randint(0, n, 4)
+    a[:400] = hubs[rng.randint(0, 4, 400)]
+    src, dst, et = np.concatenate((a, b)), np.concatenate((b, a)), np.concatenate((r, r + num_rels))
+    hb = G.HostBatch.from_edges(n, src, dst, et, num_rels)
+    hb.node_ent = rng.randint(0, n_ent, n).astype(np.int32)
+    hb.plan_node_ent = G.SegPlan.host(hb.node_ent)
+    g = G.DeviceGraph(hb, dev)
+    assert g.heavy_rows is not None and g.heavy_rows.numel() >= 2
+
+    def t32(a_):
+        return torch.from_numpy(a_.astype(np.float32)).to(dev)
+    x, w, tab = t32(rng.randn(n, d) * 0.3), t32(rng.randn(T, d * d // 100) * 0.2), t32(rng.randn(n_ent, d) * 0.3)
+    add, add_tab = t32(rng.randn(n, d)), t32(rng.randn(n_ent, d))
+    w16, tab16 = K.pack_bf16(w), K.pack_bf16(tab)
+    w_r, tab_r = w.bfloat16().float(), tab.bfloat16().float()
+    for tr in (False, True):
+        for use_add in (True, False):
+            got = torch.empty(n, d, device=dev)
+            want = torch.empty(n, d, device=dev)
+            ad = add if use_add else None
+            K.rgcn_gather_items(x, g, w, 0 if not tr else num_rels, tr, ad, 0.0, 0, not tr, got, use_norm=not tr,
+                                w16=w16)
+            K.rgcn_gather_items(x, g, w_r, 0 if not tr else num_rels, tr, ad, 0.0, 0, not tr, want, use_norm=not tr)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (d, tr, use_add, (got - want).abs().max().item())
+    for drop_p in (0.0, 0.3):
+        got = torch.empty(n, d, device=dev)
+        want = torch.empty(n, d, device=dev)
+        K.rgcn_gather_items_table(tab, g, w, 0, add_tab, drop_p, 77, True, got, table16=tab16, w16=w16)
+        K.rgcn_gather_items_table(tab_r, g, w_r, 0, add_tab, drop_p, 77, True, want)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (d, drop_p, (got - want).abs().max().item())
