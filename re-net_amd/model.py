@@ -22,6 +22,10 @@ import renet_hip as K
 from Aggregator import RGCNAggregator
 from utils import *        # noqa: F401,F403  (the reference's model.py re-exports utils the same way)
 
+# both score heads of a pass as one autograd Function (ops.DualHeadCEFn: the relation head on a second stream);
+# RENET_DUAL_HEAD=0 keeps the two ops.HeadCEFn calls
+DUAL_HEAD = os.environ.get('RENET_DUAL_HEAD', '1') != '0'
+
 
 class GRU(nn.Module):
     """Drop-in for nn.GRU(input_size, hidden_size, batch_first=True), one layer, h0 = 0, on the HIP
@@ -242,12 +246,17 @@ class RENet(nn.Module):
         # sum of two B-row means = 2 x the 2B-row mean; a rank holding a share of the batch's sequences (exact
         # data-parallel split) contributes share x that, so that the ranks' losses and gradients SUM to the batch's
         scale = 2.0 * getattr(prep, 'share', 1.0)
+        seed1, seed2 = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
+        if DUAL_HEAD:
+            return ops.DualHeadCEFn.apply(self.ent_embeds, prep.s_idx, s_h, self.rel_embeds, prep.r_idx,
+                                          self.linear.weight, self.linear.bias, prep.o_idx, s_q,
+                                          self.linear_r.weight, self.linear_r.bias, prep.r_label, prep.plan_s,
+                                          prep.plan_r, p, seed1, seed2, scale, 0.1)
         loss_sub = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_h, self.rel_embeds, prep.r_idx,
                                       self.linear.weight, self.linear.bias, prep.o_idx, prep.plan_s,
-                                      prep.plan_r, p, ops.next_seed() if p > 0 else 0, scale)
+                                      prep.plan_r, p, seed1, scale)
         loss_r = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_q, None, None, self.linear_r.weight,
-                                    self.linear_r.bias, prep.r_label, prep.plan_s, None, p,
-                                    ops.next_seed() if p > 0 else 0, scale)
+                                    self.linear_r.bias, prep.r_label, prep.plan_s, None, p, seed2, scale)
         return loss_sub + 0.1 * loss_r
 
     def prepare(self, triplets, hist, graph_dict, subject=True):
@@ -262,12 +271,17 @@ class RENet(nn.Module):
         subject = prep.subject
         rel_embeds = self.rel_embeds[:self.num_rels] if subject else self.rel_embeds[self.num_rels:]
         p = self.drop_p if self.training else 0.0
+        seed1, seed2 = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
+        if DUAL_HEAD:                                                                     # model.py:89-103
+            return ops.DualHeadCEFn.apply(self.ent_embeds, prep.s_idx, s_h, rel_embeds, prep.r_idx,
+                                          self.linear.weight, self.linear.bias, prep.o_idx, s_q,
+                                          self.linear_r.weight, self.linear_r.bias, prep.r_idx, prep.plan_s,
+                                          prep.plan_r, p, seed1, seed2, 1.0, 0.1)
         loss_sub = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_h, rel_embeds, prep.r_idx,
                                       self.linear.weight, self.linear.bias, prep.o_idx, prep.plan_s,
-                                      prep.plan_r, p, ops.next_seed() if p > 0 else 0)   # model.py:89-91
+                                      prep.plan_r, p, seed1)                              # model.py:89-91
         loss_r = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_q, None, None, self.linear_r.weight,
-                                    self.linear_r.bias, prep.r_idx, prep.plan_s, None, p,
-                                    ops.next_seed() if p > 0 else 0)                      # model.py:98-100
+                                    self.linear_r.bias, prep.r_idx, prep.plan_s, None, p, seed2)   # model.py:98-100
         return loss_sub + 0.1 * loss_r                                                    # model.py:103
 
     def _encode(self, prep):

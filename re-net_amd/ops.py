@@ -1,7 +1,9 @@
 """torch.autograd glue around the C-ABI kernels (renet_hip.py).  Each Function's forward AND backward
 run hand-written HIP kernels; torch only owns the tensors and wires the graph.  No CPU / eager
 fallback exists: on a non-HIP tensor these raise."""
+import contextlib
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -10,6 +12,36 @@ from torch.autograd import Function
 import renet_hip as K
 
 _seed_state = {'counter': 0}
+
+# A second HIP stream inside ONE autograd Function: independent kernel chains of a Function (the relation head next
+# to the entity head, encoder_r's GEMMs next to encoder's, a bandwidth-bound bias column sum next to the matrix-bound
+# GEMMs that read the same gradient) are enqueued on two streams between a fork and a join, so that the tail wave of
+# one launch and the few-workgroup kernels of the small chain fill the CUs the other leaves idle.  Fork and join both
+# lie inside the Function: everything outside sees plain stream order.  Memory: a tensor allocated under the side
+# stream is only ever written there after a later fork (which orders the side stream behind every main-stream
+# consumer enqueued so far), and the inputs the side chain reads stay referenced by the caller until after the join.
+# RENET_SIDE_STREAM=0, or kernel timing (K.set_timer: per-kernel events want serial launches), keeps one stream.
+SIDE_STREAM = os.environ.get('RENET_SIDE_STREAM', '1') != '0'
+_side_streams = {}
+
+
+class _Side(object):
+    def __init__(self, device):
+        self.on = SIDE_STREAM and device.type == 'cuda' and K._timer is None
+        if self.on:
+            key = device.index if device.index is not None else torch.cuda.current_device()
+            if key not in _side_streams:
+                _side_streams[key] = torch.cuda.Stream(device=device)
+            self.main = torch.cuda.current_stream(device)
+            self.side = _side_streams[key]
+            self.side.wait_stream(self.main)                       # fork
+
+    def __call__(self):
+        return torch.cuda.stream(self.side) if self.on else contextlib.nullcontext()
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
 
 
 def _rank():
@@ -351,7 +383,15 @@ class MultiGRUFn(Function):
         b_ihs, b_hhs = ts[3::5], ts[4::5]
         hdim = w_hhs[0].shape[1]
         x_ops = [K.operand(x) for x in xs]                              # (bf16 mode: packed once, reused by dW_ih)
-        gis = [K.gemm(x, w, tb=True, bias=b) for x, w, b in zip(x_ops, w_ihs, b_ihs)]
+        # the input projections of the problems are independent: odd problems on the side stream (_Side)
+        sd = _Side(xs[0].device)
+        gis = [None] * n
+        with sd():
+            for k in range(1, n, 2):
+                gis[k] = K.gemm(x_ops[k], w_ihs[k], tb=True, bias=b_ihs[k])
+        for k in range(0, n, 2):
+            gis[k] = K.gemm(x_ops[k], w_ihs[k], tb=True, bias=b_ihs[k])
+        sd.join()
         ctx.x_ops = x_ops if any(isinstance(x, K.BF16Mat) for x in x_ops) else None
         hs, svs = K.gru_fwd_layouts(gis, step_offs, hdim, w_hhs, b_hhs, total_rows)     # rows past nnz are zero
         ctx.step_offs, ctx.hdim, ctx.n = step_offs, hdim, n
@@ -369,8 +409,7 @@ class MultiGRUFn(Function):
         xs, w_ihs, w_hhs, svs = sv_[:n], sv_[n:2 * n], sv_[2 * n:3 * n], sv_[3 * n:4 * n]
         d_gis, d_ghs = K.gru_bwd_layouts([_c(dh[0, :nz]) for dh, nz in zip(dhs, ctx.nnz)], ctx.step_offs, hdim,
                                          list(w_hhs), list(svs), out_bf16=(K.GEMM_MODE == 'bf16s'))
-        out = [None, None, None]
-        for k in range(n):
+        def problem(k):
             t_ih, t_hh = (grad_target(t) for t in ctx.src_w[k])
             t_bi, t_bh = (grad_target(t) for t in ctx.src_b[k])
             dgi, dgh, xx, s_ = d_gis[k], d_ghs[k], xs[k], svs[k]
@@ -403,7 +442,27 @@ class MultiGRUFn(Function):
                 dxx[:, live:].zero_()         # defined values for any other consumer (hooks, detect_anomaly): 6 MB
             else:
                 dxx = K.gemm(dgi_op, w_ihs[k])
-            out += [dxx, dwi, dwh, dbi, dbh]
+            return [dxx, dwi, dwh, dbi, dbh]
+
+        # problems with DIFFERENT parameters are independent of each other (encoder / encoder_r; two problems of the
+        # same encoder accumulate into the same gradient buffers and stay on one stream): the second parameter set's
+        # problems go to the side stream
+        keys = [id(ctx.src_w[k][0]) for k in range(n)]
+        uniq = list(dict.fromkeys(keys))
+        on_side = [len(uniq) > 1 and keys[k] == uniq[1] for k in range(n)]
+        res = [None] * n
+        sd = _Side(d_gis[0].device if not isinstance(d_gis[0], K.BF16Mat) else d_gis[0].p.device)
+        with sd():
+            for k in range(n):
+                if on_side[k]:
+                    res[k] = problem(k)
+        for k in range(n):
+            if not on_side[k]:
+                res[k] = problem(k)
+        sd.join()
+        out = [None, None, None]
+        for k in range(n):
+            out += res[k]
         return tuple(out)
 
 
@@ -414,6 +473,50 @@ def dual_gru(x, xr, enc, enc_r, step_off, total_rows):
     return MultiGRUFn.apply([step_off, step_off], [total_rows, total_rows], [x.shape[1] - h, xr.shape[1] - h],
                             x, enc.weight_ih_l0, enc.weight_hh_l0, enc.bias_ih_l0, enc.bias_hh_l0,
                             xr, enc_r.weight_ih_l0, enc_r.weight_hh_l0, enc_r.bias_ih_l0, enc_r.bias_hh_l0)
+
+
+def _head_forward(a, ia, hmid, c, ic, weight, bias, target, drop_p, seed, grad_scale, need_grad, row_loss=None):
+    """One score head up to the per-row losses: [a[ia] | hmid | c[ic]] -> dropout -> Linear -> CE.
+    -> (row_loss[B], feat, logits-or-gradient buffer, bf16 gradient matrix or None, bf16 copy of feat or None)"""
+    feat = K.concat3_fwd(a, ia, hmid, c, ic, drop_p, seed)
+    feat_op = K.operand(feat)                                        # (bf16 mode: packed once, reused by dW)
+    logits = K.gemm(feat_op, weight, tb=True, bias=bias)             # [B, C]
+    if debug_tap is not None:
+        debug_tap('logits', logits)
+    dl_bf16 = None
+    if need_grad and K.GEMM_MODE == 'bf16s':
+        # bf16-storage mode: the gradient is written as a bf16 operand matrix, the fp32 logits are dropped
+        row_loss, dl_bf16 = K.softmax_ce_bf16(logits, target, grad_scale, row_loss=row_loss)
+        logits = feat.new_empty(0)
+    else:
+        row_loss = K.softmax_ce(logits, target, grad_scale, need_grad, row_loss=row_loss)
+    return row_loss, feat, logits, dl_bf16, (feat_op if isinstance(feat_op, K.BF16Mat) else None)
+
+
+def _head_backward(dlogits, feat, feat_op, weight, t_w, t_b, bias_side=None):
+    """The three gradient products of one score head from its (already scaled) CE gradient -> (dfeat, d_w, d_b).
+    bias_side: a _Side whose stream takes the bias column sum (bandwidth bound, next to the matrix-bound GEMMs that
+    read the same gradient)."""
+    dl_op = K.operand(dlogits)                                       # consumed by dfeat and dW
+    f_op = feat_op if feat_op is not None else feat
+
+    def bias_grad():
+        if t_b is not None:
+            K.colsum(dlogits, out=t_b, beta=1.0)
+            return None
+        return K.colsum(dlogits)
+    if bias_side is not None:
+        with bias_side():
+            d_b = bias_grad()
+    dfeat = K.gemm(dl_op, weight)                                    # [B, parts*D]
+    if t_w is not None:
+        K.gemm(dl_op, f_op, ta=True, out=t_w, beta=1.0)
+        d_w = None
+    else:
+        d_w = K.gemm(dl_op, f_op, ta=True)
+    if bias_side is None:
+        d_b = bias_grad()
+    return dfeat, d_w, d_b
 
 
 class HeadCEFn(Function):
@@ -427,27 +530,17 @@ class HeadCEFn(Function):
         a, hmid, weight, bias = _c(a), _c(hmid), _c(weight), _c(bias)
         c = _c(c) if c is not None else None
         b, d = hmid.shape
-        feat = K.concat3_fwd(a, ia, hmid, c, ic, drop_p, seed)
-        feat_op = K.operand(feat)                                        # (bf16 mode: packed once, reused by dW)
-        logits = K.gemm(feat_op, weight, tb=True, bias=bias)             # [B, C]
-        if debug_tap is not None:
-            debug_tap('logits', logits)
         need_grad = any(ctx.needs_input_grad)
         # loss_scale (2 for the merged batch of both passes: sum of two B-row means = 2 x the 2B-row mean) goes into
         # the gradient the CE kernel writes, so that the upstream scalar stays 1 and the 188 MB are not rescaled
-        ctx.dl_bf16 = None
-        if need_grad and K.GEMM_MODE == 'bf16s':
-            # bf16-storage mode: the gradient is written as a bf16 operand matrix, the fp32 logits are dropped
-            row_loss, ctx.dl_bf16 = K.softmax_ce_bf16(logits, target, float(loss_scale) / b)
-            logits = feat.new_empty(0)
-        else:
-            row_loss = K.softmax_ce(logits, target, float(loss_scale) / b, need_grad)
+        row_loss, feat, logits, ctx.dl_bf16, feat_op = _head_forward(a, ia, hmid, c, ic, weight, bias, target, drop_p,
+                                                                     seed, float(loss_scale) / b, need_grad)
         ctx.meta = (d, 3 if c is not None else 2, drop_p, seed, plan_a, plan_c, a.shape,
                     c.shape if c is not None else None)
         if need_grad:
             ctx.save_for_backward(feat, logits, weight)
             ctx.consumed = False
-            ctx.feat_op = feat_op if isinstance(feat_op, K.BF16Mat) else None
+            ctx.feat_op = feat_op
         return row_loss.mean() if loss_scale == 1.0 else row_loss.mean() * float(loss_scale)
 
     @staticmethod
@@ -464,19 +557,9 @@ class HeadCEFn(Function):
         if ctx.dl_bf16 is not None:
             dlogits = ctx.dl_bf16
         K.scale_by_device_scalar(dlogits, g)
-        dl_op = K.operand(dlogits)                                       # consumed by dfeat and dW
-        f_op = ctx.feat_op if ctx.feat_op is not None else feat
-        dfeat = K.gemm(dl_op, weight)                                    # [B, parts*D]
-        if t_w is not None:
-            K.gemm(dl_op, f_op, ta=True, out=t_w, beta=1.0)
-            d_w = None
-        else:
-            d_w = K.gemm(dl_op, f_op, ta=True)
-        if t_b is not None:
-            K.colsum(dlogits, out=t_b, beta=1.0)
-            d_b = None
-        else:
-            d_b = K.colsum(dlogits)
+        sd = _Side(feat.device)
+        dfeat, d_w, d_b = _head_backward(dlogits, feat, ctx.feat_op, weight, t_w, t_b, bias_side=sd)
+        sd.join()
         if t_w is not None and t_b is not None:
             grad_done(ctx.srcs[2])
             grad_done(ctx.srcs[3])
@@ -494,6 +577,98 @@ class HeadCEFn(Function):
                 d_c = torch.zeros(c_shape, device=g.device, dtype=torch.float32)
                 K.segment_add(dc_rows, plan_c, d_c)
         return d_a, None, dh, d_c, None, d_w, d_b, None, None, None, None, None, None
+
+
+_loss_weights = {}
+
+
+def _loss_weight_vector(b, w1, w2, device):
+    key = (b, float(w1), float(w2), str(device))
+    v = _loss_weights.get(key)
+    if v is None:
+        if len(_loss_weights) > 16:
+            _loss_weights.clear()
+        v = torch.cat((torch.full((b,), float(w1)), torch.full((b,), float(w2)))).to(device)
+        _loss_weights[key] = v
+    return v
+
+
+class DualHeadCEFn(Function):
+    """Both score heads of one pass and their weighted sum (model.py:89-103) as ONE Function:
+        loss_scale * ( mean CE(Linear([ent[s] | s_h | rel[r]]), o)  +  rel_weight * mean CE(Linear_r([ent[s] | s_q]), r) )
+    The relation head (C = 2R classes: three GEMMs of 16-32 workgroups and a handful of few-microsecond kernels per
+    direction of the pass) runs on the side stream next to the entity head's chip-filling GEMMs, in forward and in
+    backward; so does the entity head's bias column sum.  The two heads gather the SAME rows ent[s]: their row
+    gradients are added before ONE segmented scatter-add.  Values: those of the two HeadCEFn calls it replaces (the
+    weight rel_weight is folded into the relation head's CE gradient instead of being applied by autograd)."""
+
+    @staticmethod
+    def forward(ctx, a, ia, h1, c, ic, w1, b1, target1, h2, w2, b2, target2, plan_a, plan_c, drop_p, seed1, seed2,
+                loss_scale=1.0, rel_weight=0.1):
+        ctx.srcs = (a, c, w1, b1, w2, b2)
+        a, h1, h2, c, w1, b1, w2, b2 = (_c(t) for t in (a, h1, h2, c, w1, b1, w2, b2))
+        b, d = h1.shape
+        need_grad = any(ctx.needs_input_grad)
+        s1, s2 = float(loss_scale) / b, float(loss_scale) * float(rel_weight) / b
+        rl = torch.empty(2 * b, device=h1.device, dtype=torch.float32)
+        def head2():
+            return _head_forward(a, ia, h2, None, None, w2, b2, target2, drop_p, seed2, s2, need_grad, row_loss=rl[b:])
+        sd = _Side(h1.device)
+        if debug_tap is None:
+            with sd():
+                _, feat2, lg2, dl2, fop2 = head2()
+        _, feat1, lg1, dl1, fop1 = _head_forward(a, ia, h1, c, ic, w1, b1, target1, drop_p, seed1, s1, need_grad,
+                                                 row_loss=rl[:b])
+        if debug_tap is not None:                            # test hook: the entity head reports first
+            _, feat2, lg2, dl2, fop2 = head2()
+        sd.join()
+        ctx.meta = (d, drop_p, seed1, seed2, plan_a, plan_c, a.shape, c.shape)
+        if need_grad:
+            ctx.save_for_backward(feat1, lg1, w1, feat2, lg2, w2)
+            ctx.consumed = False
+            ctx.bf16 = (dl1, fop1, dl2, fop2)
+        return torch.dot(rl, _loss_weight_vector(b, s1, s2, h1.device))
+
+    @staticmethod
+    def backward(ctx, g):
+        feat1, dl1, w1, feat2, dl2, w2 = ctx.saved_tensors
+        d, drop_p, seed1, seed2, plan_a, plan_c, a_shape, c_shape = ctx.meta
+        t_a, t_c, t_w1, t_b1, t_w2, t_b2 = [grad_target(t) for t in ctx.srcs]
+        if ctx.consumed:
+            raise RuntimeError('DualHeadCEFn: the saved (softmax - onehot) buffers were scaled in place by the first '
+                               'backward pass; a second pass over the same graph is not supported')
+        ctx.consumed = True
+        b1_, fop1, b2_, fop2 = ctx.bf16
+        dl1 = b1_ if b1_ is not None else dl1
+        dl2 = b2_ if b2_ is not None else dl2
+        K.scale_by_device_scalar(dl1, g)                     # upstream scalar (1 in RE-Net's training step)
+        sd = _Side(feat1.device)
+        with sd():
+            K.scale_by_device_scalar(dl2, g)
+            dfeat2, d_w2, d_b2 = _head_backward(dl2, feat2, fop2, w2, t_w2, t_b2)
+            da2, dh2, _ = K.concat3_bwd(dfeat2, d, 2, drop_p, seed2)
+        dfeat1, d_w1, d_b1 = _head_backward(dl1, feat1, fop1, w1, t_w1, t_b1, bias_side=sd)
+        da1, dh1, dc1 = K.concat3_bwd(dfeat1, d, 3, drop_p, seed1)
+        sd.join()
+        if t_w1 is not None and t_b1 is not None:
+            grad_done(ctx.srcs[2])
+            grad_done(ctx.srcs[3])
+        if t_w2 is not None and t_b2 is not None:
+            grad_done(ctx.srcs[4])
+            grad_done(ctx.srcs[5])
+        da1.add_(da2)                                        # same rows ent[s] in both heads: one scatter-add
+        d_a = d_c = None
+        if t_a is not None:
+            K.segment_add(da1, plan_a, t_a)
+        else:
+            d_a = torch.zeros(a_shape, device=g.device, dtype=torch.float32)
+            K.segment_add(da1, plan_a, d_a)
+        if t_c is not None:
+            K.segment_add(dc1, plan_c, t_c)
+        else:
+            d_c = torch.zeros(c_shape, device=g.device, dtype=torch.float32)
+            K.segment_add(dc1, plan_c, d_c)
+        return (d_a, None, dh1, d_c, None, d_w1, d_b1, None, dh2, d_w2, d_b2, None) + (None,) * 7
 
 
 class SegmentPoolFn(Function):

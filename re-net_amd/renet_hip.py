@@ -751,10 +751,11 @@ def seq_assemble_fwd_bf16(h2, ent, rel, glob, subj_row, row_ent, row_rel, glob_r
     return x, xr
 
 
-def softmax_ce_bf16(logits, target, grad_scale):
+def softmax_ce_bf16(logits, target, grad_scale, row_loss=None):
     """-> (row_loss[B], BF16Mat (softmax - onehot) * grad_scale); the fp32 logits are not modified."""
     b, c = logits.shape
-    row_loss = torch.empty(b, device=logits.device, dtype=torch.float32)
+    if row_loss is None:
+        row_loss = torch.empty(b, device=logits.device, dtype=torch.float32)
     dl = bf16_empty(b, c, logits.device)
     _check(lib().renet_softmax_ce_bf16(logits.data_ptr(), _i32(target), b, c, _ld(logits), float(grad_scale),
                                        _f32(row_loss), dl.p.data_ptr(), dl.p.shape[1], min((b + 63) & ~63, dl.p.shape[0]),
@@ -930,10 +931,12 @@ def dropout(x, drop_p, seed):
     return y
 
 
-def softmax_ce(logits, target, grad_scale, want_grad):
-    """Returns row_loss[B]; if want_grad, logits is OVERWRITTEN with (softmax - onehot) * grad_scale."""
+def softmax_ce(logits, target, grad_scale, want_grad, row_loss=None):
+    """Returns row_loss[B] (written into `row_loss` when given); if want_grad, logits is OVERWRITTEN with
+    (softmax - onehot) * grad_scale."""
     b, c = logits.shape
-    row_loss = torch.empty(b, device=logits.device, dtype=torch.float32)
+    if row_loss is None:
+        row_loss = torch.empty(b, device=logits.device, dtype=torch.float32)
     _check(lib().renet_softmax_ce(logits.data_ptr(), _i32(target), b, c, _ld(logits), float(grad_scale),
                                   _f32(row_loss), logits.data_ptr() if want_grad else None, _stream()),
            'softmax_ce')

@@ -242,7 +242,7 @@ def dropout(x, drop_p, seed):
     return x.clone()
 
 
-def softmax_ce(logits, target, grad_scale, want_grad):
+def softmax_ce(logits, target, grad_scale, want_grad, row_loss=None):
     lse = torch.logsumexp(logits, dim=1)
     rows = torch.arange(logits.shape[0])
     loss = lse - logits[rows, target.long()]
@@ -250,6 +250,9 @@ def softmax_ce(logits, target, grad_scale, want_grad):
         g = torch.softmax(logits, dim=1)
         g[rows, target.long()] -= 1.0
         logits.copy_(g * grad_scale)
+    if row_loss is not None:
+        row_loss.copy_(loss)
+        return row_loss
     return loss
 
 

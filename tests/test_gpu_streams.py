@@ -1,0 +1,124 @@
+"""ops.DualHeadCEFn and the fork/join side stream (ops._Side): same values as the single-stream, two-Function path."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 're-net_amd'))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    return torch.device('cuda:0')
+
+
+def _device_plan(idx, dev):
+    import graph as G
+    h = G.SegPlan.host(idx)
+    p = G.SegPlan()
+    p.order, p.seg_ptr, p.target = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in
+                                    (h.order, h.seg_ptr, h.target))
+    p.num_segments = h.num_segments
+    return p
+
+
+def _head_case(dev, seed, b=384, n_ent=1500, n_rel=46, d=200):
+    rng = np.random.RandomState(seed)
+    f32 = lambda a: torch.from_numpy(np.asarray(a, np.float32)).to(dev)       # noqa: E731
+    i32 = lambda a: torch.from_numpy(np.asarray(a, np.int32)).to(dev)         # noqa: E731
+    ia = rng.zipf(1.3, b) % n_ent                                              # hot subjects: long segments
+    ic = rng.randint(0, n_rel, b)
+    case = dict(
+        ent=f32(rng.randn(n_ent, d) * 0.3), rel=f32(rng.randn(n_rel, d) * 0.3),
+        h1=f32(rng.randn(b, d) * 0.5), h2=f32(rng.randn(b, d) * 0.5),
+        w1=f32(rng.randn(n_ent, 3 * d) * 0.05), b1=f32(rng.randn(n_ent) * 0.1),
+        w2=f32(rng.randn(n_rel, 2 * d) * 0.05), b2=f32(rng.randn(n_rel) * 0.1),
+        ia=i32(ia), ic=i32(ic), t1=i32(rng.randint(0, n_ent, b)), t2=i32(rng.randint(0, n_rel, b)),
+        plan_a=_device_plan(ia, dev), plan_c=_device_plan(ic, dev))
+    return case
+
+
+def _run_heads(case, dual, drop_p, scale, with_grad_buffers):
+    import ops
+    names = ('ent', 'rel', 'h1', 'h2', 'w1', 'b1', 'w2', 'b2')
+    leaves = {n: case[n].clone().requires_grad_(True) for n in names}
+    if with_grad_buffers:                        # in-place accumulation targets, as under parallel.HipAdam
+        for n in ('ent', 'rel', 'w1', 'b1', 'w2', 'b2'):
+            leaves[n].grad = torch.full_like(leaves[n], 0.25)
+    L = leaves
+    if dual:
+        loss = ops.DualHeadCEFn.apply(L['ent'], case['ia'], L['h1'], L['rel'], case['ic'], L['w1'], L['b1'], case['t1'],
+                                      L['h2'], L['w2'], L['b2'], case['t2'], case['plan_a'], case['plan_c'], drop_p,
+                                      11, 12, scale, 0.1)
+    else:
+        l1 = ops.HeadCEFn.apply(L['ent'], case['ia'], L['h1'], L['rel'], case['ic'], L['w1'], L['b1'], case['t1'],
+                                case['plan_a'], case['plan_c'], drop_p, 11, scale)
+        l2 = ops.HeadCEFn.apply(L['ent'], case['ia'], L['h2'], None, None, L['w2'], L['b2'], case['t2'],
+                                case['plan_a'], None, drop_p, 12, scale)
+        loss = l1 + 0.1 * l2
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.item(), {n: L[n].grad.detach().cpu().double().numpy() for n in names}
+
+
+@pytest.mark.parametrize('drop_p', [0.0, 0.5])
+@pytest.mark.parametrize('with_grad_buffers', [False, True])
+def test_dual_head_equals_two_single_heads(dev, drop_p, with_grad_buffers):
+    case = _head_case(dev, 3)
+    l_ref, g_ref = _run_heads(case, False, drop_p, 2.0, with_grad_buffers)
+    l_new, g_new = _run_heads(case, True, drop_p, 2.0, with_grad_buffers)
+    assert abs(l_new - l_ref) <= 2e-6 * abs(l_ref), (l_new, l_ref)
+    for n in g_ref:
+        scale = np.abs(g_ref[n]).max()
+        assert scale > 0
+        # same kernels on the same inputs; the relation head's 0.1 is folded into its CE gradient before the GEMMs
+        # instead of scaling it afterwards, and the two heads' ent[s] row gradients are added before the scatter
+        assert np.abs(g_new[n] - g_ref[n]).max() <= 3e-6 * scale, (n, np.abs(g_new[n] - g_ref[n]).max(), scale)
+
+
+def test_side_stream_changes_no_value(dev, monkeypatch):
+    """One merged training step with the fork/join streams and with RENET_SIDE_STREAM=0: bit-identical loss and flat
+    gradient (every kernel sees the same inputs; only the launch interleaving differs)."""
+    import model as M
+    import ops
+    import parallel
+    import preprocess as P
+    import synth
+    quads, num_ent, num_rels, _ = synth.make_stream('ICEWS18', seed=5, num_t=40)
+    gd = P.build_graph_dict(quads, num_rels)
+    hs, ho = P.HistoryIndex(quads, 's', 10), P.HistoryIndex(quads, 'o', 10)
+    idx = np.random.RandomState(1).permutation(len(quads))[:256]
+    results = []
+    for side in (True, False):
+        monkeypatch.setattr(ops, 'SIDE_STREAM', side)
+        torch.manual_seed(7)
+        ops.reset_seed_counter()
+        net = M.RENet(num_ent, 200, num_rels, dropout=0.5, seq_len=10, num_k=10)
+        gen = torch.Generator().manual_seed(3)
+        net.global_emb = {int(t): torch.randn(1, 1, 200, generator=gen) * 0.1 for t in gd}
+        net.to(dev).train()
+        opt = parallel.HipAdam(net, lr=1e-3, weight_decay=1e-5, max_norm=1.0)
+        fs, fo = hs.take(idx), ho.take(idx)
+        losses = []
+        for _ in range(2):
+            prep = net.prepare_both(quads[idx], fs, fo, gd)
+            loss = net.loss_prepared_both(prep)
+            loss.backward()
+            losses.append(loss.item())
+            flat = opt.grads.flat.detach().clone()
+            opt.step()
+        torch.cuda.synchronize()
+        results.append((losses, flat, torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()))
+        opt.close()
+    (la, fa, pa), (lb, fb, pb) = results
+    assert la == lb, (la, lb)
+    assert float(fa.abs().max()) > 0
+    assert torch.equal(fa, fb)
+    assert torch.equal(pa, pb)
