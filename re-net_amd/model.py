@@ -241,7 +241,9 @@ class RENet(nn.Module):
         self.aggregator.last_batch = g
         x, xr = self.aggregator.encode(g, self.ent_embeds, self.rel_embeds, reverse=False, lazy_bf16=True)
         s_h, s_q = ops.dual_gru(x, xr, self.encoder, self.encoder_r, prep.step_off, prep.b)
-        s_h, s_q = s_h[0], s_q[0]
+        # [1, rows, H] -> [rows, H] as a VIEW: indexing with [0] would make autograd fill and copy a zeros tensor per
+        # encoder in the backward pass (select_backward)
+        s_h, s_q = s_h.view(s_h.shape[1:]), s_q.view(s_q.shape[1:])
         p = self.drop_p if self.training else 0.0
         # sum of two B-row means = 2 x the 2B-row mean; a rank holding a share of the batch's sequences (exact
         # data-parallel split) contributes share x that, so that the ranks' losses and gradients SUM to the batch's
@@ -300,7 +302,7 @@ class RENet(nn.Module):
         else:
             x, xr = self._encode(prep)
             s_h, s_q = ops.dual_gru(x, xr, self.encoder, self.encoder_r, prep.step_off, b)   # model.py:86-88, 94-96
-            s_h, s_q = s_h[0], s_q[0]
+            s_h, s_q = s_h.view(s_h.shape[1:]), s_q.view(s_q.shape[1:])
         return self._heads(prep, s_h, s_q)
 
     def loss_prepared_pair(self, prep_s, prep_o):

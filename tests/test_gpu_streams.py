@@ -122,3 +122,31 @@ def test_side_stream_changes_no_value(dev, monkeypatch):
     assert float(fa.abs().max()) > 0
     assert torch.equal(fa, fb)
     assert torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize('d', [100, 200, 400])
+@pytest.mark.parametrize('n_rows,n_tgt,zipf', [(5000, 900, 1.2), (40, 4000, 0.0), (3000, 3, 0.0), (1, 1, 0.0),
+                                               (70000, 23033, 1.1)])
+def test_segment_add_matches_fp64_scatter_add(dev, d, n_rows, n_tgt, zipf):
+    """renet_segment_add / renet_segment_add2: short segments (a wave each), long segments (all 16 waves of the
+    workgroup), targets without rows, one-row inputs; against a float64 index_add and bit-reproducible."""
+    import renet_hip as K
+    rng = np.random.RandomState(n_rows + d)
+    idx = (rng.zipf(zipf, n_rows) % n_tgt) if zipf else rng.randint(0, n_tgt, n_rows)
+    plan = _device_plan(idx, dev)
+    src0 = torch.from_numpy(rng.randn(n_rows, d).astype(np.float32)).to(dev)
+    src1 = torch.from_numpy(rng.randn(n_rows, d).astype(np.float32)).to(dev)
+    base = torch.from_numpy(rng.randn(n_tgt, d).astype(np.float32)).to(dev)
+    lidx = torch.from_numpy(idx.astype(np.int64)).to(dev)
+    want0 = base.double().index_add(0, lidx, src0.double())
+    want1 = base.double().index_add(0, lidx, src1.double())
+    got = K.segment_add(src0, plan, base.clone())
+    a, b = base.clone(), base.clone()
+    K.segment_add2(src0, src1, plan, a, b)
+    again = K.segment_add(src0, plan, base.clone())
+    torch.cuda.synchronize()
+    longest = int(np.bincount(idx).max())
+    tol = 1e-6 * max(1.0, longest ** 0.5) * 8
+    assert (got.double() - want0).abs().max().item() <= tol * max(1.0, want0.abs().max().item())
+    assert torch.equal(got, a) and torch.equal(got, again)
+    assert (b.double() - want1).abs().max().item() <= tol * max(1.0, want1.abs().max().item())
