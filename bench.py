@@ -387,12 +387,15 @@ def main():
     if dom:
         st = stats[dom]
         if st['flops']:
-            # `achieved` counts the ALGORITHMIC fp32 flops (2MNK).  In bf16x6 mode every fp32 product is six
-            # bf16 MFMA products (fp32-class result), so the matrix-pipe ceiling for algorithmic flops is the
-            # dense bf16 peak / 6; in f32 mode it is the f32-input MFMA peak.
+            # `achieved` counts the ALGORITHMIC fp32 flops (2MNK).  In f16x3 mode every fp32 product is three f16
+            # MFMA products (fp32-class result), so the matrix-pipe ceiling for algorithmic flops is the dense
+            # f16 peak / 3; bf16x6: six bf16 products, dense bf16 peak / 6; f32 mode: the f32-input MFMA peak.
             ach = st['flops'] / (st['ms'] * 1e-3) / 1e12
-            peak = {'bf16x6': MFMA_BF16_PEAK_TF / 6.0, 'bf16': MFMA_BF16_PEAK_TF, 'bf16s': MFMA_BF16_PEAK_TF}.get(K.GEMM_MODE, MFMA_F32_PEAK_TF)
-            note = {'bf16x6': 'algorithmic fp32 TFLOP/s; peak = bf16 dense 2500/6 (six bf16 MFMA products per fp32 '
+            peak = {'f16x3': MFMA_BF16_PEAK_TF / 3.0, 'bf16x6': MFMA_BF16_PEAK_TF / 6.0, 'bf16': MFMA_BF16_PEAK_TF,
+                    'bf16s': MFMA_BF16_PEAK_TF}.get(K.GEMM_MODE, MFMA_F32_PEAK_TF)
+            note = {'f16x3': 'algorithmic fp32 TFLOP/s; peak = f16 dense 2500/3 (three f16 MFMA products per fp32 '
+                             'product; the bf16x6 split of rounds 1-2 had 2500/6 = 416.7)',
+                    'bf16x6': 'algorithmic fp32 TFLOP/s; peak = bf16 dense 2500/6 (six bf16 MFMA products per fp32 '
                               'product)', 'bf16': 'bf16 dense MFMA peak', 'bf16s': 'bf16 dense MFMA peak (bf16 operands in HBM)'}.get(K.GEMM_MODE, 'f32-input MFMA peak')
             roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': peak,
                         'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic_of(dom),
@@ -420,7 +423,7 @@ def main():
     if 'gru_recurrence' in stats:
         st = stats['gru_recurrence']
         ach = st['flops'] / (st['ms'] * 1e-3) / 1e12
-        peak = MFMA_BF16_PEAK_TF / 6.0 if K.GEMM_MODE == 'bf16x6' else MFMA_F32_PEAK_TF
+        peak = MFMA_BF16_PEAK_TF / 6.0 if K.GEMM_MODE in ('bf16x6', 'f16x3') else MFMA_F32_PEAK_TF   # (bf16x6 products)
         gru = {'kernel': 'gru_fwd/bwd recurrence (both encoders per launch)', 'bound': 'mfma', 'achieved': ach,
                'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'avg_us': st['ms'] * 1e3 / st['calls'],
                'calls_per_step': st['calls'] / args.steps}
@@ -459,7 +462,7 @@ def main():
 
     # ---- exact-fp32 companion (RENET_GEMM=f32: v_mfma_f32_32x32x2_f32 products instead of bf16x6) ------------
     exact = None
-    if args.f32_steps > 0 and world == 1 and K.GEMM_MODE == 'bf16x6':
+    if args.f32_steps > 0 and world == 1 and K.GEMM_MODE in ('bf16x6', 'f16x3'):
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.f32_steps), '--warmup', str(args.warmup),
                '--shape', args.shape, '--batch', str(args.batch), '--hidden', str(args.hidden), '--seq-len',

@@ -185,6 +185,24 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
                          const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                          int split_k, float* workspace, size_t workspace_bytes, void* stream);
 
+/* Same contract as renet_gemm_f32 on the f16 matrix cores ("f16x3", csrc/gemm_h3.h): every operand value, scaled by
+ * a power of two of its tensor so that max |x| lands in (2^14, 2^15], is split into two binary16 terms
+ * x s = h1 + 2^-11 h2 and a b is evaluated as a1 b1 + 2^-11 (a1 b2 + a2 b1) with fp32 accumulation: the dropped
+ * term and the split error are <= 2^-24 relative for every element with |x| >= 2^-29 max |x| (smaller elements keep
+ * an ABSOLUTE error <= 2^-39 max |x|) -- fp32-class results with three matrix instructions per fragment pair
+ * instead of six.  maxA / maxB: nA / nB (1..256) device floats whose largest magnitude bounds max |A| / max |B|
+ * from above -- the output of renet_maxabs_partials, or any bound the caller knows (a bound 2^k too large costs k of
+ * the 29 binades).  A bound that is too SMALL overflows binary16: undefined results (inf / NaN).
+ *   renet_maxabs_partials : part[b], b < renet_maxabs_blocks(rows, cols, ld) <= 256 (part[0] = 0 for an empty matrix):
+ *                           the maxima of |x| over disjoint parts of x[rows, cols] (row stride ld); NaNs are ignored.
+ * Replaces the same reference calls as renet_gemm_f32 (torch.mm RGCN.py:35, nn.GRU's input projection model.py:86,94,
+ * nn.Linear model.py:89-90,98-99 and their backward GEMMs). */
+int renet_maxabs_blocks(int rows, int cols, int ld);
+int renet_maxabs_partials(const float* x, int rows, int cols, int ld, float* part, void* stream);
+int renet_gemm_f32_h3(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                      int ldb, float beta, float* C, int ldc, const float* bias, int split_k, float* workspace,
+                      size_t workspace_bytes, const float* maxA, int nA, const float* maxB, int nB, void* stream);
+
 /* Same contract in bf16 mixed precision (BASELINE config 5: "n_hidden=400 bf16"): every fp32 operand value is
  * rounded to bf16 (RNE) on its way into LDS, products on v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 C.
  * Relative error of a product ~2^-8 per operand; a K-long dot product of O(1) terms is accurate to ~2^-8/sqrt(K)
@@ -261,6 +279,10 @@ int renet_colsum(const float* X, int M, int N, int ldx, float* out, float beta, 
 /* x[0..n) *= *scale, with the factor read from DEVICE memory (an upstream autograd gradient: no host sync);
  * a factor of exactly 1 returns without touching x. */
 int renet_scale_by_device_scalar(float* x, size_t n, const float* scale, void* stream);
+/* The same, additionally writing *bound_out = |*scale| * bound_in: the caller's bound on max |x| carried through the
+ * scaling (operand bound of renet_gemm_f32_h3) without a pass over x. */
+int renet_scale_by_device_scalar_bound(float* x, size_t n, const float* scale, float bound_in, float* bound_out,
+                                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sequence assembly (Aggregator.py:142-165): builds the GRU inputs directly in PACKED time-major

@@ -310,9 +310,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
 }
 
 // x *= *scale with the factor in device memory (an upstream autograd gradient); exactly 1 => nothing to do.
+// bound_out (optional): |*scale| * bound_in -- the magnitude bound of the scaled tensor for the f16x3 GEMMs.
 __global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, size_t n,
-                                                        const float* __restrict__ scale) {
+                                                        const float* __restrict__ scale, float bound_in,
+                                                        float* __restrict__ bound_out) {
     const float f = *scale;
+    if (bound_out && blockIdx.x == 0 && threadIdx.x == 0) *bound_out = fabsf(f) * bound_in;
     if (f == 1.f) return;
     const size_t n4 = n >> 2;
     float4* x4 = reinterpret_cast<float4*>(x);
@@ -406,7 +409,16 @@ int renet_scale_by_device_scalar(float* x, size_t n, const float* scale, void* s
     if (!x || !scale || (reinterpret_cast<uintptr_t>(x) & 15)) return RENET_ERR_BADARG;
     if (n == 0) return RENET_OK;
     const int blocks = (int)min((size_t)2048, (n / 4 + 255) / 256 + 1);
-    RENET_LAUNCH(scale_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, scale);
+    RENET_LAUNCH(scale_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, scale, 0.f, (float*)nullptr);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_scale_by_device_scalar_bound(float* x, size_t n, const float* scale, float bound_in, float* bound_out,
+                                       void* stream) {
+    if (!x || !scale || !bound_out || (reinterpret_cast<uintptr_t>(x) & 15)) return RENET_ERR_BADARG;
+    const int blocks = (int)min((size_t)2048, (n / 4 + 255) / 256 + 1);
+    RENET_LAUNCH(scale_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, scale, bound_in, bound_out);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }

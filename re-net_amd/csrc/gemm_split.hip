@@ -1412,6 +1412,17 @@ bool use_tall(int M, int nbx, int split_k) {
     return (long)nbx * ((M + BMT - 1) / BMT) * split_k >= min_tiles;
 }
 
+// f16x3 kernels: the 256-row tile from RENET_H3_TALL tiles on (default 1000, as for the bf16x6 kernels; 0 disables)
+bool use_tall_h3(int M, int nbx, int split_k) {
+    static int min_tiles = -1;
+    if (min_tiles < 0) {
+        const char* e = getenv("RENET_H3_TALL");
+        min_tiles = e ? atoi(e) : 1000;
+        if (e && min_tiles == 0) min_tiles = 0x7fffffff;
+    }
+    return (long)nbx * ((M + 255) / 256) * split_k >= min_tiles;
+}
+
 // Which k-loop: the fused kernel (one workgroup per CU, 122.9 KB LDS) when the whole grid fits in ONE round of
 // 256 workgroups -- there a lone workgroup finishes a k-tile in ~2500 cycles against ~3900 for the two-phase
 // kernel (MI355X: 51 vs 35 TFLOP/s on a 64-tile problem, 155 vs 126 on 256 tiles) -- and the two-phase kernel
@@ -1427,6 +1438,8 @@ int kernel_choice(int ntiles) {
     if (forced >= 0) return forced;
     return ntiles <= 256 ? 0 : 1;
 }
+
+#include "gemm_h3.h"
 
 }  // namespace
 
@@ -1562,6 +1575,82 @@ int renet_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const floa
                     int split_k, float* workspace, size_t workspace_bytes, void* stream) {
     return gemm_planes_launch(true, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, split_k, workspace,
                               workspace_bytes, stream);
+}
+
+int renet_maxabs_blocks(int rows, int cols, int ld) {
+    if (rows <= 0 || cols <= 0) return 1;
+    const size_t total = (size_t)rows * cols;
+    if (ld == cols && (total & 3) == 0) return (int)max((size_t)1, min((size_t)256, total / 4096));
+    return min(rows, 256);
+}
+
+int renet_maxabs_partials(const float* x, int rows, int cols, int ld, float* part, void* stream) {
+    if (rows < 0 || cols < 0 || ld < cols || !part) return RENET_ERR_BADARG;
+    if (rows == 0 || cols == 0) {
+        hipError_t e = hipMemsetAsync(part, 0, sizeof(float), (hipStream_t)stream);
+        return e == hipSuccess ? RENET_OK : (int)e;
+    }
+    const int blocks = renet_maxabs_blocks(rows, cols, ld);
+    const bool flat = ld == cols && (((size_t)rows * cols) & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (flat) RENET_LAUNCH(maxabs_partials_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, rows, cols,
+                           (size_t)ld, part);
+    else RENET_LAUNCH(maxabs_partials_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, rows, cols,
+                      (size_t)ld, part);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_gemm_f32_h3(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                      int ldb, float beta, float* C, int ldc, const float* bias, int split_k, float* workspace,
+                      size_t workspace_bytes, const float* maxA, int nA, const float* maxB, int nB, void* stream) {
+    if (M < 0 || N < 0 || K < 1 || lda <= 0 || ldb <= 0 || ldc < N) return RENET_ERR_BADARG;
+    if (!maxA || !maxB || nA < 1 || nB < 1 || nA > 256 || nB > 256) return RENET_ERR_BADARG;
+    if (M == 0 || N == 0) return RENET_OK;
+    if (split_k < 1) split_k = 1;
+    const int kt_total = (K + BK - 1) / BK;
+    if (split_k > kt_total) split_k = max(kt_total, 1);
+    if (split_k > 1 && workspace_bytes < renet_gemm_workspace(M, N, split_k)) return RENET_ERR_WORKSPACE;
+    // tall activation x small weight: the weight-resident bf16x6 kernel (same accuracy class, no scales needed)
+    if (split_k == 1 && skinny_enabled() && renet_gemm_skinny_eligible(ta, M, N, K, A, lda, B, ldb, tb))
+        return renet_gemm_skinny_launch(tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, stream);
+    H3Args h;
+    SplitArgs& g = h.g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha; g.beta = beta;
+    g.split_k = split_k;
+    g.k_tiles_per_split = max(1, (kt_total + split_k - 1) / split_k);
+    g.partial = workspace;
+    g.xcd_order = tile_order();
+    h.maxA = maxA; h.maxB = maxB; h.nA = nA; h.nB = nB;
+    hipStream_t st = (hipStream_t)stream;
+    const int nbx = (N + BN - 1) / BN;
+    if (use_tall_h3(M, nbx, split_k)) {
+        dim3 grid(nbx, (M + 255) / 256, split_k);
+        if (!ta && !tb) RENET_LAUNCH((gemm_h3_kernel<false, false, true>), grid, dim3(512), 0, st, h);
+        else if (!ta && tb) RENET_LAUNCH((gemm_h3_kernel<false, true, true>), grid, dim3(512), 0, st, h);
+        else if (ta && !tb) RENET_LAUNCH((gemm_h3_kernel<true, false, true>), grid, dim3(512), 0, st, h);
+        else RENET_LAUNCH((gemm_h3_kernel<true, true, true>), grid, dim3(512), 0, st, h);
+    } else {
+        dim3 grid(nbx, (M + BM - 1) / BM, split_k);
+        if (!ta && !tb) RENET_LAUNCH((gemm_h3_kernel<false, false, false>), grid, dim3(256), 0, st, h);
+        else if (!ta && tb) RENET_LAUNCH((gemm_h3_kernel<false, true, false>), grid, dim3(256), 0, st, h);
+        else if (ta && !tb) RENET_LAUNCH((gemm_h3_kernel<true, false, false>), grid, dim3(256), 0, st, h);
+        else RENET_LAUNCH((gemm_h3_kernel<true, true, false>), grid, dim3(256), 0, st, h);
+    }
+    RENET_LAUNCH_CHECK();
+    if (split_k > 1) {
+        const size_t total = (size_t)M * N;
+        if (total <= (size_t)256 * 1024 && split_k >= 8) {
+            RENET_LAUNCH(split_reduce4_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, workspace,
+                               split_k, M, N, alpha, beta, bias, C, ldc);
+        } else {
+            int blocks = (int)min((size_t)2048, (total + 255) / 256);
+            RENET_LAUNCH(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, split_k, M, N, alpha,
+                               beta, bias, C, ldc);
+        }
+        RENET_LAUNCH_CHECK();
+    }
+    return RENET_OK;
 }
 
 size_t renet_bf16_bytes(int R, int C) {

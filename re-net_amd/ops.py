@@ -178,7 +178,7 @@ class RGCNLayerFn(Function):
         K.rgcn_gather_items(h, g, weight, shift, False, out, drop_p, seed, relu, out, use_norm=True, pruned=pruned,
                             w16=K.gather_weight_bf16(weight))
         ctx.g, ctx.relu, ctx.drop_p, ctx.seed, ctx.shift, ctx.n_out = g, relu, drop_p, seed, shift, n_out
-        ctx.h_op = h_op if isinstance(h_op, K.BF16Mat) else None
+        ctx.h_op = h_op if K.is_handle(h_op) else None
         ctx.save_for_backward(h, weight, loop_weight, out)
         return out
 
@@ -392,7 +392,7 @@ class MultiGRUFn(Function):
         for k in range(0, n, 2):
             gis[k] = K.gemm(x_ops[k], w_ihs[k], tb=True, bias=b_ihs[k])
         sd.join()
-        ctx.x_ops = x_ops if any(isinstance(x, K.BF16Mat) for x in x_ops) else None
+        ctx.x_ops = x_ops if any(K.is_handle(x) for x in x_ops) else None
         hs, svs = K.gru_fwd_layouts(gis, step_offs, hdim, w_hhs, b_hhs, total_rows)     # rows past nnz are zero
         ctx.step_offs, ctx.hdim, ctx.n = step_offs, hdim, n
         ctx.nnz = [int(o[1] - o[0]) if len(o) > 1 else 0 for o in step_offs]
@@ -420,10 +420,14 @@ class MultiGRUFn(Function):
                 K.gemm(dgi_op, x_op, ta=True, out=t_ih, beta=1.0)
             else:
                 dwi = K.gemm(dgi_op, x_op, ta=True)
+            # |dGh| <= |dGi| elementwise (equal but for the n gate's factor r in (0, 1)) and |h| <= 1: both operand
+            # bounds of the f16x3 GEMM are known without a pass over the tensors
+            dgh_op = K.operand_like(dgh, dgi_op)
+            hp_op = K.operand(s_[:, 4 * hdim:], bound=K.const_bound(1.0, s_.device))
             if t_hh is not None:
-                K.gemm(dgh, s_[:, 4 * hdim:], ta=True, out=t_hh, beta=1.0)
+                K.gemm(dgh_op, hp_op, ta=True, out=t_hh, beta=1.0)
             else:
-                dwh = K.gemm(dgh, s_[:, 4 * hdim:], ta=True)
+                dwh = K.gemm(dgh_op, hp_op, ta=True)
             if t_bi is not None:
                 K.colsum(dgi, out=t_bi, beta=1.0)
             else:
@@ -490,14 +494,24 @@ def _head_forward(a, ia, hmid, c, ic, weight, bias, target, drop_p, seed, grad_s
         logits = feat.new_empty(0)
     else:
         row_loss = K.softmax_ce(logits, target, grad_scale, need_grad, row_loss=row_loss)
-    return row_loss, feat, logits, dl_bf16, (feat_op if isinstance(feat_op, K.BF16Mat) else None)
+    return row_loss, feat, logits, dl_bf16, (feat_op if K.is_handle(feat_op) else None)
 
 
-def _head_backward(dlogits, feat, feat_op, weight, t_w, t_b, bias_side=None):
+def _scale_ce_gradient(dlogits, g, grad_scale):
+    """dlogits *= g (the upstream scalar, device memory) -> the bound |g| * grad_scale on max |dlogits| as a 1-element
+    device tensor in f16x3 mode (those GEMMs scale their operands by a bound on the tensor's magnitude; |softmax -
+    onehot| <= 1, so this one is known without a pass over the 188 MB), else None."""
+    if K.GEMM_MODE == 'f16x3' and not isinstance(dlogits, K.BF16Mat) and dlogits.is_cuda:
+        return K.scale_by_device_scalar(dlogits, g, bound_in=float(grad_scale))
+    K.scale_by_device_scalar(dlogits, g)
+    return None
+
+
+def _head_backward(dlogits, feat, feat_op, weight, t_w, t_b, bias_side=None, bound=None):
     """The three gradient products of one score head from its (already scaled) CE gradient -> (dfeat, d_w, d_b).
     bias_side: a _Side whose stream takes the bias column sum (bandwidth bound, next to the matrix-bound GEMMs that
-    read the same gradient)."""
-    dl_op = K.operand(dlogits)                                       # consumed by dfeat and dW
+    read the same gradient).  bound: see _scale_ce_gradient."""
+    dl_op = K.operand(dlogits, bound=bound)                          # consumed by dfeat and dW
     f_op = feat_op if feat_op is not None else feat
 
     def bias_grad():
@@ -533,8 +547,9 @@ class HeadCEFn(Function):
         need_grad = any(ctx.needs_input_grad)
         # loss_scale (2 for the merged batch of both passes: sum of two B-row means = 2 x the 2B-row mean) goes into
         # the gradient the CE kernel writes, so that the upstream scalar stays 1 and the 188 MB are not rescaled
+        ctx.grad_scale = float(loss_scale) / b
         row_loss, feat, logits, ctx.dl_bf16, feat_op = _head_forward(a, ia, hmid, c, ic, weight, bias, target, drop_p,
-                                                                     seed, float(loss_scale) / b, need_grad)
+                                                                     seed, ctx.grad_scale, need_grad)
         ctx.meta = (d, 3 if c is not None else 2, drop_p, seed, plan_a, plan_c, a.shape,
                     c.shape if c is not None else None)
         if need_grad:
@@ -556,9 +571,9 @@ class HeadCEFn(Function):
         # the relation head) into it ONCE, from device memory, instead of scaling three results
         if ctx.dl_bf16 is not None:
             dlogits = ctx.dl_bf16
-        K.scale_by_device_scalar(dlogits, g)
+        bound = _scale_ce_gradient(dlogits, g, ctx.grad_scale)
         sd = _Side(feat.device)
-        dfeat, d_w, d_b = _head_backward(dlogits, feat, ctx.feat_op, weight, t_w, t_b, bias_side=sd)
+        dfeat, d_w, d_b = _head_backward(dlogits, feat, ctx.feat_op, weight, t_w, t_b, bias_side=sd, bound=bound)
         sd.join()
         if t_w is not None and t_b is not None:
             grad_done(ctx.srcs[2])
@@ -623,6 +638,7 @@ class DualHeadCEFn(Function):
             _, feat2, lg2, dl2, fop2 = head2()
         sd.join()
         ctx.meta = (d, drop_p, seed1, seed2, plan_a, plan_c, a.shape, c.shape)
+        ctx.grad_scales = (s1, s2)
         if need_grad:
             ctx.save_for_backward(feat1, lg1, w1, feat2, lg2, w2)
             ctx.consumed = False
@@ -641,13 +657,13 @@ class DualHeadCEFn(Function):
         b1_, fop1, b2_, fop2 = ctx.bf16
         dl1 = b1_ if b1_ is not None else dl1
         dl2 = b2_ if b2_ is not None else dl2
-        K.scale_by_device_scalar(dl1, g)                     # upstream scalar (1 in RE-Net's training step)
+        bound1 = _scale_ce_gradient(dl1, g, ctx.grad_scales[0])      # upstream scalar (1 in RE-Net's training step)
         sd = _Side(feat1.device)
         with sd():
-            K.scale_by_device_scalar(dl2, g)
-            dfeat2, d_w2, d_b2 = _head_backward(dl2, feat2, fop2, w2, t_w2, t_b2)
+            bound2 = _scale_ce_gradient(dl2, g, ctx.grad_scales[1])
+            dfeat2, d_w2, d_b2 = _head_backward(dl2, feat2, fop2, w2, t_w2, t_b2, bound=bound2)
             da2, dh2, _ = K.concat3_bwd(dfeat2, d, 2, drop_p, seed2)
-        dfeat1, d_w1, d_b1 = _head_backward(dl1, feat1, fop1, w1, t_w1, t_b1, bias_side=sd)
+        dfeat1, d_w1, d_b1 = _head_backward(dl1, feat1, fop1, w1, t_w1, t_b1, bias_side=sd, bound=bound1)
         da1, dh1, dc1 = K.concat3_bwd(dfeat1, d, 3, drop_p, seed1)
         sd.join()
         if t_w1 is not None and t_b1 is not None:

@@ -58,6 +58,11 @@ _SIGNATURES = {
     'renet_gemm_bf16': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                 c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'renet_planes_bytes': (c_size_t, [c_int, c_int]),
+    'renet_maxabs_blocks': (c_int, [c_int, c_int, c_int]),
+    'renet_maxabs_partials': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'renet_gemm_f32_h3': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
+                                  c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_int,
+                                  c_void_p, c_int, c_void_p]),
     'renet_pack_planes': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'renet_gemm_planes': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                   c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
@@ -78,6 +83,7 @@ _SIGNATURES = {
     'renet_colsum_workspace': (c_size_t, [c_int, c_int]),
     'renet_colsum': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     'renet_scale_by_device_scalar': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    'renet_scale_by_device_scalar_bound': (c_int, [c_void_p, c_size_t, c_void_p, c_float, c_void_p, c_void_p]),
     'renet_seq_assemble_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_void_p,
                                        c_void_p]),
@@ -461,7 +467,9 @@ def auto_split_k(m, n, k):
 # 'f32'    : v_mfma_f32_32x32x2_f32, exact fp32 products (gemm.hip)
 # 'bf16x6' : fp32 operands split into 3 bf16 terms, 6 term products on v_mfma_f32_32x32x16_bf16 with fp32
 #            accumulation (gemm_split.hip): fp32-class accuracy at 2.67x the matrix-pipe rate
-GEMM_MODE = os.environ.get('RENET_GEMM', 'bf16x6')      # RENET_GEMM=f32 selects the exact-fp32 MFMA kernel
+# 'f16x3'  : fp32 operands, scaled per TENSOR by a power of two, split into 2 binary16 terms, 3 term products on
+#            v_mfma_f32_32x32x16_f16 (gemm_h3.h): fp32-class accuracy with half the matrix instructions of bf16x6
+GEMM_MODE = os.environ.get('RENET_GEMM', 'f16x3')       # RENET_GEMM=bf16x6 | f32 select the other fp32-class kernels
 
 
 class BF16Mat(object):
@@ -513,6 +521,7 @@ def unregister_weights(tensors):
     for t in tensors:
         _weight_ptrs.pop(t.data_ptr(), None)
         _weight_cache.pop(t.data_ptr(), None)
+        _weight_max.pop(t.data_ptr(), None)
 
 
 def weights_changed():
@@ -529,13 +538,110 @@ def _as_bf16(x):
             x.shape[0] <= shp[0] and x.shape[1] <= shp[1]:
         # a registered weight, or a leading row / column block of it (W_ih[:, :live]): one cached copy serves both
         ent = _weight_cache.get(ptr)
-        if ent is None or ent[0] != _weight_epoch[0]:
+        stamp = (_weight_epoch[0], x._version)      # in-place torch writes (load_state_dict) bump _version
+        if ent is None or ent[0] != stamp:
             full = torch.as_strided(x, shp, (shp[1], 1))
-            ent = (_weight_epoch[0], pack_bf16(full))
+            ent = (stamp, pack_bf16(full))
             _weight_cache[ptr] = ent
         return ent[1], x.shape[0], x.shape[1]
     m = pack_bf16(x)
     return m, m.R, m.C
+
+
+class F32Op(object):
+    """An fp32 GEMM operand together with the bound on its largest magnitude that the f16x3 GEMM scales it by:
+    `part` holds n <= 256 device floats whose maximum bounds max |t| (renet_maxabs_partials, or a known bound)."""
+    __slots__ = ('t', 'part', 'n')
+
+    def __init__(self, t, part=None, n=0):
+        self.t, self.part, self.n = t, part, n
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    def bound(self):
+        """(part, n), measured on first use: GEMMs that go to the weight-resident kernel never ask."""
+        if self.part is None:
+            self.part, self.n = _weight_or_measured_max(self.t)
+        return self.part, self.n
+
+
+def is_handle(x):
+    """x is an operand handle made by operand() (to be kept for the GEMMs of the backward pass), not a plain tensor."""
+    return isinstance(x, (BF16Mat, F32Op))
+
+
+def maxabs_partials(x):
+    """-> (part, n): n <= 256 partial maxima of |x| for a 2-D fp32 matrix (row-strided views allowed)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
+        raise RenetHipError('maxabs_partials needs a 2-D float32 device tensor with unit inner stride')
+    rows, cols = x.shape
+    n = lib().renet_maxabs_blocks(rows, cols, _ld(x))
+    part = torch.empty(n, device=x.device, dtype=torch.float32)
+    t0 = _timer.begin() if _timer is not None else None
+    _check(lib().renet_maxabs_partials(x.data_ptr(), rows, cols, _ld(x), part.data_ptr(), _stream()),
+           'maxabs_partials')
+    if t0 is not None:
+        _timer.end('maxabs', t0, nbytes=float(rows * cols * 4))
+    return part, n
+
+
+_weight_max = {}               # data_ptr -> (epoch, part, n) of a registered weight
+
+
+def _weight_or_measured_max(x):
+    """A registered weight's maxima are cached until the next optimizer step (a leading row / column block of the
+    weight is bounded by the whole weight's); anything else is measured."""
+    ptr = x.data_ptr()
+    shp = _weight_ptrs.get(ptr)
+    if shp is not None and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) == shp[1] and \
+            x.shape[0] <= shp[0] and x.shape[1] <= shp[1]:
+        ent = _weight_max.get(ptr)
+        stamp = (_weight_epoch[0], x._version)      # in-place torch writes (load_state_dict) bump _version
+        if ent is None or ent[0] != stamp:
+            part, n = maxabs_partials(torch.as_strided(x, shp, (shp[1], 1)))
+            ent = (stamp, part, n)
+            _weight_max[ptr] = ent
+        return ent[1], ent[2]
+    return maxabs_partials(x)
+
+
+def _f32op(x, bound=None):
+    """F32Op of tensor x.  bound: a 1-element device tensor known to bound max |x| (else measured lazily)."""
+    if isinstance(x, F32Op):
+        return x
+    return F32Op(x, bound, 1) if bound is not None else F32Op(x)
+
+
+_const_bounds = {}
+
+
+def const_bound(value, device):
+    """1-element device tensor holding a known bound (GRU states: 1)."""
+    key = (float(value), str(device))
+    t = _const_bounds.get(key)
+    if t is None:
+        t = torch.full((1,), float(value), device=device, dtype=torch.float32)
+        _const_bounds[key] = t
+    return t
+
+
+def operand_like(x, other):
+    """Operand handle for x that reuses the magnitude bound of handle `other` (the caller knows |x| <= max |other|
+    elementwise: the GRU's dGh against dGi); plain x outside f16x3 mode."""
+    if GEMM_MODE != 'f16x3' or not isinstance(other, F32Op):
+        return operand(x)
+    part, n = other.bound()
+    return F32Op(x, part, n)
+
+
+def _skinny_shape(ta, m, n, k, a, b, split_k):
+    """Mirror of renet_gemm_skinny_eligible (gemm_skinny.hip): these shapes run the weight-resident bf16x6 kernel in
+    every fp32-class mode and need no magnitude bounds."""
+    return (not ta and split_k == 1 and n <= 256 and 16 <= k <= 208 and k % 4 == 0 and m >= 256 and
+            a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and
+            os.environ.get('RENET_GEMM_SKINNY', '1') != '0')
 
 
 _lazy_shells = {}          # (data_ptr, shape) of an uninitialised fp32 shell -> the BF16Mat it stands for
@@ -552,10 +658,11 @@ def lazy_shell(mat, device):
     return x
 
 
-def operand(x):
+def operand(x, bound=None):
     """GEMM operand for activation tensor x: in bf16-storage mode its bf16 copy (packed ONCE, to be handed to every
-    GEMM that consumes x), otherwise x itself."""
-    if isinstance(x, BF16Mat):
+    GEMM that consumes x), in f16x3 mode x with the bound on its magnitude (ONE pass over x, or `bound`: a 1-element
+    device tensor the producer knows to bound max |x|), otherwise x itself."""
+    if isinstance(x, (BF16Mat, F32Op)):
         return x
     lazy = getattr(x, '_renet_bf16', None)          # a producer already wrote the bf16 form (ops.SeqAssembleFn)
     if lazy is None:
@@ -568,6 +675,8 @@ def operand(x):
         return lazy
     if GEMM_MODE == 'bf16s':
         return pack_bf16(x)
+    if GEMM_MODE == 'f16x3' and x.is_cuda and x.dim() == 2:
+        return _f32op(x, bound)
     return x
 
 
@@ -613,6 +722,12 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, spl
     split_k=None picks the deterministic split-K factor automatically."""
     if (mode or GEMM_MODE) == 'bf16s' or isinstance(a, BF16Mat) or isinstance(b, BF16Mat):
         return gemm_bf16s(a, b, ta=ta, tb=tb, out=out, bias=bias, alpha=alpha, beta=beta, split_k=split_k)
+    md = mode or GEMM_MODE
+    opa, opb = a, b
+    if isinstance(a, F32Op):
+        a = a.t
+    if isinstance(b, F32Op):
+        b = b.t
     if not (a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32):
         raise RenetHipError('gemm operands must be float32 device tensors')
     m, k = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
@@ -630,12 +745,22 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, spl
         ws_bytes = lib().renet_gemm_workspace(m, n, split_k)
         ws = torch.empty(ws_bytes // 4, device=a.device, dtype=torch.float32)
         ws_ptr = ws.data_ptr()
+    if md == 'f16x3' and _skinny_shape(ta, m, n, k, a, b, split_k):
+        md = 'bf16x6'
+    if md == 'f16x3':
+        (pa, na), (pb, nb) = _f32op(opa).bound(), _f32op(opb).bound()     # (measured outside the GEMM's timer)
     t0 = _timer.begin() if _timer is not None else None
-    md = mode or GEMM_MODE
-    fn = lib().renet_gemm_f32_split if md == 'bf16x6' else lib().renet_gemm_bf16 if md == 'bf16' else lib().renet_gemm_f32
-    _check(fn(int(ta), int(tb), m, n, k, float(alpha), a.data_ptr(), _ld(a), b.data_ptr(),
-              _ld(b), float(beta), out.data_ptr(), _ld(out), _f32(bias), split_k, ws_ptr,
-              ws_bytes, _stream()), 'gemm_f32')
+    if md == 'f16x3':
+        _check(lib().renet_gemm_f32_h3(int(ta), int(tb), m, n, k, float(alpha), a.data_ptr(), _ld(a), b.data_ptr(),
+                                       _ld(b), float(beta), out.data_ptr(), _ld(out), _f32(bias), split_k, ws_ptr,
+                                       ws_bytes, pa.data_ptr(), na, pb.data_ptr(), nb, _stream()),
+               'gemm_f32_h3')
+    else:
+        fn = lib().renet_gemm_f32_split if md == 'bf16x6' else lib().renet_gemm_bf16 if md == 'bf16' else \
+            lib().renet_gemm_f32
+        _check(fn(int(ta), int(tb), m, n, k, float(alpha), a.data_ptr(), _ld(a), b.data_ptr(),
+                  _ld(b), float(beta), out.data_ptr(), _ld(out), _f32(bias), split_k, ws_ptr,
+                  ws_bytes, _stream()), 'gemm_f32')
     if t0 is not None:
         _timer.end('gemm_f32', t0, flops=2.0 * m * n * k, tag=(int(ta), int(tb), m, n, k, split_k))
     return out
@@ -717,8 +842,17 @@ def colsum(x, out=None, beta=0.0):
     return out
 
 
-def scale_by_device_scalar(x, g):
-    """x *= g in place, g a 0-dim / 1-element DEVICE tensor (no host sync; g == 1 leaves x untouched)."""
+def scale_by_device_scalar(x, g, bound_in=None):
+    """x *= g in place, g a 0-dim / 1-element DEVICE tensor (no host sync; g == 1 leaves x untouched).
+    bound_in: a host float bounding max |x| before the scaling -> returns the 1-element device tensor |g| * bound_in
+    (fp32 tensors only), the operand bound of the f16x3 GEMMs that consume x; otherwise returns x."""
+    if bound_in is not None and not isinstance(x, BF16Mat):
+        if not x.is_contiguous():
+            raise RenetHipError('scale_by_device_scalar needs a contiguous tensor')
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
+        _check(lib().renet_scale_by_device_scalar_bound(_f32(x), x.numel(), _f32(g), float(bound_in), out.data_ptr(),
+                                                        _stream()), 'scale_by_device_scalar_bound')
+        return out
     if isinstance(x, BF16Mat):
         _check(lib().renet_scale_bf16_by_device_scalar(x.p.data_ptr(), x.p.numel(), _f32(g), _stream()),
                'scale_bf16_by_device_scalar')

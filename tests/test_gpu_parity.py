@@ -35,7 +35,7 @@ def _to(x, dev):
 @pytest.mark.parametrize('m,n,k', [(1, 1, 1), (7, 5, 3), (128, 128, 32), (200, 200, 200), (257, 130, 71),
                                    (1024, 777, 600), (64, 600, 200), (333, 200, 4)])
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
-@pytest.mark.parametrize('mode', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('mode', ['f32', 'bf16x6', 'f16x3'])
 def test_gemm_matches_fp64(dev, m, n, k, ta, tb, mode):
     import renet_hip as K
     rng = np.random.RandomState(m * 131 + n * 17 + k + ta * 2 + tb)
@@ -82,6 +82,72 @@ def test_gemm_both_k_loop_structures(dev, kernel):
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
 
 
+@pytest.mark.parametrize('tall', ['0', '1'])
+def test_f16x3_gemm_every_tile_and_edge(dev, tall):
+    """renet_gemm_f32_h3 with the 128-row and the 256-row tile forced (RENET_H3_TALL) over ragged shapes, one k-tile,
+    many, split-K (child process: the switch is read once per process)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RENET_H3_TALL='1' if tall == '1' else '0', RENET_GEMM_SKINNY='0')
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 're-net_amd')
+    r = subprocess.run([sys.executable, '-c', _GEMM_KERNEL_CHECK.replace("mode='bf16x6'", "mode='f16x3'"), pkg],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
+
+
+@pytest.mark.parametrize('scale_a,scale_b', [(1.0, 1.0), (3e-9, 7e4), (5e7, 2e-6), (1e-20, 1e-12), (1e15, 1e10)])
+def test_f16x3_gemm_is_fp32_class_at_any_tensor_magnitude(dev, scale_a, scale_b):
+    """The f16x3 split scales each operand TENSOR by a power of two: its error against fp64, relative to the result's
+    magnitude, must not depend on the operands' magnitudes and must stay in the class of the exact-fp32 kernel
+    (v_mfma_f32_32x32x2_f32, fp32 products and accumulation).  Rows / columns spanning 2^20 in magnitude included."""
+    import renet_hip as K
+    rng = np.random.RandomState(9)
+    m, n, k = 700, 520, 1500
+    a = rng.standard_normal((m, k)) * np.exp2(rng.uniform(-20, 0, (m, 1)))        # per-row dynamic range
+    b = rng.standard_normal((n, k)) * np.exp2(rng.uniform(-20, 0, (1, k)))        # per-k dynamic range
+    a, b = (a * scale_a).astype(np.float32), (b * scale_b).astype(np.float32)
+    ref = a.astype(np.float64) @ b.astype(np.float64).T
+    # per-element error in units of the fp32-rounding bound of that dot product: sum_k |a_ik b_jk| 2^-24
+    unit = (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64).T) * 2.0 ** -24
+    errs = {}
+    for mode in ('f32', 'bf16x6', 'f16x3'):
+        out = K.gemm(_to(a, dev), _to(b, dev), tb=True, mode=mode).cpu().numpy().astype(np.float64)
+        assert np.isfinite(out).all(), mode
+        errs[mode] = float((np.abs(out - ref) / unit).max())
+    assert errs['f16x3'] <= 4.0, errs                       # a handful of fp32 roundings of the largest term
+    assert errs['f16x3'] <= 3.0 * max(errs['f32'], errs['bf16x6'], 0.5), errs
+
+
+def test_f16x3_gemm_bounds_and_special_values(dev):
+    """Operand handles: a bound larger than the true maximum (by 2^10) only costs binades; zero operands; NaN flows
+    through; a registered weight's maxima are cached and refreshed when the weight changes."""
+    import renet_hip as K
+    rng = np.random.RandomState(3)
+    a = rng.uniform(-1, 1, (300, 96)).astype(np.float32)
+    b = rng.uniform(-1, 1, (96, 200)).astype(np.float32)
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    ta_, tb_ = _to(a, dev), _to(b, dev)
+    loose = K.F32Op(ta_, torch.full((1,), 1024.0, device=dev), 1)
+    out = K.gemm(loose, tb_, mode='f16x3')
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * 96 ** 0.5)
+    z = K.gemm(torch.zeros_like(ta_), tb_, mode='f16x3')
+    assert float(z.abs().max()) == 0.0
+    an = ta_.clone()
+    an[5, 7] = float('nan')
+    o = K.gemm(an, tb_, mode='f16x3')
+    assert bool(torch.isnan(o[5]).all()) and not bool(torch.isnan(o[6]).any())
+    w = tb_.clone()
+    K.register_weights([w])
+    try:
+        o1 = K.gemm(ta_, w, mode='f16x3')
+        w.mul_(4096.0)                                       # in-place torch write: version stamp changes
+        o2 = K.gemm(ta_, w, mode='f16x3')
+        np.testing.assert_allclose(o2.cpu().numpy(), 4096.0 * ref, rtol=1e-5, atol=4096 * 1e-5 * 96 ** 0.5)
+        np.testing.assert_allclose(o1.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * 96 ** 0.5)
+    finally:
+        K.unregister_weights([w])
+
+
 @pytest.mark.parametrize('m,n,k', [(23033, 200, 200), (14001, 200, 200), (257, 256, 208), (300, 64, 16), (4097, 100, 100),
                                    (1000, 200, 112), (999, 250, 204), (2048, 256, 128)])
 @pytest.mark.parametrize('tb', [0, 1])
@@ -121,7 +187,7 @@ def test_gemm_splitk_beta_and_strided_views(dev):
     c0 = rng.uniform(-1, 1, (96, 100)).astype(np.float32)
     ref = 0.5 * a.T.astype(np.float64) @ big[:, 400:].astype(np.float64) + 2.0 * c0
     for sk in (1, 4, 37):
-        for mode in ('f32', 'bf16x6'):
+        for mode in ('f32', 'bf16x6', 'f16x3'):
             out = _to(c0, dev).clone()
             K.gemm(_to(a, dev), b_view, ta=True, out=out, alpha=0.5, beta=2.0, split_k=sk, mode=mode)
             np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=2e-4)
