@@ -1412,15 +1412,22 @@ bool use_tall(int M, int nbx, int split_k) {
     return (long)nbx * ((M + BMT - 1) / BMT) * split_k >= min_tiles;
 }
 
-// f16x3 kernels: the 256-row tile from RENET_H3_TALL tiles on (default 1000, as for the bf16x6 kernels; 0 disables)
-bool use_tall_h3(int M, int nbx, int split_k) {
+// f16x3 kernels: the 256-row tile from RENET_H3_TALL tiles on (default 1000, as for the bf16x6 kernels; 0 disables).
+// Measured on the step's shapes (tools/sessions/r03_s20.sh): the tall tile wins for K-contiguous A from 200 tiles on
+// when the k range is split (dfeat 2048 x 600 x 23033 / 6: 286 -> 259 us) and loses for K-strided A (dW 23033 x 600 x
+// 2048: 293 -> 319 us; the split-K weight gradients 100 -> 178 us).
+bool use_tall_h3(int ta, int M, int nbx, int split_k) {
     static int min_tiles = -1;
+    static bool forced = false;
     if (min_tiles < 0) {
         const char* e = getenv("RENET_H3_TALL");
+        forced = e != nullptr;
         min_tiles = e ? atoi(e) : 1000;
         if (e && min_tiles == 0) min_tiles = 0x7fffffff;
     }
-    return (long)nbx * ((M + 255) / 256) * split_k >= min_tiles;
+    const long tiles = (long)nbx * ((M + 255) / 256) * split_k;
+    if (forced) return tiles >= min_tiles;
+    return !ta && (tiles >= min_tiles || (split_k >= 4 && tiles >= 200));
 }
 
 // Which k-loop: the fused kernel (one workgroup per CU, 122.9 KB LDS) when the whole grid fits in ONE round of
@@ -1606,13 +1613,16 @@ int renet_gemm_f32_h3(int ta, int tb, int M, int N, int K, float alpha, const fl
     if (M < 0 || N < 0 || K < 1 || lda <= 0 || ldb <= 0 || ldc < N) return RENET_ERR_BADARG;
     if (!maxA || !maxB || nA < 1 || nB < 1 || nA > 256 || nB > 256) return RENET_ERR_BADARG;
     if (M == 0 || N == 0) return RENET_OK;
+    // the f16x3 loaders address with 32-bit byte offsets; operands of 4 GiB and more and the weight-resident shapes run
+    // the bf16x6 kernels (same accuracy class, no bounds needed)
+    const bool small_ok = (size_t)(ta ? K : M) * lda < ((size_t)1 << 30) && (size_t)(tb ? N : K) * ldb < ((size_t)1 << 30);
+    if (!small_ok || ((split_k <= 1) && skinny_enabled() && renet_gemm_skinny_eligible(ta, M, N, K, A, lda, B, ldb, tb)))
+        return gemm_planes_launch(false, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, split_k, workspace,
+                                  workspace_bytes, stream);
     if (split_k < 1) split_k = 1;
     const int kt_total = (K + BK - 1) / BK;
     if (split_k > kt_total) split_k = max(kt_total, 1);
     if (split_k > 1 && workspace_bytes < renet_gemm_workspace(M, N, split_k)) return RENET_ERR_WORKSPACE;
-    // tall activation x small weight: the weight-resident bf16x6 kernel (same accuracy class, no scales needed)
-    if (split_k == 1 && skinny_enabled() && renet_gemm_skinny_eligible(ta, M, N, K, A, lda, B, ldb, tb))
-        return renet_gemm_skinny_launch(tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, stream);
     H3Args h;
     SplitArgs& g = h.g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
@@ -1624,19 +1634,21 @@ int renet_gemm_f32_h3(int ta, int tb, int M, int N, int K, float alpha, const fl
     h.maxA = maxA; h.maxB = maxB; h.nA = nA; h.nB = nB;
     hipStream_t st = (hipStream_t)stream;
     const int nbx = (N + BN - 1) / BN;
-    if (use_tall_h3(M, nbx, split_k)) {
+#define RENET_H3_LAUNCH(TALLV, THR)                                                                    \
+    do {                                                                                               \
+        if (!ta && !tb) RENET_LAUNCH((gemm_h3_kernel<false, false, TALLV>), grid, dim3(THR), 0, st, h); \
+        else if (!ta && tb) RENET_LAUNCH((gemm_h3_kernel<false, true, TALLV>), grid, dim3(THR), 0, st, h); \
+        else if (ta && !tb) RENET_LAUNCH((gemm_h3_kernel<true, false, TALLV>), grid, dim3(THR), 0, st, h); \
+        else RENET_LAUNCH((gemm_h3_kernel<true, true, TALLV>), grid, dim3(THR), 0, st, h);              \
+    } while (0)
+    if (use_tall_h3(ta, M, nbx, split_k)) {
         dim3 grid(nbx, (M + 255) / 256, split_k);
-        if (!ta && !tb) RENET_LAUNCH((gemm_h3_kernel<false, false, true>), grid, dim3(512), 0, st, h);
-        else if (!ta && tb) RENET_LAUNCH((gemm_h3_kernel<false, true, true>), grid, dim3(512), 0, st, h);
-        else if (ta && !tb) RENET_LAUNCH((gemm_h3_kernel<true, false, true>), grid, dim3(512), 0, st, h);
-        else RENET_LAUNCH((gemm_h3_kernel<true, true, true>), grid, dim3(512), 0, st, h);
+        RENET_H3_LAUNCH(true, 512);
     } else {
         dim3 grid(nbx, (M + BM - 1) / BM, split_k);
-        if (!ta && !tb) RENET_LAUNCH((gemm_h3_kernel<false, false, false>), grid, dim3(256), 0, st, h);
-        else if (!ta && tb) RENET_LAUNCH((gemm_h3_kernel<false, true, false>), grid, dim3(256), 0, st, h);
-        else if (ta && !tb) RENET_LAUNCH((gemm_h3_kernel<true, false, false>), grid, dim3(256), 0, st, h);
-        else RENET_LAUNCH((gemm_h3_kernel<true, true, false>), grid, dim3(256), 0, st, h);
+        RENET_H3_LAUNCH(false, 256);
     }
+#undef RENET_H3_LAUNCH
     RENET_LAUNCH_CHECK();
     if (split_k > 1) {
         const size_t total = (size_t)M * N;

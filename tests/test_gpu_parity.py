@@ -137,9 +137,15 @@ def test_f16x3_gemm_bounds_and_special_values(dev):
     o = K.gemm(an, tb_, mode='f16x3')
     assert bool(torch.isnan(o[5]).all()) and not bool(torch.isnan(o[6]).any())
     w = tb_.clone()
+    plain = K.gemm(ta_, w, mode='f16x3')
     K.register_weights([w])
     try:
-        o1 = K.gemm(ta_, w, mode='f16x3')
+        o1 = K.gemm(ta_, w, mode='f16x3')                    # bound from the weight cache
+        assert torch.equal(o1, plain)
+        ob = K.gemm(ta_, w[:, :130], mode='f16x3')           # a leading column block of the cached copy
+        np.testing.assert_allclose(ob.cpu().numpy(), ref[:, :130], rtol=1e-5, atol=1e-5 * 96 ** 0.5)
+        ot = K.gemm(_to(rng.uniform(-1, 1, (64, 200)).astype(np.float32), dev), w, tb=True, mode='f16x3')
+        assert ot.shape == (64, 96) and bool(torch.isfinite(ot).all())
         w.mul_(4096.0)                                       # in-place torch write: version stamp changes
         o2 = K.gemm(ta_, w, mode='f16x3')
         np.testing.assert_allclose(o2.cpu().numpy(), 4096.0 * ref, rtol=1e-5, atol=4096 * 1e-5 * 96 ** 0.5)

@@ -19,7 +19,7 @@ BLOCKS, STEPS = 64, 320
 
 def build():
     os.makedirs(OUT, exist_ok=True)
-    src = [os.path.join(ROOT, 're-net_amd', 'csrc', f) for f in ('gemm_split.hip', 'gemm.hip')]
+    src = [os.path.join(ROOT, 're-net_amd', 'csrc', f) for f in ('gemm_split.hip', 'gemm.hip', 'gemm_skinny.hip')]
     extra = sys.argv[2:]
     cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
            '-DRENET_GEMM_TRACE', '-I' + os.path.join(ROOT, 'include')] + src + ['-o', LIB] + extra
@@ -45,9 +45,27 @@ def run():
                                                                ctypes.c_size_t, vp]
     lib.renet_gemm_trace_set.argtypes = [vp]
 
+    h3 = os.environ['RENET_GEMM_KERNEL'] == 'h3'
+    if h3:
+        nw = 8 if os.environ.get('RENET_H3_TALL') == '1' else 4
+        pa, pb = torch.zeros(256, device=dev), torch.zeros(256, device=dev)
+        lib.renet_maxabs_partials.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
+        lib.renet_maxabs_blocks.argtypes = [ctypes.c_int] * 3
+        na = lib.renet_maxabs_blocks(a.shape[0], a.shape[1], a.stride(0))
+        nb = lib.renet_maxabs_blocks(b.shape[0], b.shape[1], b.stride(0))
+        assert lib.renet_maxabs_partials(a.data_ptr(), a.shape[0], a.shape[1], a.stride(0), pa.data_ptr(), None) == 0
+        assert lib.renet_maxabs_partials(b.data_ptr(), b.shape[0], b.shape[1], b.stride(0), pb.data_ptr(), None) == 0
+        lib.renet_gemm_f32_h3.argtypes = [ctypes.c_int] * 5 + [ctypes.c_float, vp, ctypes.c_int, vp, ctypes.c_int,
+                                                                ctypes.c_float, vp, ctypes.c_int, vp, ctypes.c_int, vp,
+                                                                ctypes.c_size_t, vp, ctypes.c_int, vp, ctypes.c_int, vp]
+
     def go():
-        rc = lib.renet_gemm_f32_split(ta, tb, m, n, k, 1.0, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), 0.0,
-                                      out.data_ptr(), n, None, 1, None, 0, None)
+        if h3:
+            rc = lib.renet_gemm_f32_h3(ta, tb, m, n, k, 1.0, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), 0.0,
+                                       out.data_ptr(), n, None, 1, None, 0, pa.data_ptr(), na, pb.data_ptr(), nb, None)
+        else:
+            rc = lib.renet_gemm_f32_split(ta, tb, m, n, k, 1.0, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
+                                          0.0, out.data_ptr(), n, None, 1, None, 0, None)
         assert rc == 0, rc
     go()
     torch.cuda.synchronize()
@@ -75,6 +93,16 @@ def run():
         print('convert  work %7.0f cyc   barrier wait %7.0f' % ((s1 - s0)[sl].mean(), (s2 - s1)[sl].mean()))
         print('mfma     work %7.0f cyc   barrier wait %7.0f' % ((s3 - s2)[sl].mean(), (nxt - s3)[sl].mean()))
         print('mean k-tile %7.0f cyc' % ((s0[:, :, nkt - 5] - s0[:, :, 5]) / float(nkt - 10)).mean())
+        if h3 and os.environ.get('RENET_FINE'):
+            f = t[:, :nw, 300, :]
+            print('MFMA phase of the last k-tile: g0 -> g7 %6.0f   g7 -> g11 %6.0f   g11 -> g23 %6.0f cycles' % (
+                (f[..., 1] - f[..., 0]).mean(), (f[..., 2] - f[..., 1]).mean(), (f[..., 3] - f[..., 2]).mean()))
+        if h3:
+            for w in range(nw):
+                print('  wave %d: store %6.0f  wait %6.0f  mfma %6.0f  wait %6.0f' % (
+                    w, (s1 - s0)[:, w, 4:nkt - 4].mean(), (s2 - s1)[:, w, 4:nkt - 4].mean(),
+                    (s3 - s2)[:, w, 4:nkt - 4].mean(), (nxt - s3)[:, w, 4:nkt - 4].mean()))
+            return
         # co-residence: which traced workgroups share a CU (same HW_ID cu/se/xcc bits), and their phase offset
         hw = t[:, 0, STEPS - 1, 0]
         xcc = t[:, 0, STEPS - 1, 1]
