@@ -10,6 +10,7 @@ timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 300 $O/benc
 BENCH="python $R/bench.py --steps 8 --warmup 2 --cpu-steps 0 --e2e-steps 0 --f32-steps 0 --enc-steps 0"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/kt -o kt -- $BENCH > $R/$O/kt.log 2>&1)
 DB=$(find $O/kt -name "*results.db" | head -1); python tools/prof_summary.py "$DB" $O/kernel_stats.md 10 && head -12 $O/kernel_stats.md
+python tools/prof_timeline.py "$DB" $O/timeline.md
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d $R/$O/pmc_$C -o pmc -- python $R/bench.py --steps 3 --warmup 1 --cpu-steps 0 --e2e-steps 0 --f32-steps 0 --enc-steps 0 > $R/$O/pmc_$C.log 2>&1)
 done
@@ -19,6 +20,7 @@ C5="--shape YAGO --hidden 400 --seq-len 15 --dtype bf16"
 timeout 900 python bench.py $C5 --steps 100 --f32-steps 0 > $O/bench_c5.json 2> $O/bench_c5.err; tail -c 200 $O/bench_c5.err
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/kt5 -o kt -- $BENCH $C5 > $R/$O/kt5.log 2>&1)
 DB=$(find $O/kt5 -name "*results.db" | head -1); python tools/prof_summary.py "$DB" $O/kernel_stats_c5.md 10 && head -12 $O/kernel_stats_c5.md
+python tools/prof_timeline.py "$DB" $O/timeline_c5.md
 for S in WIKI GDELT; do
   timeout 600 python bench.py --shape $S --steps 60 --cpu-steps 0 --e2e-steps 0 --f32-steps 0 --enc-steps 20 > $O/bench_$S.json 2> $O/bench_$S.err
 done
@@ -34,3 +36,5 @@ for f in ('bench', 'bench_c5', 'bench_WIKI', 'bench_GDELT'):
         print(f, 'failed', e)
 PY
 find $O -name "*.db" -delete
+(timeout 2400 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log)
+(timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log)
