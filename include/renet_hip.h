@@ -161,7 +161,13 @@ size_t renet_rgcn_bwd_w_workspace(int n_chunks, int D);
 int renet_rgcn_bwd_w(const float* x, const float* gn, const int32_t* e_src, const int32_t* e_dst,
                      const int32_t* chunk_ptr, const int32_t* chunk_type, int n_chunks,
                      const int32_t* type_chunk_ptr, int T, int type_shift, int D, float* dW, float beta,
-                     float* workspace, size_t workspace_bytes, void* stream);   /* dW = beta * dW + ... */
+                     float* workspace, size_t workspace_bytes, void* stream);
+/* The same with 64-bit global addressing of the rows of x / gn: for feature tensors of 2 GiB and more, which the
+ * 32-bit buffer offsets of renet_rgcn_bwd_w cannot reach (the counterpart of renet_rgcn_gather for the gather entry). */
+int renet_rgcn_bwd_w64(const float* x, const float* gn, const int32_t* e_src, const int32_t* e_dst,
+                       const int32_t* chunk_ptr, const int32_t* chunk_type, int n_chunks,
+                       const int32_t* type_chunk_ptr, int T, int type_shift, int D, float* dW, float beta,
+                       float* workspace, size_t workspace_bytes, void* stream);   /* dW = beta * dW + ... */
 
 /* ------------------------------------------------------------------------------------------------
  * fp32 GEMM on the f32-input MFMA (exact fp32, v_mfma_f32_32x32x2_f32):

@@ -669,8 +669,9 @@ __global__ __launch_bounds__(256) void rgcn_bwd_prep_kernel(const float4* __rest
 // order, the chunks of one type before anything is written: the partial of a run lands in the slot of the run's first
 // chunk -- the group's first chunk or the first chunk of a type -- and the reduce kernel below reads only those slots
 // (the hottest relation of a Zipf batch owns > 1000 chunks: 8x fewer dependent rounds on its critical path).
+// BIG: x / gmat of 2 GiB and more (renet_rgcn_bwd_w64) -- 64-bit global addressing instead of the 32-bit buffer offsets.
 constexpr int kBwdWGroup = 8;
-template <int SI, int NCH>
+template <int SI, int NCH, bool BIG = false>
 __global__ __launch_bounds__(kBwdWGroup * 64) void rgcn_bwd_w_partial_kernel(
     const float* __restrict__ x, const float* __restrict__ gmat, const int32_t* __restrict__ e_src,
     const int32_t* __restrict__ e_dst, const int32_t* __restrict__ chunk_ptr, const int32_t* __restrict__ chunk_type,
@@ -713,8 +714,18 @@ __global__ __launch_bounds__(kBwdWGroup * 64) void rgcn_bwd_w_partial_kernel(
                 const uint32_t dof = ok ? (uint32_t)__builtin_amdgcn_readlane(my_d, kk) * ROWB : 0u;
 #pragma unroll
                 for (int q = 0; q < NCH; ++q) {
-                    xv[u][q] = buf_load4s(rx, ok ? off[q] : kOob, so);
-                    gv[u][q] = buf_load4s(rg, ok ? off[q] : kOob, dof);
+                    if constexpr (BIG) {
+                        const int ch = lane + 64 * q;
+                        const bool on = ok && ch < CH;
+                        const size_t sr = (size_t)__builtin_amdgcn_readlane(my_s, kk) * CH + ch;
+                        const size_t dr = (size_t)__builtin_amdgcn_readlane(my_d, kk) * CH + ch;
+                        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                        xv[u][q] = on ? reinterpret_cast<const float4*>(x)[sr] : z;
+                        gv[u][q] = on ? reinterpret_cast<const float4*>(gmat)[dr] : z;
+                    } else {
+                        xv[u][q] = buf_load4s(rx, ok ? off[q] : kOob, so);
+                        gv[u][q] = buf_load4s(rg, ok ? off[q] : kOob, dof);
+                    }
                 }
             }
 #pragma unroll
@@ -1148,10 +1159,10 @@ size_t renet_rgcn_bwd_w_workspace(int n_chunks, int D) {
     return (size_t)max(n_chunks, 0) * (size_t)(D * (D / 100)) * sizeof(float);
 }
 
-int renet_rgcn_bwd_w(const float* x, const float* gn, const int32_t* e_src, const int32_t* e_dst,
-                     const int32_t* chunk_ptr, const int32_t* chunk_type, int n_chunks,
-                     const int32_t* type_chunk_ptr, int T, int type_shift, int D, float* dW, float beta,
-                     float* workspace, size_t workspace_bytes, void* stream) {
+static int bwd_w_impl(bool big, const float* x, const float* gn, const int32_t* e_src, const int32_t* e_dst,
+                      const int32_t* chunk_ptr, const int32_t* chunk_type, int n_chunks,
+                      const int32_t* type_chunk_ptr, int T, int type_shift, int D, float* dW, float beta,
+                      float* workspace, size_t workspace_bytes, void* stream) {
     if (!renet_dim_ok(D)) return RENET_ERR_UNSUPPORTED;
     if (n_chunks > 0 && !chunk_type) return RENET_ERR_BADARG;
     if (n_chunks < 0 || T <= 0 || type_shift < 0 || type_shift >= T) return RENET_ERR_BADARG;
@@ -1166,15 +1177,21 @@ int renet_rgcn_bwd_w(const float* x, const float* gn, const int32_t* e_src, cons
         float4* p4 = (float4*)workspace;
         switch (D) {
             case 100:
-                RENET_LAUNCH((rgcn_bwd_w_partial_kernel<1, 1>), grid, dim3(kBwdWGroup * 64), 0, st, x4, g4,
+                if (big) RENET_LAUNCH((rgcn_bwd_w_partial_kernel<1, 1, true>), grid, dim3(kBwdWGroup * 64), 0, st, x4, g4,
+                                            e_src, e_dst, chunk_ptr, chunk_type, n_chunks, p4);
+                else RENET_LAUNCH((rgcn_bwd_w_partial_kernel<1, 1>), grid, dim3(kBwdWGroup * 64), 0, st, x4, g4,
                                    e_src, e_dst, chunk_ptr, chunk_type, n_chunks, p4);
                 break;
             case 200:
-                RENET_LAUNCH((rgcn_bwd_w_partial_kernel<2, 1>), grid, dim3(kBwdWGroup * 64), 0, st, x4, g4,
+                if (big) RENET_LAUNCH((rgcn_bwd_w_partial_kernel<2, 1, true>), grid, dim3(kBwdWGroup * 64), 0, st, x4, g4,
+                                            e_src, e_dst, chunk_ptr, chunk_type, n_chunks, p4);
+                else RENET_LAUNCH((rgcn_bwd_w_partial_kernel<2, 1>), grid, dim3(kBwdWGroup * 64), 0, st, x4, g4,
                                    e_src, e_dst, chunk_ptr, chunk_type, n_chunks, p4);
                 break;
             default:
-                RENET_LAUNCH((rgcn_bwd_w_partial_kernel<4, 2>), grid, dim3(kBwdWGroup * 64), 0, st, x4, g4,
+                if (big) RENET_LAUNCH((rgcn_bwd_w_partial_kernel<4, 2, true>), grid, dim3(kBwdWGroup * 64), 0, st, x4, g4,
+                                            e_src, e_dst, chunk_ptr, chunk_type, n_chunks, p4);
+                else RENET_LAUNCH((rgcn_bwd_w_partial_kernel<4, 2>), grid, dim3(kBwdWGroup * 64), 0, st, x4, g4,
                                    e_src, e_dst, chunk_ptr, chunk_type, n_chunks, p4);
                 break;
         }
@@ -1184,6 +1201,22 @@ int renet_rgcn_bwd_w(const float* x, const float* gn, const int32_t* e_src, cons
                        (const float4*)workspace, type_chunk_ptr, WROW4, T, type_shift, beta, (float4*)dW);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
+}
+
+int renet_rgcn_bwd_w(const float* x, const float* gn, const int32_t* e_src, const int32_t* e_dst,
+                     const int32_t* chunk_ptr, const int32_t* chunk_type, int n_chunks,
+                     const int32_t* type_chunk_ptr, int T, int type_shift, int D, float* dW, float beta,
+                     float* workspace, size_t workspace_bytes, void* stream) {
+    return bwd_w_impl(false, x, gn, e_src, e_dst, chunk_ptr, chunk_type, n_chunks, type_chunk_ptr, T, type_shift, D, dW,
+                      beta, workspace, workspace_bytes, stream);
+}
+
+int renet_rgcn_bwd_w64(const float* x, const float* gn, const int32_t* e_src, const int32_t* e_dst,
+                       const int32_t* chunk_ptr, const int32_t* chunk_type, int n_chunks,
+                       const int32_t* type_chunk_ptr, int T, int type_shift, int D, float* dW, float beta,
+                       float* workspace, size_t workspace_bytes, void* stream) {
+    return bwd_w_impl(true, x, gn, e_src, e_dst, chunk_ptr, chunk_type, n_chunks, type_chunk_ptr, T, type_shift, D, dW,
+                      beta, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

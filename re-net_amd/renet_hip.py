@@ -50,6 +50,8 @@ _SIGNATURES = {
     'renet_rgcn_bwd_w_workspace': (c_size_t, [c_int, c_int]),
     'renet_rgcn_bwd_w': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                  c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    'renet_rgcn_bwd_w64': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     'renet_gemm_workspace': (c_size_t, [c_int, c_int, c_int]),
     'renet_gemm_f32': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
@@ -418,14 +420,16 @@ def rgcn_bwd_prep(g_out, out, norm, relu, drop_p, seed, gn, g_loop):
 def rgcn_bwd_w(x, gn, e_src, e_dst, chunk_ptr, chunk_type, n_chunks, type_chunk_ptr, num_types, type_shift,
                dW, beta=0.0):
     d = x.shape[1]
-    if max(x.numel(), gn.numel()) * 4 >= (1 << 31):
-        raise RenetHipError('rgcn_bwd_w addresses rows with 32-bit buffer offsets: x / gn must be smaller than 2 GiB')
+    # feature tensors of 2 GiB and more: the entry with 64-bit addressing (as rgcn_gather_items falls back to the CSR
+    # kernel); RENET_BWDW_64=1 forces it (tests)
+    big = max(x.numel(), gn.numel()) * 4 >= (1 << 31) or os.environ.get('RENET_BWDW_64') == '1'
     nbytes = lib().renet_rgcn_bwd_w_workspace(n_chunks, d)
     ws = torch.empty(max(nbytes // 4, 1), device=x.device, dtype=torch.float32)
     t0 = _timer.begin() if _timer is not None else None
-    _check(lib().renet_rgcn_bwd_w(_f32(x), _f32(gn), _i32(e_src), _i32(e_dst), _i32(chunk_ptr),
-                                  _i32(chunk_type), n_chunks, _i32(type_chunk_ptr), num_types, type_shift, d,
-                                  _f32(dW), float(beta), ws.data_ptr(), nbytes, _stream()), 'rgcn_bwd_w')
+    fn = lib().renet_rgcn_bwd_w64 if big else lib().renet_rgcn_bwd_w
+    _check(fn(_f32(x), _f32(gn), _i32(e_src), _i32(e_dst), _i32(chunk_ptr), _i32(chunk_type), n_chunks,
+              _i32(type_chunk_ptr), num_types, type_shift, d, _f32(dW), float(beta), ws.data_ptr(), nbytes, _stream()),
+           'rgcn_bwd_w')
     if t0 is not None:      # SURVEY 8d backward-W: E * 2 rows + indices, dW written once
         _timer.end('rgcn_bwd_w', t0, nbytes=float(e_src.numel() * (2 * d * 4 + 8) + dW.numel() * 4))
     return dW

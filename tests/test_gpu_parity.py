@@ -584,6 +584,14 @@ def test_full_size_dw_matches_fp64_sampled(dev):
                  beta=1.0)
     assert torch.equal(acc, dw + dw)
     assert torch.equal(dw, dw2)
+    # the 64-bit-addressing entry (feature tensors >= 2 GiB) is the same arithmetic in the same order
+    os.environ['RENET_BWDW_64'] = '1'
+    try:
+        dw64 = torch.empty_like(dw)
+        K.rgcn_bwd_w(x, gn, g.e_src, g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr, 2 * R, 0, dw64)
+    finally:
+        del os.environ['RENET_BWDW_64']
+    assert torch.equal(dw64, dw)
     xc, gc = x.cpu().double().numpy(), gn.cpu().double().numpy()
     got = dw.cpu().numpy()
     for t in (0, 1, 5, R, R + 2, 2 * R - 1):
