@@ -400,6 +400,9 @@ def main():
             roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': peak,
                         'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic_of(dom),
                         'gemm_mode': K.GEMM_MODE, 'note': note}
+            if K.GEMM_MODE == 'f16x3':
+                # continuity with rounds 1-2, whose fp32-class GEMM needed six matrix instructions per product
+                roofline['frac_of_bf16x6_ceiling'] = ach / (MFMA_BF16_PEAK_TF / 6.0)
         else:
             ach = st['bytes'] / (st['ms'] * 1e-3) / 1e9
             roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
