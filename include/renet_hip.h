@@ -148,6 +148,11 @@ int renet_compose_table_items(const int32_t* row_map, const int32_t* it_src, con
 int renet_rgcn_bwd_prep(const float* g_out, const float* out, const float* norm, int relu,
                         float drop_p, uint64_t seed, int N, int D, float* gn, float* g_loop,
                         void* stream);
+/* The same with the operand bound of g_loop for renet_gemm_f32_h3: bound_part receives renet_bound_parts(N * D / 4)
+ * floats (one maximum of |g_loop| per workgroup). */
+int renet_rgcn_bwd_prep_bounds(const float* g_out, const float* out, const float* norm, int relu,
+                               float drop_p, uint64_t seed, int N, int D, float* gn, float* g_loop,
+                               float* bound_part, void* stream);
 
 /* Gradient of the relation weights (RGCN.py:81-87 backward):
  *   dW[tau, b, i, j] = sum_{e: tau(e) == tau} x[src[e], b*si+i] * gn[dst[e], b*so+j]
@@ -196,7 +201,7 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
  * x s = h1 + 2^-11 h2 and a b is evaluated as a1 b1 + 2^-11 (a1 b2 + a2 b1) with fp32 accumulation: the dropped
  * term and the split error are <= 2^-24 relative for every element with |x| >= 2^-29 max |x| (smaller elements keep
  * an ABSOLUTE error <= 2^-39 max |x|) -- fp32-class results with three matrix instructions per fragment pair
- * instead of six.  maxA / maxB: nA / nB (1..256) device floats whose largest magnitude bounds max |A| / max |B|
+ * instead of six.  maxA / maxB: nA / nB (1..1024) device floats whose largest magnitude bounds max |A| / max |B|
  * from above -- the output of renet_maxabs_partials, or any bound the caller knows (a bound 2^k too large costs k of
  * the 29 binades).  A bound that is too SMALL overflows binary16: undefined results (inf / NaN).
  *   renet_maxabs_partials : part[b], b < renet_maxabs_blocks(rows, cols, ld) <= 256 (part[0] = 0 for an empty matrix):
@@ -308,6 +313,14 @@ int renet_seq_assemble_fwd(const float* h2, const float* ent, const float* rel, 
                            const int32_t* subj_row, const int32_t* row_ent, const int32_t* row_rel,
                            const int32_t* glob_row, int S, int D, float drop_p, uint64_t seed_x,
                            uint64_t seed_xr, float* X, float* Xr, void* stream);
+/* The same, additionally emitting the operand bounds of renet_gemm_f32_h3 for X and Xr: partX / partXr receive
+ * renet_bound_parts(S * D) floats each (one maximum of |value written| per workgroup), so that no separate
+ * renet_maxabs_partials pass over the 51 + 38 MB is needed.  S > 0. */
+int renet_bound_parts(size_t total4);
+int renet_seq_assemble_fwd_bounds(const float* h2, const float* ent, const float* rel, const float* glob,
+                                  const int32_t* subj_row, const int32_t* row_ent, const int32_t* row_rel,
+                                  const int32_t* glob_row, int S, int D, float drop_p, uint64_t seed_x,
+                                  uint64_t seed_xr, float* X, float* Xr, float* partX, float* partXr, void* stream);
 int renet_seq_assemble_bwd(const float* dX, const float* dXr, const int32_t* step_off, int L, int S,
                            int B, int D, float drop_p, uint64_t seed_x, uint64_t seed_xr, float* dRows,
                            float* dEntSeq, float* dRelSeq, void* stream);
@@ -380,6 +393,10 @@ int renet_gru_bwd_layouts_bf16(int n, const float* const* dh_last, const int32_t
 int renet_concat3_fwd(const float* a, const int32_t* ia, const float* hmid, const float* c,
                       const int32_t* ic, int B, int D, float drop_p, uint64_t seed, float* feat,
                       void* stream);
+/* The same with the operand bound of feat: bound_part receives renet_bound_parts(B * parts * D / 4) floats. */
+int renet_concat3_fwd_bounds(const float* a, const int32_t* ia, const float* hmid, const float* c,
+                             const int32_t* ic, int B, int D, float drop_p, uint64_t seed, float* feat,
+                             float* bound_part, void* stream);
 int renet_concat3_bwd(const float* dfeat, int B, int D, int parts, float drop_p, uint64_t seed,
                       float* da_rows, float* dhmid, float* dc_rows, void* stream);
 /* y = x * keepmask(seed) / (1 - p) on float4 groups (n % 4 == 0); its own backward (apply to dy).

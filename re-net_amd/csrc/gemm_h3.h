@@ -15,7 +15,7 @@
 //
 // The tensor scale comes from a bound on max |x|: renet_maxabs_partials (one pass over an activation, <= 256 partial
 // maxima; a weight's are cached per optimizer step by the caller) or any upper bound the producer knows (the CE
-// gradient is bounded by its scale factor) -- a bound 2^k too large costs k of the 29 binades, nothing else.  The
+// gradient is bounded by its scale factor; up to 1024 partials, so that a producer kernel can emit one per workgroup) -- a bound 2^k too large costs k of the 29 binades, nothing else.  The
 // kernel reduces the partial maxima in its prologue (no extra launch, no atomics).
 //
 // Structure: the two-phase k-loop of gemm_split_kernel / gemm_split_tall_kernel (128 x 128 x 32 or 256 x 128 x 32

@@ -1611,7 +1611,7 @@ int renet_gemm_f32_h3(int ta, int tb, int M, int N, int K, float alpha, const fl
                       int ldb, float beta, float* C, int ldc, const float* bias, int split_k, float* workspace,
                       size_t workspace_bytes, const float* maxA, int nA, const float* maxB, int nB, void* stream) {
     if (M < 0 || N < 0 || K < 1 || lda <= 0 || ldb <= 0 || ldc < N) return RENET_ERR_BADARG;
-    if (!maxA || !maxB || nA < 1 || nB < 1 || nA > 256 || nB > 256) return RENET_ERR_BADARG;
+    if (!maxA || !maxB || nA < 1 || nB < 1 || nA > 1024 || nB > 1024) return RENET_ERR_BADARG;
     if (M == 0 || N == 0) return RENET_OK;
     // the f16x3 loaders address with 32-bit byte offsets; operands of 4 GiB and more and the weight-resident shapes run
     // the bf16x6 kernels (same accuracy class, no bounds needed)

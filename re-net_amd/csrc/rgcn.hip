@@ -643,7 +643,11 @@ __global__ __launch_bounds__(256) void rgcn_bwd_prep_kernel(const float4* __rest
                                                             const float* __restrict__ norm, int relu,
                                                             DropCfg drop, int N, int CH,
                                                             float4* __restrict__ gn,
-                                                            float4* __restrict__ g_loop) {
+                                                            float4* __restrict__ g_loop,
+                                                            float* __restrict__ bound_part) {
+    // bound_part (optional): per-workgroup maxima of |g_loop|, the operand bound of the f16x3 GEMM that consumes it
+    __shared__ float red[4];
+    float mx = 0.f;
     const size_t total = (size_t)N * CH;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -657,7 +661,16 @@ __global__ __launch_bounds__(256) void rgcn_bwd_prep_kernel(const float4* __rest
             g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
         }
         gn[i] = f4_scale(g, norm[v]);
-        nt_store4(g_loop + i, f4_mul(g, renet_drop4(drop, i)));
+        const float4 gl = f4_mul(g, renet_drop4(drop, i));
+        nt_store4(g_loop + i, gl);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(gl.x), fabsf(gl.y))), fmaxf(fabsf(gl.z), fabsf(gl.w)));
+    }
+    if (bound_part) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) bound_part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     }
 }
 
@@ -1141,18 +1154,30 @@ int renet_compose_table_items(const int32_t* row_map, const int32_t* it_src, con
     return RENET_OK;
 }
 
+static int bwd_prep_impl(const float* g_out, const float* out, const float* norm, int relu, float drop_p,
+                         uint64_t seed, int N, int D, float* gn, float* g_loop, float* bound_part, void* stream) {
+    if (N < 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f) return RENET_ERR_BADARG;
+    if (N == 0) return bound_part ? RENET_ERR_BADARG : RENET_OK;
+    const size_t total = (size_t)N * (D / 4);
+    int blocks = (int)min((size_t)(bound_part ? 1024 : 2048), (total + 255) / 256);     // = renet_bound_parts(total)
+    RENET_LAUNCH(rgcn_bwd_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)g_out, (const float4*)out, norm, relu, make_drop(drop_p, seed), N,
+                       D / 4, (float4*)gn, (float4*)g_loop, bound_part);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
 int renet_rgcn_bwd_prep(const float* g_out, const float* out, const float* norm, int relu,
                         float drop_p, uint64_t seed, int N, int D, float* gn, float* g_loop,
                         void* stream) {
-    if (N < 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f) return RENET_ERR_BADARG;
-    if (N == 0) return RENET_OK;
-    const size_t total = (size_t)N * (D / 4);
-    int blocks = (int)min((size_t)2048, (total + 255) / 256);
-    RENET_LAUNCH(rgcn_bwd_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)g_out, (const float4*)out, norm, relu, make_drop(drop_p, seed), N,
-                       D / 4, (float4*)gn, (float4*)g_loop);
-    RENET_LAUNCH_CHECK();
-    return RENET_OK;
+    return bwd_prep_impl(g_out, out, norm, relu, drop_p, seed, N, D, gn, g_loop, nullptr, stream);
+}
+
+int renet_rgcn_bwd_prep_bounds(const float* g_out, const float* out, const float* norm, int relu,
+                               float drop_p, uint64_t seed, int N, int D, float* gn, float* g_loop,
+                               float* bound_part, void* stream) {
+    if (!bound_part) return RENET_ERR_BADARG;
+    return bwd_prep_impl(g_out, out, norm, relu, drop_p, seed, N, D, gn, g_loop, bound_part, stream);
 }
 
 size_t renet_rgcn_bwd_w_workspace(int n_chunks, int D) {

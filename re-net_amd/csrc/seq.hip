@@ -4,13 +4,31 @@
 
 namespace {
 
+// Magnitude bounds for the f16x3 GEMMs (gemm_h3.h), produced by the kernel that WRITES the operand instead of a
+// separate pass over it: every workgroup's maximum of |value written| goes to part[blockIdx.x] (grid <= 1024 = the
+// number of partial maxima renet_gemm_f32_h3 accepts).  The maximum over the partials is the tensor's exact maximum,
+// so the GEMMs scale -- and round -- exactly as with renet_maxabs_partials.
+__device__ __forceinline__ float sq_max4(float m, const float4& v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+__device__ __forceinline__ void sq_block_max_write(float m, float* __restrict__ part, float* red /* [4] LDS */) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+}
+
 // ---- Aggregator.py:142-165: packed GRU inputs X [S,4D], Xr [S,3D] ----------------------------
 __global__ __launch_bounds__(256) void seq_assemble_fwd_kernel(
     const float4* __restrict__ h2, const float4* __restrict__ ent, const float4* __restrict__ rel,
     const float4* __restrict__ glob, const int32_t* __restrict__ subj_row,
     const int32_t* __restrict__ row_ent, const int32_t* __restrict__ row_rel,
     const int32_t* __restrict__ glob_row, int S, int CH, DropCfg dx, DropCfg dxr,
-    float4* __restrict__ X, float4* __restrict__ Xr) {
+    float4* __restrict__ X, float4* __restrict__ Xr, float* __restrict__ partX, float* __restrict__ partXr) {
+    __shared__ float red[4];
+    float mx = 0.f, mxr = 0.f;
     const size_t total = (size_t)S * 4 * CH;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -22,12 +40,20 @@ __global__ __launch_bounds__(256) void seq_assemble_fwd_kernel(
         else if (part == 1) v = ent[(size_t)row_ent[p] * CH + cc];
         else if (part == 2) v = rel[(size_t)row_rel[p] * CH + cc];
         else v = glob[(size_t)glob_row[p] * CH + cc];
-        X[i] = f4_mul(v, renet_drop4(dx, i));
+        const float4 o = f4_mul(v, renet_drop4(dx, i));
+        X[i] = o;
+        mx = sq_max4(mx, o);
         if (part != 2) {                                   // Xr = [h2 | ent | glob]
             const int cr = (part == 3 ? 2 : part) * CH + cc;
             const size_t ir = (size_t)p * 3 * CH + cr;
-            Xr[ir] = f4_mul(v, renet_drop4(dxr, ir));
+            const float4 orr = f4_mul(v, renet_drop4(dxr, ir));
+            Xr[ir] = orr;
+            mxr = sq_max4(mxr, orr);
         }
+    }
+    if (partX) {                                           // kernel-uniform
+        sq_block_max_write(mx, partX, red);
+        sq_block_max_write(mxr, partXr, red);
     }
 }
 
@@ -121,7 +147,10 @@ __global__ __launch_bounds__(256) void concat3_fwd_kernel(const float4* __restri
                                                           const float4* __restrict__ hmid,
                                                           const float4* __restrict__ c,
                                                           const int32_t* __restrict__ ic, int B, int CH,
-                                                          int parts, DropCfg d, float4* __restrict__ feat) {
+                                                          int parts, DropCfg d, float4* __restrict__ feat,
+                                                          float* __restrict__ bound_part) {
+    __shared__ float red[4];
+    float mx = 0.f;
     const size_t total = (size_t)B * parts * CH;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -132,8 +161,11 @@ __global__ __launch_bounds__(256) void concat3_fwd_kernel(const float4* __restri
         if (part == 0) v = a[(size_t)ia[b] * CH + cc];
         else if (part == 1) v = hmid[(size_t)b * CH + cc];
         else v = c[(size_t)ic[b] * CH + cc];
-        feat[i] = f4_mul(v, renet_drop4(d, i));
+        const float4 o = f4_mul(v, renet_drop4(d, i));
+        feat[i] = o;
+        mx = sq_max4(mx, o);
     }
+    if (bound_part) sq_block_max_write(mx, bound_part, red);
 }
 
 __global__ __launch_bounds__(256) void concat3_bwd_kernel(const float4* __restrict__ dfeat, int B, int CH,
@@ -369,7 +401,24 @@ int renet_seq_assemble_fwd(const float* h2, const float* ent, const float* rel, 
     RENET_LAUNCH(seq_assemble_fwd_kernel, dim3(grid_for((size_t)S * 4 * CH)), dim3(256), 0,
                        (hipStream_t)stream, (const float4*)h2, (const float4*)ent, (const float4*)rel,
                        (const float4*)glob, subj_row, row_ent, row_rel, glob_row, S, CH,
-                       make_drop(drop_p, seed_x), make_drop(drop_p, seed_xr), (float4*)X, (float4*)Xr);
+                       make_drop(drop_p, seed_x), make_drop(drop_p, seed_xr), (float4*)X, (float4*)Xr,
+                       (float*)nullptr, (float*)nullptr);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_bound_parts(size_t total4) { return (int)max((size_t)1, min((size_t)1024, (total4 + 255) / 256)); }
+
+int renet_seq_assemble_fwd_bounds(const float* h2, const float* ent, const float* rel, const float* glob,
+                                  const int32_t* subj_row, const int32_t* row_ent, const int32_t* row_rel,
+                                  const int32_t* glob_row, int S, int D, float drop_p, uint64_t seed_x,
+                                  uint64_t seed_xr, float* X, float* Xr, float* partX, float* partXr, void* stream) {
+    if (S <= 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f || !partX || !partXr) return RENET_ERR_BADARG;
+    const int CH = D / 4;
+    RENET_LAUNCH(seq_assemble_fwd_kernel, dim3(renet_bound_parts((size_t)S * 4 * CH)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)h2, (const float4*)ent, (const float4*)rel,
+                       (const float4*)glob, subj_row, row_ent, row_rel, glob_row, S, CH,
+                       make_drop(drop_p, seed_x), make_drop(drop_p, seed_xr), (float4*)X, (float4*)Xr, partX, partXr);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -433,17 +482,31 @@ int renet_seq_assemble_bwd(const float* dX, const float* dXr, const int32_t* ste
     return RENET_OK;
 }
 
+static int concat3_fwd_impl(const float* a, const int32_t* ia, const float* hmid, const float* c,
+                            const int32_t* ic, int B, int D, float drop_p, uint64_t seed, float* feat,
+                            float* bound_part, void* stream) {
+    if (B < 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f) return RENET_ERR_BADARG;
+    if (B == 0) return bound_part ? RENET_ERR_BADARG : RENET_OK;
+    const int CH = D / 4, parts = c ? 3 : 2;
+    RENET_LAUNCH(concat3_fwd_kernel, dim3(bound_part ? renet_bound_parts((size_t)B * parts * CH)
+                                                     : grid_for((size_t)B * parts * CH)), dim3(256), 0,
+                       (hipStream_t)stream, (const float4*)a, ia, (const float4*)hmid, (const float4*)c, ic,
+                       B, CH, parts, make_drop(drop_p, seed), (float4*)feat, bound_part);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
 int renet_concat3_fwd(const float* a, const int32_t* ia, const float* hmid, const float* c,
                       const int32_t* ic, int B, int D, float drop_p, uint64_t seed, float* feat,
                       void* stream) {
-    if (B < 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f) return RENET_ERR_BADARG;
-    if (B == 0) return RENET_OK;
-    const int CH = D / 4, parts = c ? 3 : 2;
-    RENET_LAUNCH(concat3_fwd_kernel, dim3(grid_for((size_t)B * parts * CH)), dim3(256), 0,
-                       (hipStream_t)stream, (const float4*)a, ia, (const float4*)hmid, (const float4*)c, ic,
-                       B, CH, parts, make_drop(drop_p, seed), (float4*)feat);
-    RENET_LAUNCH_CHECK();
-    return RENET_OK;
+    return concat3_fwd_impl(a, ia, hmid, c, ic, B, D, drop_p, seed, feat, nullptr, stream);
+}
+
+int renet_concat3_fwd_bounds(const float* a, const int32_t* ia, const float* hmid, const float* c,
+                             const int32_t* ic, int B, int D, float drop_p, uint64_t seed, float* feat,
+                             float* bound_part, void* stream) {
+    if (!bound_part) return RENET_ERR_BADARG;
+    return concat3_fwd_impl(a, ia, hmid, c, ic, B, D, drop_p, seed, feat, bound_part, stream);
 }
 
 int renet_concat3_bwd(const float* dfeat, int B, int D, int parts, float drop_p, uint64_t seed,

@@ -47,6 +47,9 @@ _SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
     'renet_rgcn_bwd_prep': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_u64, c_int, c_int,
                                     c_void_p, c_void_p, c_void_p]),
+    'renet_rgcn_bwd_prep_bounds': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_u64, c_int, c_int,
+                                           c_void_p, c_void_p, c_void_p, c_void_p]),
+    'renet_bound_parts': (c_int, [c_size_t]),
     'renet_rgcn_bwd_w_workspace': (c_size_t, [c_int, c_int]),
     'renet_rgcn_bwd_w': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                  c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
@@ -89,6 +92,9 @@ _SIGNATURES = {
     'renet_seq_assemble_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_void_p,
                                        c_void_p]),
+    'renet_seq_assemble_fwd_bounds': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_int, c_int, c_float, c_u64, c_u64, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p]),
     'renet_seq_assemble_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                        c_u64, c_u64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'renet_gru_workspace': (c_size_t, [c_int, c_int]),
@@ -110,6 +116,8 @@ _SIGNATURES = {
                                            c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_concat3_fwd': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
                                   c_u64, c_void_p, c_void_p]),
+    'renet_concat3_fwd_bounds': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                                         c_u64, c_void_p, c_void_p, c_void_p]),
     'renet_concat3_bwd': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_u64, c_void_p, c_void_p,
                                   c_void_p, c_void_p]),
     'renet_dropout': (c_int, [c_void_p, c_size_t, c_float, c_u64, c_void_p, c_void_p]),
@@ -413,6 +421,14 @@ def rgcn_gather_items_table(table, g, weight, type_shift, addend_table, drop_p, 
 
 def rgcn_bwd_prep(g_out, out, norm, relu, drop_p, seed, gn, g_loop):
     n, d = g_out.shape
+    if _fused_bounds(g_loop):                    # g_loop's operand bound comes out of the kernel that writes it
+        nparts = lib().renet_bound_parts(n * (d // 4))
+        part = torch.empty(nparts, device=g_loop.device, dtype=torch.float32)
+        _check(lib().renet_rgcn_bwd_prep_bounds(_f32(g_out), _f32(out), _f32(norm), int(relu), float(drop_p),
+                                                int(seed), n, d, _f32(gn), _f32(g_loop), part.data_ptr(), _stream()),
+               'rgcn_bwd_prep_bounds')
+        _note_bound(g_loop, part, nparts)
+        return
     _check(lib().renet_rgcn_bwd_prep(_f32(g_out), _f32(out), _f32(norm), int(relu), float(drop_p),
                                      int(seed), n, d, _f32(gn), _f32(g_loop), _stream()), 'rgcn_bwd_prep')
 
@@ -648,6 +664,18 @@ def _skinny_shape(ta, m, n, k, a, b, split_k):
             os.environ.get('RENET_GEMM_SKINNY', '1') != '0')
 
 
+# Operand bounds emitted by the kernel that WROTE the tensor (seq_assemble_fwd, concat3_fwd, rgcn_bwd_prep in f16x3
+# mode) ride on the tensor OBJECT (`_renet_bound` = (part, n)) and are picked up by operand() instead of a
+# renet_maxabs_partials pass; a tensor that arrives without the attribute (re-wrapped by autograd, a view, a copy) is
+# simply measured.  The producers' outputs are never modified in place.  RENET_FUSED_BOUNDS=0 turns this off.
+def _fused_bounds(t):
+    return GEMM_MODE == 'f16x3' and t.is_cuda and t.numel() > 0 and os.environ.get('RENET_FUSED_BOUNDS', '1') != '0'
+
+
+def _note_bound(t, part, n):
+    t._renet_bound = (part, n)
+
+
 _lazy_shells = {}          # (data_ptr, shape) of an uninitialised fp32 shell -> the BF16Mat it stands for
 
 
@@ -680,6 +708,9 @@ def operand(x, bound=None):
     if GEMM_MODE == 'bf16s':
         return pack_bf16(x)
     if GEMM_MODE == 'f16x3' and x.is_cuda and x.dim() == 2:
+        noted = getattr(x, '_renet_bound', None)
+        if noted is not None and bound is None:
+            return F32Op(x, noted[0], noted[1])
         return _f32op(x, bound)
     return x
 
@@ -871,6 +902,16 @@ def seq_assemble_fwd(h2, ent, rel, glob, subj_row, row_ent, row_rel, glob_row, d
     s, d = subj_row.numel(), h2.shape[1]
     x = torch.empty(s, 4 * d, device=h2.device, dtype=torch.float32)
     xr = torch.empty(s, 3 * d, device=h2.device, dtype=torch.float32)
+    if _fused_bounds(x):                         # the operand bounds of X / Xr come out of the kernel that writes them
+        nparts = lib().renet_bound_parts(s * d)
+        parts = torch.empty(2, nparts, device=h2.device, dtype=torch.float32)
+        _check(lib().renet_seq_assemble_fwd_bounds(_f32(h2), _f32(ent), _f32(rel), _f32(glob), _i32(subj_row),
+                                                   _i32(row_ent), _i32(row_rel), _i32(glob_row), s, d, float(drop_p),
+                                                   int(seed_x), int(seed_xr), _f32(x), _f32(xr), parts[0].data_ptr(),
+                                                   parts[1].data_ptr(), _stream()), 'seq_assemble_fwd_bounds')
+        _note_bound(x, parts[0], nparts)
+        _note_bound(xr, parts[1], nparts)
+        return x, xr
     _check(lib().renet_seq_assemble_fwd(_f32(h2), _f32(ent), _f32(rel), _f32(glob), _i32(subj_row),
                                         _i32(row_ent), _i32(row_rel), _i32(glob_row), s, d, float(drop_p),
                                         int(seed_x), int(seed_xr), _f32(x), _f32(xr), _stream()),
@@ -1048,6 +1089,13 @@ def concat3_fwd(a, ia, hmid, c, ic, drop_p, seed):
     b, d = hmid.shape
     parts = 3 if c is not None else 2
     feat = torch.empty(b, parts * d, device=hmid.device, dtype=torch.float32)
+    if _fused_bounds(feat):
+        nparts = lib().renet_bound_parts(b * parts * (d // 4))
+        part = torch.empty(nparts, device=hmid.device, dtype=torch.float32)
+        _check(lib().renet_concat3_fwd_bounds(_f32(a), _i32(ia), _f32(hmid), _f32(c), _i32(ic), b, d, float(drop_p),
+                                              int(seed), _f32(feat), part.data_ptr(), _stream()), 'concat3_fwd_bounds')
+        _note_bound(feat, part, nparts)
+        return feat
     _check(lib().renet_concat3_fwd(_f32(a), _i32(ia), _f32(hmid), _f32(c), _i32(ic), b, d, float(drop_p),
                                    int(seed), _f32(feat), _stream()), 'concat3_fwd')
     return feat

@@ -150,3 +150,43 @@ def test_segment_add_matches_fp64_scatter_add(dev, d, n_rows, n_tgt, zipf):
     assert (got.double() - want0).abs().max().item() <= tol * max(1.0, want0.abs().max().item())
     assert torch.equal(got, a) and torch.equal(got, again)
     assert (b.double() - want1).abs().max().item() <= tol * max(1.0, want1.abs().max().item())
+
+
+def test_bounds_from_the_producer_kernels_change_no_bit(dev, monkeypatch):
+    """f16x3 GEMM operand bounds emitted by seq_assemble_fwd / concat3_fwd / rgcn_bwd_prep (per-workgroup maxima of what
+    they write) against RENET_FUSED_BOUNDS=0 (a renet_maxabs_partials pass per tensor): the maximum is the same number
+    either way, so loss and every gradient are bit-identical -- and the passes over X, Xr, feat x2 and layer 2's g_loop
+    are gone."""
+    import model as M
+    import ops
+    import preprocess as P
+    import renet_hip as K
+    import synth
+    if K.GEMM_MODE != 'f16x3':
+        pytest.skip('bounds only exist in f16x3 mode')
+    quads, num_ent, num_rels, _ = synth.make_stream('ICEWS18', seed=6, num_t=40)
+    gd = P.build_graph_dict(quads, num_rels)
+    hs, ho = P.HistoryIndex(quads, 's', 10), P.HistoryIndex(quads, 'o', 10)
+    idx = np.random.RandomState(2).permutation(len(quads))[:256]
+    calls = []
+    real = K.maxabs_partials
+    monkeypatch.setattr(K, 'maxabs_partials', lambda x: (calls.append(tuple(x.shape)), real(x))[1])
+    res = []
+    for fused in ('1', '0'):
+        monkeypatch.setenv('RENET_FUSED_BOUNDS', fused)
+        torch.manual_seed(11)
+        ops.reset_seed_counter()
+        net = M.RENet(num_ent, 200, num_rels, dropout=0.5, seq_len=10, num_k=10)
+        gen = torch.Generator().manual_seed(3)
+        net.global_emb = {int(t): torch.randn(1, 1, 200, generator=gen) * 0.1 for t in gd}
+        net.to(dev).train()
+        prep = net.prepare_both(quads[idx], hs.take(idx), ho.take(idx), gd)
+        del calls[:]
+        loss = net.loss_prepared_both(prep)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((loss.item(), {k: p.grad.clone() for k, p in net.named_parameters()}, len(calls)))
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    assert res[0][2] <= res[1][2] - 5, (res[0][2], res[1][2])       # X, Xr, feat x2, g_loop no longer measured
