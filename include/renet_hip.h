@@ -372,6 +372,15 @@ int renet_gru_fwd_layouts(int n, const float* const* Gi, const int32_t* const* s
 int renet_gru_bwd_layouts(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
                           const float* const* Whh, const float* const* saved, float* const* dGi,
                           float* const* dGh, float* workspace, size_t workspace_bytes, void* stream);
+/* renet_gru_bwd_layouts that additionally emits the operand bound of dGi for renet_gemm_f32_h3: bounds[k] receives
+ * renet_gru_bound_parts(max over the problems of their sequence count) floats, one maximum of |dGi| per workgroup
+ * (|dGh| <= |dGi| elementwise: the same bound serves both).  Only the persistent bf16x6 recurrence emits them;
+ * RENET_ERR_UNSUPPORTED otherwise (RENET_GEMM=f32, RENET_GRU=steps) -- call the plain entry then. */
+int renet_gru_bound_parts(int max_rows);
+int renet_gru_bwd_layouts_bounds(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
+                                 const float* const* Whh, const float* const* saved, float* const* dGi,
+                                 float* const* dGh, float* const* bounds, float* workspace, size_t workspace_bytes,
+                                 void* stream);
 /* The same recurrences in bf16 mode (BASELINE config 5): W_hh and the hidden state / gate gradients are rounded to
  * bf16 (RNE) as MFMA operands -- ONE v_mfma_f32_16x16x32_bf16 product per fragment pair instead of the six of the
  * fp32-class split, a third of the W_hh stream -- with fp32 accumulation, fp32 gate math, fp32 state and outputs. */

@@ -363,7 +363,8 @@ __device__ __forceinline__ f32x4 mfma_p(const bf16x8 (&a)[NPL], const bf16x8 (&b
 
 struct FwdProbB { const float* Gi; const bf16x8* Wp; const float* bhh; float* h_last; float* saved; };
 struct FwdProbsB { FwdProbB p[MAXP]; };
-struct BwdProbB { const float* dh_last; const bf16x8* WTp; const float* saved; float* dGi; float* dGh; int out_ld; };
+struct BwdProbB { const float* dh_last; const bf16x8* WTp; const float* saved; float* dGi; float* dGh; int out_ld;
+                  float* bound; /* optional: bound[blockIdx.x] = this workgroup's max |dGi| (f16x3 GEMM operand bound) */ };
 struct BwdProbsB { BwdProbB p[MAXP]; };
 
 // Wp: bf16 planes of W_hh in fragment order (split_frag_kernel with G = 3 gates)
@@ -522,7 +523,14 @@ __global__ __launch_bounds__(WV * 64) void gru_bwd_bf_kernel(BwdProbsB ps, Layou
     const int lay = ly.lay_of[blockIdx.y];
     const StepOff& so = ly.so[lay];
     const int L = ly.L[lay];
-    if ((int)blockIdx.x * MT >= ly.rows[lay]) return;
+    float* __restrict__ bound = ps.p[blockIdx.y].bound;
+    if ((int)blockIdx.x * MT >= ly.rows[lay]) {
+        if (bound && threadIdx.x == 0) bound[blockIdx.x] = 0.f;
+        return;
+    }
+    constexpr bool TRACK = NPL == 3;              // only the bf16x6 kernels feed f16x3 GEMMs (the bf16-storage ones don't)
+    __shared__ float gred[16];
+    float gmax = 0.f;                                                     // max |dGi| written by this thread
     using C = Cfg<H>;
     using Bc = BCfg<H>;
     const float* __restrict__ dh_last = ps.p[blockIdx.y].dh_last;
@@ -583,6 +591,7 @@ __global__ __launch_bounds__(WV * 64) void gru_bwd_bf_kernel(BwdProbsB ps, Layou
                     const float daz = g * (hp - n) * z * (1.f - z);
                     const float dar = dan * hn * r * (1.f - r);
                     gr = dar; gz = daz; gn = dan * r;
+                    if constexpr (TRACK) gmax = fmaxf(gmax, fmaxf(fabsf(dar), fmaxf(fabsf(daz), fabsf(dan))));
                     if constexpr (OUT16) {
                         __bf16* gi = reinterpret_cast<__bf16*>(dGi) + p * ps.p[blockIdx.y].out_ld;
                         __bf16* gh = reinterpret_cast<__bf16*>(dGh) + p * ps.p[blockIdx.y].out_ld;
@@ -662,6 +671,17 @@ __global__ __launch_bounds__(WV * 64) void gru_bwd_bf_kernel(BwdProbsB ps, Layou
                 }
             }
             __syncthreads();
+        }
+    }
+    if (TRACK && bound) {                                                 // kernel-uniform per problem
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off));
+        if (lane == 0) gred[wave] = gmax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = 0.f;
+            for (int w = 0; w < WV; ++w) m = fmaxf(m, gred[w]);
+            bound[blockIdx.x] = m;
         }
     }
 }
@@ -1376,12 +1396,24 @@ static int gru_fwd_impl(int npl, int n, const float* const* Gi, const int32_t* c
 
 static int gru_bwd_impl(int npl, int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
                         const float* const* Whh, const float* const* saved, float* const* dGi,
-                        float* const* dGh, float* workspace, size_t workspace_bytes, void* stream, int out_ld = 0);
+                        float* const* dGh, float* workspace, size_t workspace_bytes, void* stream, int out_ld = 0,
+                        float* const* bounds = nullptr);
 
 int renet_gru_bwd_layouts(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
                           const float* const* Whh, const float* const* saved, float* const* dGi,
                           float* const* dGh, float* workspace, size_t workspace_bytes, void* stream) {
     return gru_bwd_impl(3, n, dh_last, step_off, L, H, Whh, saved, dGi, dGh, workspace, workspace_bytes, stream);
+}
+
+int renet_gru_bound_parts(int max_rows) { return max(1, (max_rows + MT - 1) / MT); }
+
+int renet_gru_bwd_layouts_bounds(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
+                                 const float* const* Whh, const float* const* saved, float* const* dGi,
+                                 float* const* dGh, float* const* bounds, float* workspace, size_t workspace_bytes,
+                                 void* stream) {
+    if (!bounds) return RENET_ERR_BADARG;
+    return gru_bwd_impl(3, n, dh_last, step_off, L, H, Whh, saved, dGi, dGh, workspace, workspace_bytes, stream, 0,
+                        bounds);
 }
 
 int renet_gru_bwd_layouts_bf16(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
@@ -1401,7 +1433,8 @@ int renet_gru_bwd_layouts_bf16out(int n, const float* const* dh_last, const int3
 
 static int gru_bwd_impl(int npl, int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
                         const float* const* Whh, const float* const* saved, float* const* dGi,
-                        float* const* dGh, float* workspace, size_t workspace_bytes, void* stream, int out_ld) {
+                        float* const* dGh, float* workspace, size_t workspace_bytes, void* stream, int out_ld,
+                        float* const* bounds) {
     if (n < 1 || n > MAXP) return RENET_ERR_BADARG;
     Layouts ly;
     int B_of[MAXP];
@@ -1412,6 +1445,7 @@ static int gru_bwd_impl(int npl, int n, const float* const* dh_last, const int32
     hipStream_t st = (hipStream_t)stream;
     const bool f32 = use_f32() && npl == 3;
     const bool steps = npl == 3 && !f32 && !use_persistent(H);
+    if (bounds && (f32 || steps || npl != 3)) return RENET_ERR_UNSUPPORTED;   // only the persistent bf16x6 kernel emits them
     int Bmax = 0;
     for (int k = 0; k < n; ++k) Bmax = B_of[k] > Bmax ? B_of[k] : Bmax;
     const size_t per = renet_gru_workspace(steps ? Bmax : 0, H);
@@ -1439,7 +1473,7 @@ static int gru_bwd_impl(int npl, int n, const float* const* dh_last, const int32
         ps.p[i].dh_last = dh_last[k]; ps.p[i].WhhT = WhhT; ps.p[i].saved = saved[k]; ps.p[i].dGi = dGi[k];
         ps.p[i].dGh = dGh[k];
         pb.p[i].dh_last = dh_last[k]; pb.p[i].WTp = planes; pb.p[i].saved = saved[k]; pb.p[i].dGi = dGi[k];
-        pb.p[i].dGh = dGh[k]; pb.p[i].out_ld = out_ld;
+        pb.p[i].dGh = dGh[k]; pb.p[i].out_ld = out_ld; pb.p[i].bound = bounds ? bounds[k] : nullptr;
         if (steps && i < n) {
             const size_t kp = kp_of(3 * H);
             stt[i] = carve_state(reinterpret_cast<char*>(workspace) + (size_t)i * per, H, Bmax, kp);

@@ -110,6 +110,9 @@ _SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_gru_bwd_layouts': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    'renet_gru_bound_parts': (c_int, [c_int]),
+    'renet_gru_bwd_layouts_bounds': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_gru_fwd_layouts_bf16': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_gru_bwd_layouts_bf16': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
@@ -1077,9 +1080,24 @@ def gru_bwd_layouts(dh_lasts, step_offs, hdim, w_hhs, saveds, out_bf16=False):
     ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
     so, ls = _offs(step_offs)
     t0 = _timer.begin() if _timer is not None else None
-    fn = lib().renet_gru_bwd_layouts_bf16 if GEMM_MODE == 'bf16s' else lib().renet_gru_bwd_layouts
-    _check(fn(n, _ptrs(dh_lasts), so, ls, hdim, _ptrs(w_hhs), _ptrs(saveds), _ptrs(d_gis),
-                                       _ptrs(d_ghs), ws.data_ptr(), nbytes, _stream()), 'gru_bwd_layouts')
+    done = False
+    if _fused_bounds(d_gis[0]) and bmax > 0:
+        # the kernel that writes dGi also emits its operand bound (one max |dGi| per workgroup)
+        nparts = lib().renet_gru_bound_parts(int(bmax))
+        parts = torch.empty(n, nparts, device=dev, dtype=torch.float32)
+        rc = lib().renet_gru_bwd_layouts_bounds(n, _ptrs(dh_lasts), so, ls, hdim, _ptrs(w_hhs), _ptrs(saveds),
+                                                _ptrs(d_gis), _ptrs(d_ghs), _ptrs([parts[k] for k in range(n)]),
+                                                ws.data_ptr(), nbytes, _stream())
+        if rc == 0:
+            for k in range(n):
+                _note_bound(d_gis[k], parts[k], nparts)
+            done = True
+        elif rc != -2:                                   # RENET_ERR_UNSUPPORTED: another recurrence is selected
+            _check(rc, 'gru_bwd_layouts_bounds')
+    if not done:
+        fn = lib().renet_gru_bwd_layouts_bf16 if GEMM_MODE == 'bf16s' else lib().renet_gru_bwd_layouts
+        _check(fn(n, _ptrs(dh_lasts), so, ls, hdim, _ptrs(w_hhs), _ptrs(saveds), _ptrs(d_gis),
+                  _ptrs(d_ghs), ws.data_ptr(), nbytes, _stream()), 'gru_bwd_layouts')
     if t0 is not None:
         _timer.end('gru_recurrence', t0, flops=sum(2.0 * 3 * hdim * hdim * s_.shape[0] for s_ in saveds))
     return d_gis, d_ghs
