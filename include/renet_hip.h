@@ -210,6 +210,10 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
  * nn.Linear model.py:89-90,98-99 and their backward GEMMs). */
 int renet_maxabs_blocks(int rows, int cols, int ld);
 int renet_maxabs_partials(const float* x, int rows, int cols, int ld, float* part, void* stream);
+/* renet_maxabs_partials for n_jobs CONTIGUOUS, 16-byte aligned arrays in one launch (a model's weights, once per
+ * optimizer step).  jobs: device array of n_jobs records {const float* x; uint64 n4 (number of float4); float* part;
+ * int32 nblocks (<= 256 partials written to part); int32 pad}. */
+int renet_maxabs_partials_multi(const void* jobs, int n_jobs, void* stream);
 int renet_gemm_f32_h3(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
                       int ldb, float beta, float* C, int ldc, const float* bias, int split_k, float* workspace,
                       size_t workspace_bytes, const float* maxA, int nA, const float* maxB, int nB, void* stream);

@@ -297,3 +297,27 @@ __global__ __launch_bounds__(256) void maxabs_partials_kernel(const float* __res
     if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+
+// The same for SEVERAL contiguous fp32 arrays in one launch (the weights of a model, once per optimizer step):
+// blockIdx.y = array, table[y] = {pointer, number of float4, pointer to its partials, number of partials}.
+struct MaxabsJob { const float* x; unsigned long long n4; float* part; int nblocks; int pad; };
+__global__ __launch_bounds__(256) void maxabs_multi_kernel(const MaxabsJob* __restrict__ jobs) {
+    __shared__ float red[4];
+    const MaxabsJob j = jobs[blockIdx.y];
+    if ((int)blockIdx.x >= j.nblocks) return;
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(j.x);
+    const size_t stride = (size_t)j.nblocks * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float m = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    for (; i + 3 * stride < j.n4; i += 4 * stride) {
+        const float4 v0 = p[i], v1 = p[i + stride], v2 = p[i + 2 * stride], v3 = p[i + 3 * stride];
+        m = max4(m, v0); m1 = max4(m1, v1); m2 = max4(m2, v2); m3 = max4(m3, v3);
+    }
+    for (; i < j.n4; i += stride) m = max4(m, p[i]);
+    m = fmaxf(fmaxf(m, m1), fmaxf(m2, m3));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) j.part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}

@@ -1607,6 +1607,14 @@ int renet_maxabs_partials(const float* x, int rows, int cols, int ld, float* par
     return RENET_OK;
 }
 
+int renet_maxabs_partials_multi(const void* jobs, int n_jobs, void* stream) {
+    if (n_jobs < 0 || (n_jobs > 0 && !jobs)) return RENET_ERR_BADARG;
+    if (n_jobs == 0) return RENET_OK;
+    RENET_LAUNCH(maxabs_multi_kernel, dim3(256, n_jobs), dim3(256), 0, (hipStream_t)stream, (const MaxabsJob*)jobs);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
 int renet_gemm_f32_h3(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
                       int ldb, float beta, float* C, int ldc, const float* bias, int split_k, float* workspace,
                       size_t workspace_bytes, const float* maxA, int nA, const float* maxB, int nB, void* stream) {

@@ -64,6 +64,7 @@ _SIGNATURES = {
                                 c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'renet_planes_bytes': (c_size_t, [c_int, c_int]),
     'renet_maxabs_blocks': (c_int, [c_int, c_int, c_int]),
+    'renet_maxabs_partials_multi': (c_int, [c_void_p, c_int, c_void_p]),
     'renet_maxabs_partials': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'renet_gemm_f32_h3': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                   c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_int,
@@ -535,9 +536,11 @@ _weight_epoch = [0]
 
 
 def register_weights(tensors):
+    import weakref
     for t in tensors:
         if t.dim() == 2 and t.is_contiguous():
             _weight_ptrs[t.data_ptr()] = tuple(t.shape)
+            _weight_objs[t.data_ptr()] = weakref.ref(t)
 
 
 def unregister_weights(tensors):
@@ -545,6 +548,7 @@ def unregister_weights(tensors):
         _weight_ptrs.pop(t.data_ptr(), None)
         _weight_cache.pop(t.data_ptr(), None)
         _weight_max.pop(t.data_ptr(), None)
+        _weight_objs.pop(t.data_ptr(), None)
 
 
 def weights_changed():
@@ -613,6 +617,37 @@ def maxabs_partials(x):
 _weight_max = {}               # data_ptr -> (epoch, part, n) of a registered weight
 
 
+_weight_jobs = {'key': None, 'table': None, 'parts': {}}     # one multi-array launch for all registered weights
+_weight_objs = {}              # data_ptr -> weakref of the registered weight (its torch version counter is read)
+
+
+def _measure_all_weights(device):
+    """-> {data_ptr: ((epoch, version), part, n)} for EVERY registered weight that is alive, contiguous, 16-byte aligned
+    and a multiple of 4 elements long, from one launch (renet_maxabs_partials_multi)."""
+    live = {p: r() for p, r in _weight_objs.items()}
+    ptrs = sorted(p for p, t in live.items() if t is not None and t.is_cuda and t.device == device and p in _weight_ptrs
+                  and t.numel() % 4 == 0 and p % 16 == 0 and t.data_ptr() == p)
+    key = (tuple(ptrs), str(device))
+    if _weight_jobs['key'] != key:
+        rows, parts = [], {}
+        for p in ptrs:
+            shp = _weight_ptrs[p]
+            nb = lib().renet_maxabs_blocks(shp[0], shp[1], shp[1])
+            part = torch.empty(nb, device=device, dtype=torch.float32)
+            parts[p] = (part, nb)
+            rows.append([p, shp[0] * shp[1] // 4, part.data_ptr(), nb])        # {x, n4, part, nblocks | pad}
+        _weight_jobs.update(key=key, parts=parts,
+                            table=torch.tensor(rows, dtype=torch.int64).to(device) if rows else None)
+    if _weight_jobs['table'] is None:
+        return {}
+    t0 = _timer.begin() if _timer is not None else None
+    _check(lib().renet_maxabs_partials_multi(_weight_jobs['table'].data_ptr(), len(ptrs), _stream()),
+           'maxabs_partials_multi')
+    if t0 is not None:
+        _timer.end('maxabs', t0, nbytes=float(sum(_weight_ptrs[p][0] * _weight_ptrs[p][1] * 4 for p in ptrs)))
+    return {p: ((_weight_epoch[0], live[p]._version), part, nb) for p, (part, nb) in _weight_jobs['parts'].items()}
+
+
 def _weight_or_measured_max(x):
     """A registered weight's maxima are cached until the next optimizer step (a leading row / column block of the
     weight is bounded by the whole weight's); anything else is measured."""
@@ -620,9 +655,13 @@ def _weight_or_measured_max(x):
     shp = _weight_ptrs.get(ptr)
     if shp is not None and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) == shp[1] and \
             x.shape[0] <= shp[0] and x.shape[1] <= shp[1]:
-        ent = _weight_max.get(ptr)
         stamp = (_weight_epoch[0], x._version)      # in-place torch writes (load_state_dict) bump _version
-        if ent is None or ent[0] != stamp:
+        ent = _weight_max.get(ptr)
+        if ent is None or ent[0][0] != _weight_epoch[0]:
+            # first request after an optimizer step: every registered weight changed -- ONE launch measures them all
+            _weight_max.update(_measure_all_weights(x.device))
+            ent = _weight_max.get(ptr)
+        if ent is None or ent[0] != stamp:          # not coverable by the joint launch, or modified since: on its own
             part, n = maxabs_partials(torch.as_strided(x, shp, (shp[1], 1)))
             ent = (stamp, part, n)
             _weight_max[ptr] = ent
