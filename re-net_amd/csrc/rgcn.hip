@@ -983,12 +983,17 @@ int renet_gather_rows(const float* table, const int32_t* idx, int n, int D, floa
     return RENET_OK;
 }
 
+// Workgroups of a segmented add over U segments: one per segment while that still fills the chip (a plan over 20
+// relations is 20 long segments -- 16 of them dealt to ONE workgroup would be walked one after the other), 16
+// segments per workgroup beyond that.
+static int seg_grid(int U) { return U <= 512 ? U : max(512, (U + kSegWaves - 1) / kSegWaves); }
+
 int renet_segment_add(const float* src, const int32_t* order, const int32_t* seg_ptr,
                       const int32_t* seg_target, int U, int D, float* dst, void* stream) {
     if (U < 0 || D <= 0 || (D & 3)) return RENET_ERR_BADARG;
     if (U == 0) return RENET_OK;
     if (D > 512) return RENET_ERR_UNSUPPORTED;
-    RENET_LAUNCH(segment_add_kernel, dim3((U + kSegWaves - 1) / kSegWaves), dim3(kSegWaves * 64), 0,
+    RENET_LAUNCH(segment_add_kernel, dim3(seg_grid(U)), dim3(kSegWaves * 64), 0,
                        (hipStream_t)stream, (const float4*)src, (const float4*)src, order, seg_ptr, seg_target, U, D / 4,
                        (float4*)dst, (float4*)dst);
     RENET_LAUNCH_CHECK();
@@ -1000,7 +1005,7 @@ int renet_segment_add2(const float* src0, const float* src1, const int32_t* orde
     if (U < 0 || D <= 0 || (D & 3)) return RENET_ERR_BADARG;
     if (U == 0) return RENET_OK;
     if (D > 512) return RENET_ERR_UNSUPPORTED;
-    RENET_LAUNCH(segment_add_kernel, dim3((U + kSegWaves - 1) / kSegWaves, 2), dim3(kSegWaves * 64), 0,
+    RENET_LAUNCH(segment_add_kernel, dim3(seg_grid(U), 2), dim3(kSegWaves * 64), 0,
                        (hipStream_t)stream, (const float4*)src0, (const float4*)src1, order, seg_ptr, seg_target, U, D / 4,
                        (float4*)dst0, (float4*)dst1);
     RENET_LAUNCH_CHECK();
