@@ -666,26 +666,7 @@ def _weight_or_measured_max(x):
             ent = (stamp, part, n)
             _weight_max[ptr] = ent
         return ent[1], ent[2]
-    # an nn.Parameter (or a leading block of one) outside any registered optimizer -- inference, evaluation: its maxima
-    # are cached against torch's version counter (torch optimizers and load_state_dict write in place and bump it; the
-    # raw-pointer updates of parallel.HipAdam are covered by the registration above)
-    base = x._base if x._base is not None else x
-    if isinstance(base, torch.nn.Parameter) and base.dim() == 2 and base.is_contiguous() and x.dim() == 2 and \
-            x.data_ptr() == base.data_ptr() and x.stride(1) == 1 and x.stride(0) == base.shape[1] and \
-            x.shape[0] <= base.shape[0] and x.shape[1] <= base.shape[1]:
-        stamp = (base._version, tuple(base.shape))
-        ent = _param_max.get(ptr)
-        if ent is None or ent[0] != stamp:
-            if len(_param_max) > 64:
-                _param_max.clear()
-            part, n = maxabs_partials(base.detach())
-            ent = (stamp, part, n)
-            _param_max[ptr] = ent
-        return ent[1], ent[2]
     return maxabs_partials(x)
-
-
-_param_max = {}                # data_ptr -> ((version, shape), part, n) of an unregistered nn.Parameter
 
 
 def _f32op(x, bound=None):
