@@ -60,7 +60,7 @@ def parse():
                          'batch of --batch quadruples per step, every rank builds its graph and keeps 1/N of the '
                          'sequences, gradients are summed (SURVEY 8e option (i): N-GPU step == 1-GPU step)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
-                    help="f32: fp32-class GEMMs (bf16x6 split, or exact fp32 with RENET_GEMM=f32); bf16: GEMM operands "
+                    help="f32: fp32-class GEMMs (f16x3 split; RENET_GEMM=bf16x6 | f32 select the 24-bit split / exact fp32); bf16: GEMM operands "
                          "rounded to bf16, fp32 accumulate (BASELINE config 5)")
     ap.add_argument('--passes', choices=('merged', 'pair', 'serial'), default='merged',
                     help='how a step runs the subject and the object pass of its batch (train.py:136-138): merged = '
@@ -70,7 +70,8 @@ def parse():
                     help='run the subject and object passes strictly one after the other (RENet.loss_prepared twice) '
                          'instead of RENet.loss_prepared_pair')
     ap.add_argument('--f32-steps', type=int, default=40,
-                    help='steps of the exact-fp32 companion run (RENET_GEMM=f32, child process; 0 = skip)')
+                    help='steps of the companion runs in the other fp32-class GEMM modes (RENET_GEMM=f32, and bf16x6 when the '
+                         'default f16x3 mode is timed; child processes; 0 = skip)')
     return ap.parse_args()
 
 
@@ -463,21 +464,28 @@ def main():
                   'grad_sampled_max_err_over_max': float(np.abs(g_hip[samp] - g_ref[samp]).max() / np.abs(g_ref).max()),
                   'grad_tolerance': 5e-2 if args.dtype == 'bf16' else 2e-3}
 
-    # ---- exact-fp32 companion (RENET_GEMM=f32: v_mfma_f32_32x32x2_f32 products instead of bf16x6) ------------
-    exact = None
-    if args.f32_steps > 0 and world == 1 and K.GEMM_MODE in ('bf16x6', 'f16x3'):
+    # ---- companions in the other fp32-class GEMM modes (child processes): RENET_GEMM=f32 = exact fp32 products
+    # (v_mfma_f32_32x32x2_f32); in f16x3 mode (22-bit operand split) also RENET_GEMM=bf16x6, the 24-bit split that was
+    # the default of rounds 1-2 -- so that the line carries the rate at every precision level it can be read against
+    def companion(gemm_env):
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.f32_steps), '--warmup', str(args.warmup),
                '--shape', args.shape, '--batch', str(args.batch), '--hidden', str(args.hidden), '--seq-len',
                str(args.seq_len), '--dropout', str(args.dropout), '--cpu-steps', '0', '--e2e-steps', '0',
-               '--f32-steps', '0', '--passes', args.passes]
-        r = subprocess.run(cmd, env=dict(os.environ, RENET_GEMM='f32'), capture_output=True, text=True)
+               '--f32-steps', '0', '--enc-steps', '0', '--passes', args.passes]
+        r = subprocess.run(cmd, env=dict(os.environ, RENET_GEMM=gemm_env), capture_output=True, text=True)
         try:
             j = json.loads(r.stdout.strip().splitlines()[-1])
-            exact = {'value': j['value'], 'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'gemm_mode': 'f32',
-                     'last_loss': j['last_loss']}
+            return {'value': j['value'], 'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'gemm_mode': gemm_env,
+                    'last_loss': j['last_loss']}
         except (ValueError, IndexError, KeyError):
-            exact = {'error': (r.stderr or r.stdout)[-300:]}
+            return {'error': (r.stderr or r.stdout)[-300:]}
+
+    exact = x6 = None
+    if args.f32_steps > 0 and world == 1 and K.GEMM_MODE in ('bf16x6', 'f16x3'):
+        exact = companion('f32')
+        if K.GEMM_MODE == 'f16x3':
+            x6 = companion('bf16x6')
 
     out = {
         'metric': 'RGCN+GRU encoder triples/s at bs=%d n_hidden=%d (full training step, both directions)'
@@ -498,7 +506,14 @@ def main():
                         'value': rank_batch / max(sum(e_['ms_per_step'] for e_ in kernels.values()) * 1e-3, 1e-12),
                         'what': 'sum of the HIP-event durations of the timed C-ABI kernel classes per step (the classes '
                                 'listed in `kernels`; untimed glue launches are not included)'},
-        'value_exact_f32': exact, 'pmc_source': pmc_file,
+        'value_exact_f32': exact, 'value_bf16x6': x6,
+        'precision': {'f16x3': 'fp32 storage; GEMM operands split into two tensor-scaled binary16 planes (22 significant '
+                               'bits), three f16 MFMA products, fp32 accumulation (DESIGN 3f)',
+                      'bf16x6': 'fp32 storage; GEMM operands split into three bf16 planes (24 bits), six bf16 MFMA '
+                                'products, fp32 accumulation',
+                      'f32': 'fp32 storage, exact fp32 MFMA products', 'bf16s': 'bf16 storage of the GEMM operands',
+                      'bf16': 'fp32 storage, operands rounded to bf16 in the GEMM loaders'}.get(K.GEMM_MODE),
+        'pmc_source': pmc_file,
         'traffic_source': ('%s: rocprofv3 --pmc passes of this command (tools/pmc_traffic.py), NOT measured in this run' % pmc_file) if pmc_file else None, 'kernels': kernels, 'gemm_shapes': gemm_shapes, 'cpu_baseline': cpu,
         'host_build_ms': host_build_ms, 'e2e_value': e2e, 'e2e_workers': e2e_workers, 'e2e_inline': e2e_inline, 'e2e_threads8': e2e_threads,
         'e2e_device_builder': e2e_device_builder, 'device_build_ms': device_build_ms,

@@ -197,10 +197,12 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
                          int split_k, float* workspace, size_t workspace_bytes, void* stream);
 
 /* Same contract as renet_gemm_f32 on the f16 matrix cores ("f16x3", csrc/gemm_h3.h): every operand value, scaled by
- * a power of two of its tensor so that max |x| lands in (2^14, 2^15], is split into two binary16 terms
- * x s = h1 + 2^-11 h2 and a b is evaluated as a1 b1 + 2^-11 (a1 b2 + a2 b1) with fp32 accumulation: the dropped
- * term and the split error are <= 2^-24 relative for every element with |x| >= 2^-29 max |x| (smaller elements keep
- * an ABSOLUTE error <= 2^-39 max |x|) -- fp32-class results with three matrix instructions per fragment pair
+ * a power of two of its tensor so that max |x| lands in [2^14, 2^15), is split into two binary16 terms
+ * x s = h1 + 2^-11 h2 (22 significant bits) and a b is evaluated as a1 b1 + 2^-11 (a1 b2 + a2 b1) with fp32
+ * accumulation: split error and dropped term are each <= 2^-22 relative for every element with |x| >= 2^-29 max |x|
+ * (smaller elements keep an ABSOLUTE error <= 2^-39 max |x|), unbiased, so that a K-long dot product stays within a
+ * small multiple of the error of fp32 products with fp32 accumulation (measured next to renet_gemm_f32 and
+ * renet_gemm_f32_split in tests/test_gpu_parity.py) -- with three matrix instructions per fragment pair
  * instead of six.  maxA / maxB: nA / nB (1..1024) device floats whose largest magnitude bounds max |A| / max |B|
  * from above -- the output of renet_maxabs_partials, or any bound the caller knows (a bound 2^k too large costs k of
  * the 29 binades).  A bound that is too SMALL overflows binary16: undefined results (inf / NaN).

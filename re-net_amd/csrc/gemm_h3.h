@@ -3,15 +3,18 @@
 // fp32-accurate GEMM on the f16 matrix cores of gfx950 ("f16x3 split", renet_gemm_f32_h3):
 //
 //   every fp32 operand value, multiplied by a power-of-two scale s of its TENSOR (so that max |x| s lies in
-//   (2^14, 2^15]), is split into TWO binary16 terms   x s = h1 + 2^-11 h2,   h1 = rne16(x s),  h2 = rne16((x s - h1) 2^11)
-//   (both subtractions / scalings exact in fp32; |x s - h1 - 2^-11 h2| <= 2^-24 |x s| while h1 is a normal fp16, i.e. for
-//   |x| >= 2^-29 max |x|; below that the ABSOLUTE error stays <= 2^-39 max |x|), and the product a*b is evaluated as
+//   [2^14, 2^15)), is split into TWO binary16 terms   x s = h1 + 2^-11 h2,   h1 = rne16(x s),  h2 = rne16((x s - h1) 2^11)
+//   (both subtractions / scalings exact in fp32).  Two 11-bit significands: |x s - h1 - 2^-11 h2| <= 2^-22 |x s| while h1
+//   is a normal fp16, i.e. for |x| >= 2^-29 max |x|; below that the ABSOLUTE error stays <= 2^-39 max |x|.  The product
+//   a*b is evaluated as
 //        a1 b1  +  2^-11 (a1 b2 + a2 b1)
 //   on v_mfma_f32_32x32x16_f16 with two fp32 accumulators per output element (the 2^-11 is applied once, in the
-//   epilogue; the dropped pair a2 b2 2^-22 is <= 2^-24 |a b|).  f16 x f16 products are exact in fp32.  THREE matrix
-//   instructions per fragment pair where the bf16x6 split needs six, two LDS planes per operand instead of three:
-//   the bf16 split spends 16 of a plane's bits on fp32's exponent range, which a GEMM operand does not need per
-//   ELEMENT once the tensor's magnitude is factored out.
+//   epilogue; the dropped pair a2 b2 2^-22 is <= 2^-22 |a b|): every product is accurate to ~2^-21 (worst case; the
+//   errors are unbiased and average out along k -- a K-long dot product comes out within a small multiple of what fp32
+//   products with fp32 accumulation give, tests/test_gpu_parity.py).  f16 x f16 products are exact in fp32.  THREE
+//   matrix instructions per fragment pair where the bf16x6 split (24 significant bits, worst case 2^-23) needs six,
+//   two LDS planes per operand instead of three: the bf16 split spends 16 of a plane's bits on fp32's exponent range,
+//   which a GEMM operand does not need per ELEMENT once the tensor's magnitude is factored out.
 //
 // The tensor scale comes from a bound on max |x|: renet_maxabs_partials (one pass over an activation, <= 256 partial
 // maxima; a weight's are cached per optimizer step by the caller) or any upper bound the producer knows (the CE
@@ -31,7 +34,7 @@ struct H3Args {
     int nA, nB;
 };
 
-// 2^(15 - e) for bound = m 2^e, m in [0.5, 1): bound * scale in (2^14, 2^15].  (0, denormal: the largest scale.)
+// 2^(15 - e) for bound = m 2^e, m in [0.5, 1): bound * scale in [2^14, 2^15).  (0, denormal: the largest scale.)
 __device__ __forceinline__ float h3_scale_of(float bound, float& inv) {
     const uint32_t E = (__float_as_uint(bound) >> 23) & 0xffu;
     int f = 268 - (int)E;                      // exponent field of the scale

@@ -491,8 +491,9 @@ def auto_split_k(m, n, k):
 # 'f32'    : v_mfma_f32_32x32x2_f32, exact fp32 products (gemm.hip)
 # 'bf16x6' : fp32 operands split into 3 bf16 terms, 6 term products on v_mfma_f32_32x32x16_bf16 with fp32
 #            accumulation (gemm_split.hip): fp32-class accuracy at 2.67x the matrix-pipe rate
-# 'f16x3'  : fp32 operands, scaled per TENSOR by a power of two, split into 2 binary16 terms, 3 term products on
-#            v_mfma_f32_32x32x16_f16 (gemm_h3.h): fp32-class accuracy with half the matrix instructions of bf16x6
+# 'f16x3'  : fp32 operands, scaled per TENSOR by a power of two, split into 2 binary16 terms (22 significant bits),
+#            3 term products on v_mfma_f32_32x32x16_f16 (gemm_h3.h): GEMM errors within a small multiple of fp32's
+#            own accumulation error (include/renet_hip.h), half the matrix instructions of bf16x6
 GEMM_MODE = os.environ.get('RENET_GEMM', 'f16x3')       # RENET_GEMM=bf16x6 | f32 select the other fp32-class kernels
 
 
