@@ -158,3 +158,56 @@ def test_sequence_shards_of_one_batch_sum_to_the_batch():
             assert float((flat.flat - gf).abs().max()) <= 4e-6 * float(gf.abs().max()), world
     finally:
         undo()
+
+
+def test_dual_head_function_equals_two_head_functions_over_emulated_kernels():
+    """ops.DualHeadCEFn (both score heads + their weighted sum as one Function) against two ops.HeadCEFn calls combined
+    by autograd, kernels emulated in torch-CPU: loss and every gradient, with and without pre-existing .grad buffers
+    (the in-place accumulation targets of the training step)."""
+    import cpu_abi_emulation
+    import ops
+    undo = cpu_abi_emulation.install()
+    try:
+        rng = np.random.RandomState(4)
+        b, n_ent, n_rel, d = 48, 90, 14, 8
+        ia = torch.from_numpy(rng.randint(0, n_ent, b).astype(np.int32))
+        ic = torch.from_numpy(rng.randint(0, n_rel, b).astype(np.int32))
+        t1 = torch.from_numpy(rng.randint(0, n_ent, b).astype(np.int32))
+        t2 = torch.from_numpy(rng.randint(0, n_rel, b).astype(np.int32))
+
+        def plan(idx):
+            h = G.SegPlan.host(idx.numpy())
+            p = G.SegPlan()
+            p.order, p.seg_ptr, p.target = (torch.from_numpy(np.ascontiguousarray(a)) for a in
+                                            (h.order, h.seg_ptr, h.target))
+            p.num_segments = h.num_segments
+            return p
+        plan_a, plan_c = plan(ia), plan(ic)
+        base = {n: torch.from_numpy(rng.randn(*shp).astype(np.float32) * 0.3) for n, shp in (
+            ('ent', (n_ent, d)), ('rel', (n_rel, d)), ('h1', (b, d)), ('h2', (b, d)), ('w1', (n_ent, 3 * d)),
+            ('b1', (n_ent,)), ('w2', (n_rel, 2 * d)), ('b2', (n_rel,)))}
+
+        def run(dual, with_buffers):
+            L = {n: v.clone().requires_grad_(True) for n, v in base.items()}
+            if with_buffers:
+                for n in ('ent', 'rel', 'w1', 'b1', 'w2', 'b2'):
+                    L[n].grad = torch.full_like(L[n], 0.5)
+            if dual:
+                loss = ops.DualHeadCEFn.apply(L['ent'], ia, L['h1'], L['rel'], ic, L['w1'], L['b1'], t1, L['h2'], L['w2'],
+                                              L['b2'], t2, plan_a, plan_c, 0.0, 0, 0, 2.0, 0.1)
+            else:
+                l1 = ops.HeadCEFn.apply(L['ent'], ia, L['h1'], L['rel'], ic, L['w1'], L['b1'], t1, plan_a, plan_c, 0.0,
+                                        0, 2.0)
+                l2 = ops.HeadCEFn.apply(L['ent'], ia, L['h2'], None, None, L['w2'], L['b2'], t2, plan_a, None, 0.0, 0,
+                                        2.0)
+                loss = l1 + 0.1 * l2
+            loss.backward()
+            return float(loss), {n: L[n].grad.clone() for n in L}
+        for with_buffers in (False, True):
+            l_ref, g_ref = run(False, with_buffers)
+            l_new, g_new = run(True, with_buffers)
+            assert abs(l_new - l_ref) <= 1e-6 * abs(l_ref)
+            for n in g_ref:
+                assert torch.allclose(g_new[n], g_ref[n], rtol=1e-5, atol=1e-7), n
+    finally:
+        undo()
