@@ -8,8 +8,15 @@ n_hidden=200, seq_len=10, batch=1024 per GPU, dropout 0.5, fp32, random-init wei
 Inputs are device-resident when the timed region starts: the batch graphs / packed layouts of the
 W+K steps are prepared (host builder + one upload each) before it; the per-step host build time is
 reported separately (`host_build_ms`) and an end-to-end rate with the builder in the loop as
-`e2e_value`.  Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under
-torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+`e2e_value`.  Launch: python bench.py [--gpus N --steps K --warmup W].  For N > 1 either under
+torch.distributed.run (one rank per GPU, RCCL: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or
+plainly -- without WORLD_SIZE in the environment the script re-executes itself under torch.distributed.run with N
+ranks on 127.0.0.1.  Rank 0 prints ONE JSON line.
+
+Precision (round 4): `value` is timed in the DEFAULT fp32-class GEMM mode, bf16x6 (fp32 storage, every operand split
+into three bf16 planes = all 24 significand bits, six MFMA products, fp32 accumulation).  The two other modes run as
+child processes of the same command and are reported as full records `value_f16x3` (22-bit operands, the fast mode)
+and `value_exact_f32` (exact fp32 MFMA products), each with its own kernels / gemm_shapes / roofline.
 """
 import argparse
 import json
@@ -70,9 +77,28 @@ def parse():
                     help='run the subject and object passes strictly one after the other (RENet.loss_prepared twice) '
                          'instead of RENet.loss_prepared_pair')
     ap.add_argument('--f32-steps', type=int, default=40,
-                    help='steps of the companion runs in the other fp32-class GEMM modes (RENET_GEMM=f32, and bf16x6 when the '
-                         'default f16x3 mode is timed; child processes; 0 = skip)')
+                    help='steps of the companion runs in the OTHER fp32-class GEMM modes (of bf16x6 / f16x3 / f32; child '
+                         'processes, full records; 0 = skip)')
+    ap.add_argument('--other-steps', type=int, default=20,
+                    help='steps of the other BASELINE.json configs (WIKI-shaped, GDELT-shaped, YAGO-shaped n_hidden 400 '
+                         'seq_len 15 bf16 storage), each a child process reported under `other_configs` (0 = skip)')
+    ap.add_argument('--child', default='', help='(internal) this run is a companion of another: print the reduced record')
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: re-execute under torch.distributed.run, N ranks on this
+    node, rendezvous on 127.0.0.1 (the container hostname may not resolve).  Returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -80,16 +106,34 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus:
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))          # no launcher around us: start the N ranks ourselves
+    if world != args.gpus and rank == 0:
+        sys.stderr.write('WORLD_SIZE (%d) != --gpus (%d): running with %d ranks\n' % (world, args.gpus, world))
+    if os.environ.get('RENET_BENCH_LAUNCH_CHECK') == '1':
+        # launcher self-test (tests/test_parallel_cpu.py, no GPU needed): the ranks started above rendezvous over gloo,
+        # all-reduce a one, and rank 0 prints the line's launch fields; nothing is measured
+        if world > 1:
+            dist.init_process_group('gloo')
+            ones = torch.ones(1)
+            dist.all_reduce(ones)
+            seen = int(ones.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            seen = 1
         if rank == 0:
-            sys.stderr.write('WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run\n' % (world, args.gpus))
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(2)
+            print(json.dumps({'launcher_check': True, 'n_gpus': world, 'rccl_ranks_seen': seen, 'gpus_arg': args.gpus}))
+        return
     assert torch.cuda.is_available(), 'bench.py needs a HIP device (no CPU fallback exists)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    ranks_seen = 1
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                        # RCCL is really connecting `world` ranks
+        ranks_seen = int(round(float(ones.item())))
 
     import renet_hip as K
     K.lib()
@@ -166,19 +210,22 @@ def main():
                 opt.step()                   # gradient all-reduce (N>1) -> clip -> Adam -> zero_grad
             return loss
 
-        def run(self, timer=None):
+        def run(self, timer=None, prepared=None):
             """W untimed + K timed steps on device-resident batches -> (elapsed seconds [max over ranks], last
-            loss, host build ms per step, the prepared batches)."""
+            loss, host build ms per step, the prepared batches).  timer: a K.KernelTimer -- HIP events around every
+            C-ABI launch (one stream, serial launches); `value` comes from a run WITHOUT one."""
             n_total = args.warmup + args.steps
-            t0 = time.time()
-            prepared = [self.prepare(k) for k in range(n_total)]
-            torch.cuda.synchronize()
-            host_ms = (time.time() - t0) * 1e3 / max(n_total, 1)
+            host_ms = None
+            if prepared is None:
+                t0 = time.time()
+                prepared = [self.prepare(k) for k in range(n_total)]
+                torch.cuda.synchronize()
+                host_ms = (time.time() - t0) * 1e3 / max(n_total, 1)
             for k in range(args.warmup):
                 self.train_step(*prepared[k])
             assert flat.check_views(), 'param.grad views were replaced'
             if timer is not None:
-                K.set_timer(timer)
+                K.set_timer(timer, glue=True)            # every C-ABI launch of the step is timed (classes 'glue:*')
             sync_all()
             t0 = time.perf_counter()
             for k in range(args.warmup, n_total):
@@ -198,9 +245,13 @@ def main():
     exact_split, rank_batch = mode.exact, mode.rank_batch
     prepare, step_loss, train_step = mode.prepare, mode.step_loss, mode.train_step
     n_total = args.warmup + args.steps
-    timer = K.KernelTimer()
-    elapsed, last_loss, host_build_ms, prepared = mode.run(timer)
+    # the timed region of `value`: the product configuration (side streams on, no per-kernel events) ...
+    elapsed, last_loss, host_build_ms, prepared = mode.run()
     value = mode.global_batch * args.steps / elapsed
+    # ... then the SAME K steps once more with HIP events around every C-ABI launch: the per-class kernel table, the
+    # roofline's average launch durations and `kernel_only` come from this second pass (its wall time is reported too)
+    timer = K.KernelTimer()
+    elapsed_timed, _, _, _ = mode.run(timer, prepared)
 
     # ---- N > 1: the other scaling modes of the same step, so that the line is explicit about global batch size ----
     companions = {}
@@ -345,18 +396,20 @@ def main():
     # `traffic`: HBM bytes per launch.  Hardware counters cannot be read from inside the process: they come from
     # the rocprofv3 --pmc passes of this same command (FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled
     # for 16 B/lane reads per MI355X_MICROARCH.md; tools/pmc_traffic.py), committed under profiles/ -- the newest
-    # round's file is used, and only for the workload it was collected on; otherwise null.
+    # file collected in THIS GEMM mode is used, and only for the workload it was collected on; otherwise null.
     pmc, pmc_file = {}, None
+    legacy_mode = {'r02_pmc_traffic.json': 'bf16x6', 'r03_pmc_traffic.json': 'f16x3'}
     for name in sorted(os.listdir(os.path.join(ROOT, 'profiles')), reverse=True) \
             if os.path.isdir(os.path.join(ROOT, 'profiles')) else []:
-        if name.endswith('_pmc_traffic.json'):
+        if '_pmc_traffic' in name and name.endswith('.json'):
             try:
                 with open(os.path.join(ROOT, 'profiles', name)) as f:
-                    pmc = json.load(f).get('classes', {})
-                pmc_file = 'profiles/' + name
-                break
+                    rec = json.load(f)
             except (OSError, ValueError):
-                pmc = {}
+                continue
+            if rec.get('gemm_mode', legacy_mode.get(name)) == K.GEMM_MODE:
+                pmc, pmc_file = rec.get('classes', {}), 'profiles/' + name
+                break
     same_workload = (args.shape == 'ICEWS18' and args.batch == 1024 and args.hidden == 200 and args.seq_len == 10)
 
     def traffic_of(name):
@@ -375,6 +428,8 @@ def main():
     # per-shape view of the GEMM class (row counts that vary with the batch graph are rounded to thousands)
     merged = {}
     for tag, o in timer.by_tag('gemm_f32').items():
+        if tag is None:
+            continue
         key = tuple(tag[:2]) + tuple(v if v <= 2048 or v == num_ent else int(round(v, -3)) for v in tag[2:5]) + (tag[5],)
         mo = merged.setdefault(key, {'calls': 0, 'ms': 0.0, 'flops': 0.0})
         for f in mo:
@@ -383,27 +438,30 @@ def main():
                     'avg_us': round(o['ms'] * 1e3 / o['calls'], 2),
                     'tflops': round(o['flops'] / (o['ms'] * 1e-3) / 1e12, 1)}
                    for key, o in sorted(merged.items(), key=lambda kv: -kv[1]['ms'])]
-    dom = max(stats, key=lambda n: stats[n]['ms']) if stats else None
+    named = {n: st for n, st in stats.items() if not n.startswith('glue:')}
+    dom = max(named, key=lambda n: named[n]['ms']) if named else None
+    # matrix-pipe ceilings for ALGORITHMIC fp32 flops (2MNK) per GEMM mode: f32 = the f32-input MFMA peak; bf16x6 = six
+    # bf16 products per fp32 product, dense bf16 peak / 6; f16x3 = three f16 products, / 3; bf16 / bf16s = one product
+    gemm_peak = {'f16x3': MFMA_BF16_PEAK_TF / 3.0, 'bf16x6': MFMA_BF16_PEAK_TF / 6.0, 'bf16': MFMA_BF16_PEAK_TF,
+                 'bf16s': MFMA_BF16_PEAK_TF}.get(K.GEMM_MODE, MFMA_F32_PEAK_TF)
+    gemm_note = {'f16x3': 'algorithmic fp32 TFLOP/s; peak = f16 dense 2500/3 (three f16 MFMA products per fp32 product)',
+                 'bf16x6': 'algorithmic fp32 TFLOP/s; peak = bf16 dense 2500/6 (six bf16 MFMA products per fp32 '
+                           'product)', 'bf16': 'bf16 dense MFMA peak',
+                 'bf16s': 'bf16 dense MFMA peak (bf16 operands in HBM)'}.get(K.GEMM_MODE, 'f32-input MFMA peak')
     roofline = None
     if dom:
         st = stats[dom]
         if st['flops']:
-            # `achieved` counts the ALGORITHMIC fp32 flops (2MNK).  In f16x3 mode every fp32 product is three f16
-            # MFMA products (fp32-class result), so the matrix-pipe ceiling for algorithmic flops is the dense
-            # f16 peak / 3; bf16x6: six bf16 products, dense bf16 peak / 6; f32 mode: the f32-input MFMA peak.
             ach = st['flops'] / (st['ms'] * 1e-3) / 1e12
-            peak = {'f16x3': MFMA_BF16_PEAK_TF / 3.0, 'bf16x6': MFMA_BF16_PEAK_TF / 6.0, 'bf16': MFMA_BF16_PEAK_TF,
-                    'bf16s': MFMA_BF16_PEAK_TF}.get(K.GEMM_MODE, MFMA_F32_PEAK_TF)
-            note = {'f16x3': 'algorithmic fp32 TFLOP/s; peak = f16 dense 2500/3 (three f16 MFMA products per fp32 '
-                             'product; the bf16x6 split of rounds 1-2 had 2500/6 = 416.7)',
-                    'bf16x6': 'algorithmic fp32 TFLOP/s; peak = bf16 dense 2500/6 (six bf16 MFMA products per fp32 '
-                              'product)', 'bf16': 'bf16 dense MFMA peak', 'bf16s': 'bf16 dense MFMA peak (bf16 operands in HBM)'}.get(K.GEMM_MODE, 'f32-input MFMA peak')
-            roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': peak,
-                        'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': traffic_of(dom),
-                        'gemm_mode': K.GEMM_MODE, 'note': note}
-            if K.GEMM_MODE == 'f16x3':
-                # continuity with rounds 1-2, whose fp32-class GEMM needed six matrix instructions per product
-                roofline['frac_of_bf16x6_ceiling'] = ach / (MFMA_BF16_PEAK_TF / 6.0)
+            operand_bytes = None
+            if dom == 'gemm_f32' and merged:
+                # operands + outputs of the class per launch (fp32 elements; what `traffic` is to be read against)
+                tot = sum(o['calls'] * 4.0 * (k_[2] * k_[4] + k_[3] * k_[4] + k_[2] * k_[3]) for k_, o in merged.items())
+                operand_bytes = tot / max(1, sum(o['calls'] for o in merged.values()))
+            roofline = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': gemm_peak,
+                        'unit': 'TFLOP/s', 'frac': ach / gemm_peak, 'traffic': traffic_of(dom),
+                        'operand_bytes_per_launch': operand_bytes, 'avg_us': st['ms'] * 1e3 / st['calls'],
+                        'calls_per_step': st['calls'] / args.steps, 'gemm_mode': K.GEMM_MODE, 'note': gemm_note}
         else:
             ach = st['bytes'] / (st['ms'] * 1e-3) / 1e9
             roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -427,10 +485,16 @@ def main():
     if 'gru_recurrence' in stats:
         st = stats['gru_recurrence']
         ach = st['flops'] / (st['ms'] * 1e-3) / 1e12
-        peak = MFMA_BF16_PEAK_TF / 6.0 if K.GEMM_MODE in ('bf16x6', 'f16x3') else MFMA_F32_PEAK_TF   # (bf16x6 products)
+        # the recurrent products run bf16x6 in both split modes, exact fp32 MFMAs in f32 mode, one bf16 product in the
+        # bf16 modes (gru.hip)
+        peak = {'bf16x6': MFMA_BF16_PEAK_TF / 6.0, 'f16x3': MFMA_BF16_PEAK_TF / 6.0, 'bf16': MFMA_BF16_PEAK_TF,
+                'bf16s': MFMA_BF16_PEAK_TF}.get(K.GEMM_MODE, MFMA_F32_PEAK_TF)
         gru = {'kernel': 'gru_fwd/bwd recurrence (both encoders per launch)', 'bound': 'mfma', 'achieved': ach,
                'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'avg_us': st['ms'] * 1e3 / st['calls'],
-               'calls_per_step': st['calls'] / args.steps}
+               'calls_per_step': st['calls'] / args.steps,
+               'note': 'products: %s; in practice bound by the W_hh stream L2 -> LDS (DESIGN 4c)' % (
+                   {'bf16x6': 'bf16x6', 'f16x3': 'bf16x6', 'bf16': 'one bf16 plane', 'bf16s': 'one bf16 plane'}.get(
+                       K.GEMM_MODE, 'exact fp32'))}
 
     # ---- CPU baseline: the oracle (restated reference path) on this box's host cores; the same oracle steps give
     # the parity check: HIP eval-mode loss vs oracle loss on identical batches and (current) parameters ----------
@@ -464,36 +528,64 @@ def main():
                   'grad_sampled_max_err_over_max': float(np.abs(g_hip[samp] - g_ref[samp]).max() / np.abs(g_ref).max()),
                   'grad_tolerance': 5e-2 if args.dtype == 'bf16' else 2e-3}
 
-    # ---- companions in the other fp32-class GEMM modes (child processes): RENET_GEMM=f32 = exact fp32 products
-    # (v_mfma_f32_32x32x2_f32); in f16x3 mode (22-bit operand split) also RENET_GEMM=bf16x6, the 24-bit split that was
-    # the default of rounds 1-2 -- so that the line carries the rate at every precision level it can be read against
-    def companion(gemm_env):
+    # ---- companions (child processes of this command): the other fp32-class GEMM modes as FULL records (value, ms per
+    # step, kernels, gemm_shapes, roofline with that mode's own ceiling and PMC file), and the other BASELINE.json
+    # configs (configs[2..4]) with their parity against the oracle step
+    def child(extra_args, env_extra, steps, cpu_steps=0):
         import subprocess
-        cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(args.f32_steps), '--warmup', str(args.warmup),
-               '--shape', args.shape, '--batch', str(args.batch), '--hidden', str(args.hidden), '--seq-len',
-               str(args.seq_len), '--dropout', str(args.dropout), '--cpu-steps', '0', '--e2e-steps', '0',
-               '--f32-steps', '0', '--enc-steps', '0', '--passes', args.passes]
-        r = subprocess.run(cmd, env=dict(os.environ, RENET_GEMM=gemm_env), capture_output=True, text=True)
+        cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(steps), '--warmup', str(args.warmup),
+               '--batch', str(args.batch), '--dropout', str(args.dropout), '--cpu-steps', str(cpu_steps),
+               '--cpu-warmup', '0', '--e2e-steps', '0', '--f32-steps', '0', '--enc-steps', '0', '--other-steps', '0',
+               '--passes', args.passes, '--child', '1'] + extra_args
+        r = subprocess.run(cmd, env=dict(os.environ, **env_extra), capture_output=True, text=True)
         try:
             j = json.loads(r.stdout.strip().splitlines()[-1])
-            return {'value': j['value'], 'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'gemm_mode': gemm_env,
-                    'last_loss': j['last_loss']}
-        except (ValueError, IndexError, KeyError):
+        except (ValueError, IndexError):
             return {'error': (r.stderr or r.stdout)[-300:]}
+        keep = ('value', 'ms_per_step', 'steps', 'dtype', 'gemm_mode', 'precision', 'last_loss', 'roofline',
+                'roofline_rgcn_gather', 'roofline_gru', 'kernels', 'gemm_shapes', 'kernel_only', 'parity',
+                'pmc_source')
+        rec = {k_: j.get(k_) for k_ in keep}
+        rec['workload'] = j.get('config', {}).get('workload')
+        return rec
 
-    exact = x6 = None
-    if args.f32_steps > 0 and world == 1 and K.GEMM_MODE in ('bf16x6', 'f16x3'):
-        exact = companion('f32')
-        if K.GEMM_MODE == 'f16x3':
-            x6 = companion('bf16x6')
+    same = ['--shape', args.shape, '--hidden', str(args.hidden), '--seq-len', str(args.seq_len)]
+    modes = {}
+    if args.f32_steps > 0 and world == 1 and not args.child and K.GEMM_MODE in ('bf16x6', 'f16x3', 'f32'):
+        for md in ('bf16x6', 'f16x3', 'f32'):
+            if md != K.GEMM_MODE:
+                modes[md] = child(same, {'RENET_GEMM': md}, args.f32_steps)
+    other_configs = None
+    if args.other_steps > 0 and world == 1 and not args.child and same_workload and args.dtype == 'f32':
+        other_configs = {
+            'wiki_d200': child(['--shape', 'WIKI'], {}, args.other_steps, cpu_steps=1),
+            'gdelt_d200': child(['--shape', 'GDELT'], {}, args.other_steps, cpu_steps=1),
+            'yago_d400_l15_bf16': child(['--shape', 'YAGO', '--hidden', '400', '--seq-len', '15', '--dtype', 'bf16'], {},
+                                        args.other_steps, cpu_steps=1),
+        }
+        for rec in other_configs.values():          # the per-shape tables stay in the child's own run: keep the line short
+            rec.pop('gemm_shapes', None)
+            rec.pop('kernels', None)
 
+    ko = sum(e_['ms_per_step'] for e_ in kernels.values())
+    glue_ms = sum(e_['ms_per_step'] for n_, e_ in kernels.items() if n_.startswith('glue:'))
+    precision = {'f16x3': 'fp32 storage; GEMM operands split into two tensor-scaled binary16 planes (22 significant '
+                          'bits), three f16 MFMA products, fp32 accumulation (DESIGN 3f)',
+                 'bf16x6': 'fp32 storage; GEMM operands split into three bf16 planes (all 24 significand bits), six bf16 '
+                           'MFMA products, fp32 accumulation: fp32-class',
+                 'f32': 'fp32 storage, exact fp32 MFMA products (v_mfma_f32_32x32x2_f32)',
+                 'bf16s': 'bf16 storage of the GEMM operands, fp32 accumulation',
+                 'bf16': 'fp32 storage, operands rounded to bf16 in the GEMM loaders'}.get(K.GEMM_MODE)
     out = {
         'metric': 'RGCN+GRU encoder triples/s at bs=%d n_hidden=%d (full training step, both directions)'
                   % (args.batch, args.hidden),
         'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'strong' if exact_split else args.scaling,
-        'scaling_mode': args.scaling, 'global_batch': mode.global_batch,
-        'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'gemm_mode': K.GEMM_MODE, 'passes': args.passes,
+        'scaling_mode': args.scaling, 'global_batch': mode.global_batch, 'rccl_ranks_seen': ranks_seen,
+        'vs_baseline': None,
+        # the arithmetic type the path computes in: fp32 tensors everywhere ('f32'); --dtype bf16 = bf16 operand storage
+        'dtype': args.dtype, 'data': 'synthetic', 'gemm_mode': K.GEMM_MODE, 'precision': precision,
+        'passes': args.passes,
         'config': {'workload': '%s-shaped synthetic stream (seed 999), n_hidden=%d, seq_len=%d, batch=%d per GPU, '
                                'dropout=%.2f, fwd+bwd both directions + clip + Adam' %
                                (args.shape, args.hidden, args.seq_len, rank_batch, args.dropout),
@@ -502,17 +594,14 @@ def main():
                                    'nonempty': int(g0.nnz)}},
         'roofline': roofline, 'roofline_rgcn_gather': gather, 'roofline_gru': gru, 'parity': parity,
         'encoder_only': encoder_only,
-        'kernel_only': {'ms_per_step': sum(e_['ms_per_step'] for e_ in kernels.values()),
-                        'value': rank_batch / max(sum(e_['ms_per_step'] for e_ in kernels.values()) * 1e-3, 1e-12),
-                        'what': 'sum of the HIP-event durations of the timed C-ABI kernel classes per step (the classes '
-                                'listed in `kernels`; untimed glue launches are not included)'},
-        'value_exact_f32': exact, 'value_bf16x6': x6,
-        'precision': {'f16x3': 'fp32 storage; GEMM operands split into two tensor-scaled binary16 planes (22 significant '
-                               'bits), three f16 MFMA products, fp32 accumulation (DESIGN 3f)',
-                      'bf16x6': 'fp32 storage; GEMM operands split into three bf16 planes (24 bits), six bf16 MFMA '
-                                'products, fp32 accumulation',
-                      'f32': 'fp32 storage, exact fp32 MFMA products', 'bf16s': 'bf16 storage of the GEMM operands',
-                      'bf16': 'fp32 storage, operands rounded to bf16 in the GEMM loaders'}.get(K.GEMM_MODE),
+        'kernel_only': {'ms_per_step': ko, 'value': rank_batch / max(ko * 1e-3, 1e-12), 'glue_ms_per_step': glue_ms,
+                        'timed_pass_ms_per_step': elapsed_timed * 1e3 / args.steps,
+                        'what': 'sum of the HIP-event durations of EVERY C-ABI launch of a step (named classes + the '
+                                "small kernels as 'glue:*'), from a second pass over the same steps with events on "
+                                '(serial launches, no side stream); torch-native launches (a dot, a few fills / adds) are '
+                                'the only ones outside it'},
+        'value_bf16x6': modes.get('bf16x6'), 'value_f16x3': modes.get('f16x3'), 'value_exact_f32': modes.get('f32'),
+        'other_configs': other_configs,
         'pmc_source': pmc_file,
         'traffic_source': ('%s: rocprofv3 --pmc passes of this command (tools/pmc_traffic.py), NOT measured in this run' % pmc_file) if pmc_file else None, 'kernels': kernels, 'gemm_shapes': gemm_shapes, 'cpu_baseline': cpu,
         'host_build_ms': host_build_ms, 'e2e_value': e2e, 'e2e_workers': e2e_workers, 'e2e_inline': e2e_inline, 'e2e_threads8': e2e_threads,

@@ -116,9 +116,9 @@ class RGCNAggregator(nn.Module):
         g.glob = table.mat
         return g
 
-    def encode(self, g, ent_embeds, rel_embeds, reverse, lazy_bf16=False):
+    def encode(self, g, ent_embeds, rel_embeds, reverse, _lazy_bf16=False):
         """Device side: h0 gather, two RGCN layers, packed sequence assembly (Aggregator.py:136-165).
-        lazy_bf16 (internal callers that hand X / Xr straight to ops.dual_gru / MultiGRUFn): in bf16-storage mode the
+        _lazy_bf16 (PRIVATE: internal callers that hand X / Xr straight to ops.dual_gru / MultiGRUFn): in bf16-storage mode the
         GRU inputs are produced as bf16 operand matrices only (ops.SeqAssembleFn)."""
         g.ndata['h'] = ops.TableRows(ent_embeds, g.node_ent, g.plan_node_ent)               # utils.py:239, deferred
         self.rgcn1(g, reverse)
@@ -128,7 +128,7 @@ class RGCNAggregator(nn.Module):
         h2 = g.ndata.pop('h')           # [nA, D]; subj_row < nA by construction
         p = self.drop_p if self.training else 0.0
         sx, sxr = (ops.next_seed(), ops.next_seed()) if p > 0 else (0, 0)
-        return ops.SeqAssembleFn.apply(h2, ent_embeds, rel_embeds, g.glob, g, p, sx, sxr, bool(lazy_bf16))
+        return ops.SeqAssembleFn.apply(h2, ent_embeds, rel_embeds, g.glob, g, p, sx, sxr, bool(_lazy_bf16))
 
     def _run(self, s_hist, s, r, ent_embeds, rel_embeds, graph_dict, global_emb, reverse, sort, group=None):
         g = self.build(s_hist, s, r, ent_embeds, graph_dict, global_emb, sort, group)

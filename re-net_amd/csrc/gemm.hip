@@ -17,6 +17,8 @@
 // model.py:86,94), the score heads (model.py:89-90,98-99) and all their backward GEMMs
 // (dX = dY W, dW = dY^T X with deterministic split-K).
 #include <cstdint>
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -40,6 +42,7 @@ struct GemmArgs {
     int k_tiles_per_split;      // in units of BK
     int split_k;
     float* partial;             // [split_k, M, N] when split_k > 1
+    int xcd_order;              // 1: XCD-aware virtual tile order (tile_of_block)
 };
 
 // Loads one 128 x BK operand tile into 4 float4 registers per thread.
@@ -148,9 +151,11 @@ __device__ __forceinline__ float4 read_frag(const float* __restrict__ S, int row
     }
 }
 
+// The round-1 kernel: 64-bit addressing and per-element predication for ANY extent.  Since round 4 only the fallback for
+// operands the buffer-addressed kernel below cannot take (>= 4 GiB, K < 4, fewer than 4 rows along a contiguous row index).
 // TA: A stored [K,M] (A^T);  TB: B stored [N,K] (B^T)
 template <bool TA, bool TB>
-__global__ __launch_bounds__(THREADS) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(THREADS) void gemm_f32_generic_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[2][2][OPBUF];       // [buffer][A|B]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -259,6 +264,278 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_kernel(GemmArgs g) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The production exact-fp32 kernel (round 4).  Same tile, LDS images and permuted k order as above; what changed is
+// everything AROUND the 64 MFMAs of a k-tile, which at 64 cycles per v_mfma_f32_32x32x2_f32 leave 16 issue slots each:
+//   * operands are addressed through raw buffer descriptors (whole-tensor extent in SGPRs, one 32-bit byte offset per
+//     item, advanced by a uniform k-tile step): no 64-bit address arithmetic, no clamping, NO BRANCH in the loop.
+//     Dwords beyond the tensor read as 0 in hardware; what lies inside the tensor but outside the tile's logical
+//     extent (the next row behind a K tail, the next k line behind a row tail) is zeroed by selects on the way into
+//     LDS, one k-tile after the load was issued;
+//   * the loop body is unconditional: tile t+1 is stored and tile t+2 is loaded even past the end of the split (zeros
+//     or data nobody reads, into the buffer nobody reads);
+//   * the order inside a k-tile is pinned (sched_barrier): fragments of k-group g+1 are read behind the first MFMAs of
+//     group g, one {select, ds_write_b128, buffer_load} piece follows every seventh MFMA;
+//   * the barrier at the end of a k-tile waits for LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier): the global loads
+//     of tile t+2 stay in flight across it (__syncthreads() drains vmcnt).
+// Two workgroups per CU (73.7 KB of LDS each): while one sits at its barrier or in its epilogue the other owns the
+// matrix pipe.  Bound: the f32-input MFMA rate, 157.3 TFLOP/s (MI355X_MICROARCH.md); LDS / L2 traffic is an order
+// of magnitude below its ceilings (16 ds_read_b128 + 8 ds_write_b128 + 8 buffer loads per wave and 4096 MFMA cycles).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void tile_of_block(int nbx, int nby, bool xcd_order, int& bx, int& by) {
+    // same virtual tile order as gemm_split.hip: XCD x owns one contiguous 1/8 of the tile sequence, in which the SHORT
+    // grid dimension runs fastest in panels of <= 8 tiles (tiles sharing a slab of the long operand share an L2)
+    if (!xcd_order) { bx = blockIdx.x; by = blockIdx.y; return; }
+    const int nb = nbx * nby, per = nb >> 3;
+    const int L = blockIdx.x + nbx * blockIdx.y;
+    const int t = L < 8 * per ? (L & 7) * per + (L >> 3) : L;
+    const int ns = min(nbx, nby), nl = max(nbx, nby);
+    const int w = min(ns, 8);
+    const int p = t / (w * nl), r = t - p * (w * nl);
+    const int wp = min(w, ns - p * w);
+    const int l = r / wp, sh = p * w + (r - l * wp);
+    if (nby <= nbx) { bx = l; by = sh; }
+    else { by = l; bx = sh; }
+}
+
+// One operand tile (128 rows x KT k) of the buffer-addressed kernel.  KT = 32 or 16 floats of k per stage.
+//   CONTIG_K (storage [rows, K]): item f -> row f / (KT/4), k 4 * (f % (KT/4)); LDS image [row][KT + 4]
+//   else     (storage [K, rows]): item f -> k f / 32, rows 4 * (f % 32) ..;      LDS image [k][132]
+template <bool CONTIG_K, int KT>
+struct BufLoader {
+    static constexpr int NI = KT / 8;              // float4 items per thread and stage
+    static constexpr int CPR = KT / 4;             // float4 chunks per tile row (CONTIG_K)
+    static constexpr int LDKT = KT + 4;
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t off[NI];          // byte offset of item i in k-tile 0
+    uint32_t kstep;            // bytes per k-tile
+    int lim[NI];               // CONTIG_K: k of the item inside a tile (K-tail fix-up); unused otherwise
+    int rows, K;
+
+    __device__ __forceinline__ void init(const float* P, int ld, int rows_, int K_, int row0, int tid) {
+        rows = rows_; K = K_;
+        const uint32_t extent = CONTIG_K ? (uint32_t)(rows - 1) * (uint32_t)ld + (uint32_t)K
+                                         : (uint32_t)(K - 1) * (uint32_t)ld + (uint32_t)rows;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), (short)0, (int)(extent * 4u), 0x00020000);
+        kstep = CONTIG_K ? (uint32_t)KT * 4u : (uint32_t)KT * (uint32_t)ld * 4u;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int f = tid + THREADS * i;
+            if constexpr (CONTIG_K) {
+                const int row = row0 + f / CPR, k = (f % CPR) << 2;
+                off[i] = ((uint32_t)min(row, rows - 1) * (uint32_t)ld + (uint32_t)k) * 4u;
+                lim[i] = k;
+            } else {
+                const int k = f >> 5, row = row0 + ((f & 31) << 2);
+                off[i] = ((uint32_t)k * (uint32_t)ld + (uint32_t)min(row, rows - 1)) * 4u;
+                lim[i] = 0;
+            }
+        }
+    }
+
+    __device__ __forceinline__ float4 load(int i, int kt) const {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off[i] + (uint32_t)kt * kstep), 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+
+    // K tail of an operand whose k index is contiguous in memory: the dwords behind K belong to the NEXT ROW (inside the
+    // tensor: not zeroed by the range check) -> select zeros.  k0 = first k of the item's tile.  Nothing to do for the
+    // other storage order (k >= K lies behind the tensor's extent: hardware zeros), and nothing for rows past the
+    // operand in either order (they only feed outputs that are never stored).
+    __device__ __forceinline__ float4 fix(int i, int k0, float4 v) const {
+        if constexpr (CONTIG_K) {
+            const int room = K - k0 - lim[i];           // components j < room are valid
+            v.x = room > 0 ? v.x : 0.f;
+            v.y = room > 1 ? v.y : 0.f;
+            v.z = room > 2 ? v.z : 0.f;
+            v.w = room > 3 ? v.w : 0.f;
+        }
+        return v;
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ S, int i, int tid, float4 v) const {
+        const int f = tid + THREADS * i;
+        if constexpr (CONTIG_K) *reinterpret_cast<float4*>(&S[(f / CPR) * LDKT + ((f % CPR) << 2)]) = v;
+        else *reinterpret_cast<float4*>(&S[(f >> 5) * LDR + ((f & 31) << 2)]) = v;
+    }
+
+    // the 4 values (MFMA steps 0..3) of k-group g for tile row `row`, half-wave ksel
+    static __device__ __forceinline__ float4 frag(const float* __restrict__ S, int row, int g, int ksel) {
+        if constexpr (CONTIG_K) {
+            return *reinterpret_cast<const float4*>(&S[row * LDKT + 8 * g + 4 * ksel]);
+        } else {
+            const float* p = S + (8 * g + 4 * ksel) * LDR + row;
+            return make_float4(p[0], p[LDR], p[2 * LDR], p[3 * LDR]);
+        }
+    }
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__device__ __forceinline__ float f4_get(const float4& v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
+
+// accumulators -> C (or the split-K partial plane).  C/D layout of the 32x32 MFMA: col = lane & 31,
+// row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  beta != 0: ALL reads of C before the stores (a store may alias
+// the next load as far as the compiler knows: 64 chained round trips per lane otherwise).
+__device__ __forceinline__ void store_acc(const GemmArgs& g, int m0, int n0, int z, int wm, int wn, int lane,
+                                          const f32x16 (&acc)[2][2]) {
+    const bool split = g.split_k > 1;
+    float* Cout = split ? g.partial + (size_t)z * g.M * g.N : g.C;
+    const int ldo = split ? g.N : g.ldc;
+    const int half = lane >> 5;
+    const bool accumulate = !split && g.beta != 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= g.N) continue;
+            const float bv = (!split && g.bias) ? g.bias[col] : 0.f;
+            const int row_base = m0 + wm * 64 + i * 32 + 4 * half;
+            float old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = 0.f;
+            if (accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(row_base + (r & 3) + 8 * (r >> 2), g.M - 1);
+                    old[r] = Cout[(size_t)row * ldo + col];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + (r & 3) + 8 * (r >> 2);
+                if (row < g.M) {
+                    float* p = Cout + (size_t)row * ldo + col;
+                    if (split) *p = acc[i][j][r];
+                    else *p = g.alpha * acc[i][j][r] + bv + (accumulate ? g.beta * old[r] : 0.f);
+                }
+            }
+        }
+}
+
+#ifndef F32P_NOBAR
+#define F32_LOOP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define F32_LOOP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
+// KT floats of k per stage; g.k_tiles_per_split counts KT-tiles.  WPE = workgroups per CU the launch is compiled for
+// (KT 32: 73.7 KB of LDS, 2 per CU; KT 16: 41 KB, 3 per CU).
+template <bool TA, bool TB, int KT, int WPE>
+__global__ __launch_bounds__(THREADS, WPE) void gemm_f32_kernel(GemmArgs g) {
+    constexpr bool A_CK = !TA;
+    constexpr bool B_CK = TB;
+    typedef BufLoader<A_CK, KT> LA;
+    typedef BufLoader<B_CK, KT> LB;
+    constexpr int NI = KT / 8, NG = KT / 8, NM = 16 * NG;              // items / k-groups / MFMAs per stage
+    constexpr int OPB = (BM * (KT + 4) > KT * LDR) ? BM * (KT + 4) : KT * LDR;
+    __shared__ __attribute__((aligned(16))) float smem[2][2][OPB];          // [buffer][A|B]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx, by;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    const int m0 = by * BM, n0 = bx * BN;
+    const int z = blockIdx.z;
+    const int kt0 = z * g.k_tiles_per_split;
+    const int kt_total = (g.K + KT - 1) / KT;
+    const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
+
+    // Known loss (profiles/r04_f32_gemm_probes.md): the co-resident workgroups of a CU start together, share the matrix
+    // pipe evenly, therefore finish, store and are replaced together -- prologue + epilogue of a round of tiles never
+    // overlap anybody's k-loop (2048 x 23033 x 600: 510 us with an empty loop body around the MFMAs against 414 us of
+    // sustained matrix-pipe time).  A static s_setprio by hardware wave slot does not break the symmetry (measured: no
+    // change -- the other wave's MFMAs slip in whenever the favoured one issues an LDS / memory instruction); the fix
+    // is a persistent tile loop with a second accumulator set (epilogue of tile i under the k-loop of tile i+1).
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    LA la;
+    LB lb;
+    la.init(g.A, g.lda, g.M, g.K, m0, tid);
+    lb.init(g.B, g.ldb, g.N, g.K, n0, tid);
+    float4 ra[NI], rb[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { ra[i] = la.load(i, kt0); rb[i] = lb.load(i, kt0); }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        la.store(smem[0][0], i, tid, la.fix(i, kt0 * KT, ra[i]));
+        lb.store(smem[0][1], i, tid, lb.fix(i, kt0 * KT, rb[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { ra[i] = la.load(i, kt0 + 1); rb[i] = lb.load(i, kt0 + 1); }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const int arow = wm * 64 + (lane & 31);
+    const int brow = wn * 64 + (lane & 31);
+    const int ksel = lane >> 5;
+
+    // One k-tile: 16 * NG MFMAs; tile kt+1 goes registers -> LDS and tile kt+2 global -> registers on the way.  FIX: the
+    // stored tile may hold k >= K (only the last k-tile of the operand, or tiles past it): select zeros there.  Rows
+    // past the operand need no fix-up at all: they only feed output rows / columns that are never stored.
+    auto k_tile = [&](int kt, auto fixc) {
+        constexpr bool FIX = decltype(fixc)::value;
+        const int cur = (kt - kt0) & 1;
+        const float* As = smem[cur][0];
+        const float* Bs = smem[cur][1];
+        float* An = smem[cur ^ 1][0];
+        float* Bn = smem[cur ^ 1][1];
+        float4 fa[2][2], fb[2][2];                       // [fragment buffer][MFMA tile]
+        fa[0][0] = LA::frag(As, arow, 0, ksel);
+        fb[0][0] = LB::frag(Bs, brow, 0, ksel);
+        fa[0][1] = LA::frag(As, arow + 32, 0, ksel);
+        fb[0][1] = LB::frag(Bs, brow + 32, 0, ksel);
+        static_for<0, NM>([&](auto mc) {
+            constexpr int m = mc.value, grp = m >> 4, t = (m >> 2) & 3, i = (m >> 1) & 1, j = m & 1, fbuf = grp & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4_get(fa[fbuf][i], t), f4_get(fb[fbuf][j], t), acc[i][j],
+                                                             0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (grp + 1 < NG && (m & 15) < 4) {         // fragments of k-group grp + 1, one per MFMA
+                constexpr int q = m & 15;
+                if constexpr (q == 0) fa[fbuf ^ 1][0] = LA::frag(As, arow, grp + 1, ksel);
+                if constexpr (q == 1) fb[fbuf ^ 1][0] = LB::frag(Bs, brow, grp + 1, ksel);
+                if constexpr (q == 2) fa[fbuf ^ 1][1] = LA::frag(As, arow + 32, grp + 1, ksel);
+                if constexpr (q == 3) fb[fbuf ^ 1][1] = LB::frag(Bs, brow + 32, grp + 1, ksel);
+            }
+#ifndef F32P_NOSTAGE
+            // staging: piece pc = {store item, reload item}; the store behind MFMA 4 + STRIDE * pc, its reload one MFMA on
+            constexpr int STRIDE = (NM - 6) / (2 * NI);
+            if constexpr (m >= 4 && (m - 4) % STRIDE == 0 && (m - 4) / STRIDE < 2 * NI) {
+                constexpr int pc = (m - 4) / STRIDE, it = pc >> 1;
+                if constexpr ((pc & 1) == 0) la.store(An, it, tid, FIX ? la.fix(it, (kt + 1) * KT, ra[it]) : ra[it]);
+                else lb.store(Bn, it, tid, FIX ? lb.fix(it, (kt + 1) * KT, rb[it]) : rb[it]);
+            }
+            if constexpr (m >= 5 && (m - 5) % STRIDE == 0 && (m - 5) / STRIDE < 2 * NI) {
+                constexpr int pc = (m - 5) / STRIDE, it = pc >> 1;
+                if constexpr ((pc & 1) == 0) ra[it] = la.load(it, kt + 2);
+                else rb[it] = lb.load(it, kt + 2);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        F32_LOOP_BARRIER();                              // LDS only: tile t+2's loads stay in flight
+    };
+    // tiles kt+1 <= kt_total - 2 are complete along k: no fix-up in the steady state
+    const int kt_plain = min(kt1, kt_total - 2);
+    int kt = kt0;
+    for (; kt < kt_plain; ++kt) k_tile(kt, std::false_type{});
+    for (; kt < kt1; ++kt) k_tile(kt, std::true_type{});
+    store_acc(g, m0, n0, z, wm, wn, lane, acc);
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int split_k,
                                                             int M, int N, float alpha, float beta,
                                                             const float* __restrict__ bias,
@@ -359,6 +636,25 @@ int colsum_impl(const T* X, int M, int N, int ldx, float* out, float beta, float
 }
 
 
+int tile_order_f32() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RENET_GEMM_TILE_ORDER");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+
+// RENET_GEMM_F32_GENERIC=1: the round-1 kernel for every shape (A/B runs, tests of the fallback)
+bool generic_forced() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RENET_GEMM_F32_GENERIC");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v != 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -383,12 +679,35 @@ int renet_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, const float
     g.k_tiles_per_split = (kt_total + split_k - 1) / split_k;
     if (g.k_tiles_per_split < 1) g.k_tiles_per_split = 1;
     g.partial = workspace;
+    g.xcd_order = tile_order_f32();
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, split_k);
-    if (!ta && !tb) RENET_LAUNCH((gemm_f32_kernel<false, false>), grid, dim3(THREADS), 0, st, g);
-    else if (!ta && tb) RENET_LAUNCH((gemm_f32_kernel<false, true>), grid, dim3(THREADS), 0, st, g);
-    else if (ta && !tb) RENET_LAUNCH((gemm_f32_kernel<true, false>), grid, dim3(THREADS), 0, st, g);
-    else RENET_LAUNCH((gemm_f32_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
+    const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, split_k);
+    // the buffer-addressed kernel reaches every element (and up to two k-tiles past the end) with a 32-bit byte offset
+    const size_t reach_a = ta ? ((size_t)K + 3 * BK) * lda + M : (size_t)M * lda + K + 3 * BK;
+    const size_t reach_b = tb ? (size_t)N * ldb + K + 3 * BK : ((size_t)K + 3 * BK) * ldb + N;
+    const bool buffered = K >= 1 && reach_a < ((size_t)1 << 30) && reach_b < ((size_t)1 << 30) && !generic_forced();
+    if (buffered) {
+        constexpr int kt = 32;      // a 16-deep stage (3 workgroups per CU) was measured: no gain on the step's shapes
+        const int ktiles = (K + kt - 1) / kt;
+        if (split_k > ktiles) { split_k = max(ktiles, 1); g.split_k = split_k; }
+        g.k_tiles_per_split = max(1, (ktiles + split_k - 1) / split_k);
+        const dim3 gridb((N + BN - 1) / BN, (M + BM - 1) / BM, split_k);
+#define RENET_F32_LAUNCH(KT_, WPE_)                                                                                   \
+        do {                                                                                                          \
+            if (!ta && !tb) RENET_LAUNCH((gemm_f32_kernel<false, false, KT_, WPE_>), gridb, dim3(THREADS), 0, st, g); \
+            else if (!ta && tb) RENET_LAUNCH((gemm_f32_kernel<false, true, KT_, WPE_>), gridb, dim3(THREADS), 0, st, g); \
+            else if (ta && !tb) RENET_LAUNCH((gemm_f32_kernel<true, false, KT_, WPE_>), gridb, dim3(THREADS), 0, st, g); \
+            else RENET_LAUNCH((gemm_f32_kernel<true, true, KT_, WPE_>), gridb, dim3(THREADS), 0, st, g);              \
+        } while (0)
+        RENET_F32_LAUNCH(32, 2);
+#undef RENET_F32_LAUNCH
+    } else {
+        g.xcd_order = 0;
+        if (!ta && !tb) RENET_LAUNCH((gemm_f32_generic_kernel<false, false>), grid, dim3(THREADS), 0, st, g);
+        else if (!ta && tb) RENET_LAUNCH((gemm_f32_generic_kernel<false, true>), grid, dim3(THREADS), 0, st, g);
+        else if (ta && !tb) RENET_LAUNCH((gemm_f32_generic_kernel<true, false>), grid, dim3(THREADS), 0, st, g);
+        else RENET_LAUNCH((gemm_f32_generic_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
+    }
     RENET_LAUNCH_CHECK();
     if (split_k > 1) {
         const size_t total = (size_t)M * N;

@@ -86,8 +86,19 @@ class DeviceStore(object):
         self.c = sd
         # capacities: grown on demand (an overflow is reported in the counts and the batch rebuilt)
         self.cap_nodes, self.cap_edges = 1 << 17, 1 << 19
-        self._pinned = [torch.empty(NCOUNTS, dtype=torch.int32, pin_memory=True) for _ in range(8)]
-        self._pin_next = 0
+        # pinned 256-byte count buffers: a free-list, not a ring -- every DeviceBatch OWNS its buffer from the async
+        # D2H copy until finalize() has read it (with a shared ring of 8, the ninth pending batch overwrote
+        # the counts of the first)
+        self._pinned_free = []
+
+    def _take_pinned(self):
+        if self._pinned_free:
+            return self._pinned_free.pop()
+        return torch.empty(NCOUNTS, dtype=torch.int32, pin_memory=True)
+
+    def _give_pinned(self, buf):
+        if buf is not None and len(self._pinned_free) < 64:
+            self._pinned_free.append(buf)
 
 
 class _Host(object):
@@ -155,8 +166,7 @@ class DeviceBatch(object):
         if rc != 0:
             raise K.RenetHipError('renet_build_batch_both failed with code %d' % rc)
         self._ws = ws                       # stays alive until the kernels have run (freed in finalize)
-        self._counts_host = store._pinned[store._pin_next % len(store._pinned)]      # (pinned ring: no allocation per batch)
-        store._pin_next += 1
+        self._counts_host = store._take_pinned()     # owned by this batch until finalize() / release
         self._stream = st
         with torch.cuda.stream(st):
             self._counts_host.copy_(self._v['counts'], non_blocking=True)
@@ -170,7 +180,9 @@ class DeviceBatch(object):
         if self._final:
             return True
         self._done.synchronize()
-        c = self._counts_host.numpy().astype(np.int64)
+        c = self._counts_host.numpy().astype(np.int64)      # (a copy: the pinned buffer goes back to the free-list)
+        self.store._give_pinned(self._counts_host)
+        self._counts_host = None
         self._ws = None
         cur = torch.cuda.current_stream()
         if cur != self._stream:                  # built on a side stream, consumed on this one
@@ -225,6 +237,16 @@ class DeviceBatch(object):
         self.host = _Host(self, c)
         self._final = True
         return True
+
+    def __del__(self):
+        # a batch dropped before finalize(): its copy may still be in flight -- wait for it before the buffer is reused
+        try:
+            if getattr(self, '_counts_host', None) is not None:
+                self._done.synchronize()
+                self.store._give_pinned(self._counts_host)
+                self._counts_host = None
+        except Exception:       # interpreter shutdown
+            pass
 
     def table_items(self):
         if self._table_items is None:

@@ -239,7 +239,7 @@ class RENet(nn.Module):
         with M (or K) doubled.  Each CE is a mean over its B rows: the sum of the two is 2 x the mean over 2B."""
         g = prep.g
         self.aggregator.last_batch = g
-        x, xr = self.aggregator.encode(g, self.ent_embeds, self.rel_embeds, reverse=False, lazy_bf16=True)
+        x, xr = self.aggregator.encode(g, self.ent_embeds, self.rel_embeds, reverse=False, _lazy_bf16=True)
         s_h, s_q = ops.dual_gru(x, xr, self.encoder, self.encoder_r, prep.step_off, prep.b)
         # [1, rows, H] -> [rows, H] as a VIEW: indexing with [0] would make autograd fill and copy a zeros tensor per
         # encoder in the backward pass (select_backward)
@@ -289,7 +289,7 @@ class RENet(nn.Module):
     def _encode(self, prep):
         rel_embeds = self.rel_embeds[:self.num_rels] if prep.subject else self.rel_embeds[self.num_rels:]
         self.aggregator.last_batch = prep.g
-        return self.aggregator.encode(prep.g, self.ent_embeds, rel_embeds, reverse=not prep.subject, lazy_bf16=True)
+        return self.aggregator.encode(prep.g, self.ent_embeds, rel_embeds, reverse=not prep.subject, _lazy_bf16=True)
 
     def loss_prepared(self, prep):
         """Device half (model.py:82-103): RGCN x2 -> sequence assembly -> GRU x2 -> heads -> loss."""

@@ -292,10 +292,10 @@ class SeqAssembleFn(Function):
     """Aggregator.py:139-165: packed GRU inputs X [S,4D], Xr [S,3D] with fused dropout."""
 
     @staticmethod
-    def forward(ctx, h2, ent, rel, glob, g, drop_p, seed_x, seed_xr, lazy_bf16=False):
+    def forward(ctx, h2, ent, rel, glob, g, drop_p, seed_x, seed_xr, _lazy_bf16=False):
         ctx.src_ent, ctx.src_rel = ent, rel
         h2, ent, rel, glob = _c(h2), _c(ent), _c(rel), _c(glob)
-        if lazy_bf16 and K.GEMM_MODE == 'bf16s':
+        if _lazy_bf16 and K.GEMM_MODE == 'bf16s':
             # bf16-storage mode, internal callers only (RENet.loss_prepared*): X / Xr exist ONLY as bf16 operand
             # matrices; the fp32 tensors returned to autograd are uninitialised shells that carry them (K.operand
             # picks the attribute up) -- their values must never be read

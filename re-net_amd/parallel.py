@@ -279,6 +279,9 @@ class HipAdam(object):
         self.K.adam_step(self.params.flat, self.grads.flat, self.m, self.v, self.lr, self.betas[0], self.betas[1],
                          self.eps, self.wd, self.max_norm, self.t, True, self.norm, grad_scale=scale)
         self.K.weights_changed()
+        # f16x3 mode: the magnitude bounds of all registered weights, measured HERE on the step's stream (one launch), so
+        # that no GEMM of the next step -- on whichever stream ops._Side puts it -- is the one that triggers the pass
+        self.K.prefetch_weight_bounds(self.params.flat.device)
 
 
 class _StepScope(object):

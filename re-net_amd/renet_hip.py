@@ -267,10 +267,44 @@ class KernelTimer(object):
 
 _timer = None
 
+# wrappers without a timer of their own (the step's small kernels): set_timer(t, glue=True) times each of them as class
+# 'glue:<name>' so that bench.py's `kernel_only` covers EVERY C-ABI launch of a step, not only the named classes
+GLUE = ('gather_rows', 'segment_add', 'segment_add2', 'compose_table_items', 'rgcn_bwd_prep', 'colsum',
+        'scale_by_device_scalar', 'seq_assemble_fwd', 'seq_assemble_fwd_bf16', 'softmax_ce_bf16', 'seq_assemble_bwd',
+        'concat3_fwd', 'concat3_bwd', 'dropout', 'softmax_ce', 'adam_step', 'segment_pool_fwd', 'segment_pool_bwd',
+        'pack_bf16_glue')
+_glue_saved = {}
 
-def set_timer(t):
+
+def _timed_glue(name, fn):
+    import functools
+
+    @functools.wraps(fn)
+    def call(*a, **k):
+        t = _timer
+        if t is None:
+            return fn(*a, **k)
+        e0 = t.begin()
+        try:
+            return fn(*a, **k)
+        finally:
+            t.end('glue:' + name, e0)
+    return call
+
+
+def set_timer(t, glue=False):
+    """Installs (None: removes) the kernel timer.  glue=True also times the wrappers listed in GLUE."""
     global _timer
     _timer = t
+    g = globals()
+    for name, fn in _glue_saved.items():
+        g[name] = fn
+    _glue_saved.clear()
+    if t is not None and glue:
+        for name in GLUE:
+            if name in g and callable(g[name]):
+                _glue_saved[name] = g[name]
+                g[name] = _timed_glue(name, g[name])
 
 
 # ---- thin typed wrappers -----------------------------------------------------------------------
@@ -494,7 +528,9 @@ def auto_split_k(m, n, k):
 # 'f16x3'  : fp32 operands, scaled per TENSOR by a power of two, split into 2 binary16 terms (22 significant bits),
 #            3 term products on v_mfma_f32_32x32x16_f16 (gemm_h3.h): GEMM errors within a small multiple of fp32's
 #            own accumulation error (include/renet_hip.h), half the matrix instructions of bf16x6
-GEMM_MODE = os.environ.get('RENET_GEMM', 'f16x3')       # RENET_GEMM=bf16x6 | f32 select the other fp32-class kernels
+# Default since round 4: 'bf16x6', the 24-bit split (fp32-class: every operand bit enters the product).  'f16x3' (22-bit
+# operands, the round-3 default) is the opt-in FAST mode, 'f32' the exact-product mode; bench.py reports all three.
+GEMM_MODE = os.environ.get('RENET_GEMM', 'bf16x6')
 
 
 class BF16Mat(object):
@@ -615,7 +651,25 @@ def maxabs_partials(x):
     return part, n
 
 
-_weight_max = {}               # data_ptr -> (epoch, part, n) of a registered weight
+_weight_max = {}               # data_ptr -> (stamp, part, n, guard) of a registered weight
+
+
+class _StreamGuard(object):
+    """Orders consumers on OTHER streams behind the launch that filled a cached device buffer (the first
+    bound request after an optimizer step may come from ops._Side's side stream; a main-stream GEMM that then hits
+    the cache must not read the partial maxima before that launch has run).  Created right behind the producing
+    launch on the producing stream; wait() is free on that same stream."""
+    __slots__ = ('stream', 'event')
+
+    def __init__(self, device):
+        self.stream = torch.cuda.current_stream(device)
+        self.event = torch.cuda.Event()
+        self.event.record(self.stream)
+
+    def wait(self, device):
+        cur = torch.cuda.current_stream(device)
+        if cur != self.stream:
+            cur.wait_event(self.event)
 
 
 _weight_jobs = {'key': None, 'table': None, 'parts': {}}     # one multi-array launch for all registered weights
@@ -646,7 +700,15 @@ def _measure_all_weights(device):
            'maxabs_partials_multi')
     if t0 is not None:
         _timer.end('maxabs', t0, nbytes=float(sum(_weight_ptrs[p][0] * _weight_ptrs[p][1] * 4 for p in ptrs)))
-    return {p: ((_weight_epoch[0], live[p]._version), part, nb) for p, (part, nb) in _weight_jobs['parts'].items()}
+    guard = _StreamGuard(device)
+    return {p: ((_weight_epoch[0], live[p]._version), part, nb, guard) for p, (part, nb) in _weight_jobs['parts'].items()}
+
+
+def prefetch_weight_bounds(device):
+    """Measure every registered weight NOW, on the current stream (parallel.HipAdam.step calls this right behind the
+    update, on the stream the step runs on): the f16x3 GEMMs of the next step then only ever hit the cache."""
+    if GEMM_MODE == 'f16x3' and _weight_ptrs:
+        _weight_max.update(_measure_all_weights(device))
 
 
 def _weight_or_measured_max(x):
@@ -664,8 +726,9 @@ def _weight_or_measured_max(x):
             ent = _weight_max.get(ptr)
         if ent is None or ent[0] != stamp:          # not coverable by the joint launch, or modified since: on its own
             part, n = maxabs_partials(torch.as_strided(x, shp, (shp[1], 1)))
-            ent = (stamp, part, n)
+            ent = (stamp, part, n, _StreamGuard(x.device))
             _weight_max[ptr] = ent
+        ent[3].wait(x.device)                       # (no-op on the stream that measured)
         return ent[1], ent[2]
     return maxabs_partials(x)
 
@@ -683,11 +746,14 @@ _const_bounds = {}
 def const_bound(value, device):
     """1-element device tensor holding a known bound (GRU states: 1)."""
     key = (float(value), str(device))
-    t = _const_bounds.get(key)
-    if t is None:
+    ent = _const_bounds.get(key)
+    if ent is None:
         t = torch.full((1,), float(value), device=device, dtype=torch.float32)
-        _const_bounds[key] = t
-    return t
+        ent = (t, _StreamGuard(device) if t.is_cuda else None)
+        _const_bounds[key] = ent
+    if ent[1] is not None:
+        ent[1].wait(device)                         # filled on another stream (ops._Side): order this one behind it
+    return ent[0]
 
 
 def operand_like(x, other):
@@ -725,12 +791,20 @@ _lazy_shells = {}          # (data_ptr, shape) of an uninitialised fp32 shell ->
 def lazy_shell(mat, device):
     """fp32 tensor of mat's logical shape whose VALUES ARE NEVER WRITTEN: the autograd-visible stand-in of a tensor
     that exists only as a bf16 operand matrix (bf16-storage mode); operand() resolves it to `mat`."""
+    import weakref
     x = torch.empty(mat.R, mat.C, device=device, dtype=torch.float32)
     x._renet_bf16 = mat
-    if len(_lazy_shells) > 64:
-        _lazy_shells.clear()
-    _lazy_shells[(x.data_ptr(), (mat.R, mat.C))] = mat
+    key = (x.data_ptr(), (mat.R, mat.C))
+    _lazy_shells[key] = mat
+    # the address-keyed entry lives exactly as long as the shell OBJECT (ADVICE r3: a shell dropped before it reached
+    # operand() must not leave an entry that a later fp32 tensor at the same address and shape would resolve to)
+    weakref.finalize(x, _drop_lazy_shell, key, mat)
     return x
+
+
+def _drop_lazy_shell(key, mat):
+    if _lazy_shells.get(key) is mat:
+        del _lazy_shells[key]
 
 
 def operand(x, bound=None):

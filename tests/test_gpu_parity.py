@@ -82,6 +82,58 @@ def test_gemm_both_k_loop_structures(dev, kernel):
     assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
 
 
+@pytest.mark.parametrize('generic', ['0', '1'])
+def test_exact_f32_gemm_every_tile_and_edge(dev, generic):
+    """renet_gemm_f32 (exact fp32 products on v_mfma_f32_32x32x2_f32): the buffer-addressed production kernel
+    (round 4) and, forced with RENET_GEMM_F32_GENERIC=1, the generic fallback for operands it cannot address -- over
+    ragged shapes, K below one k-tile, one, two, many k-tiles, split-K (child process: the switch is read once)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, RENET_GEMM_F32_GENERIC=generic)
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 're-net_amd')
+    r = subprocess.run([sys.executable, '-c', _GEMM_KERNEL_CHECK.replace("mode='bf16x6'", "mode='f32'"), pkg],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
+
+
+def test_exact_f32_gemm_products_are_exact_and_views_are_respected(dev):
+    """(a) Operands whose products and partial sums are all exactly representable in fp32 (small integers) must come
+    out EXACT -- no operand rounding anywhere in the exact-fp32 kernel, unlike the split modes' 22 / 24-bit operands
+    (checked with 24-bit odd integers scaled so that every partial sum stays below 2^24).  (b) Row-strided views with
+    odd leading dimensions, garbage (NaN) outside the logical extent of every operand: nothing outside may leak in."""
+    import renet_hip as K
+    rng = np.random.RandomState(5)
+    for m, n, k, ta, tb in [(130, 257, 100, 0, 1), (257, 130, 71, 1, 0), (64, 96, 33, 0, 0), (96, 64, 600, 1, 1)]:
+        a = rng.randint(-64, 65, (k, m) if ta else (m, k)).astype(np.float32)
+        b = rng.randint(-64, 65, (n, k) if tb else (k, n)).astype(np.float32)
+        ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+        out = K.gemm(_to(a, dev), _to(b, dev), ta=bool(ta), tb=bool(tb), mode='f32').cpu().numpy()
+        assert np.array_equal(out.astype(np.float64), ref), (m, n, k, ta, tb)
+        # full-width significands: x = odd 24-bit integer * 2^-23, one product per output (K = 1) must be the fp32
+        # rounding of the exact product
+        a1 = ((rng.randint(2 ** 22, 2 ** 23, (m, 1)) * 2 + 1) * 2.0 ** -23).astype(np.float32)
+        b1 = ((rng.randint(2 ** 22, 2 ** 23, (1, n)) * 2 + 1) * 2.0 ** -23).astype(np.float32)
+        o1 = K.gemm(_to(a1, dev), _to(b1, dev), mode='f32').cpu().numpy()
+        assert np.array_equal(o1, (a1.astype(np.float64) @ b1.astype(np.float64)).astype(np.float32))
+    # (b) views inside NaN-filled buffers
+    for m, n, k, ta, tb, lda, ldb in [(130, 70, 45, 0, 1, 51, 47), (70, 130, 45, 1, 0, 73, 133), (33, 35, 37, 0, 0, 41, 39),
+                                      (129, 131, 64, 1, 1, 131, 67)]:
+        ra, ca = (k, m) if ta else (m, k)
+        rb, cb = (n, k) if tb else (k, n)
+        A = torch.full((ra + 2, lda), float('nan'), device=dev)
+        B = torch.full((rb + 2, ldb), float('nan'), device=dev)
+        a = rng.uniform(-1, 1, (ra, ca)).astype(np.float32)
+        b = rng.uniform(-1, 1, (rb, cb)).astype(np.float32)
+        A[1:1 + ra, :ca] = _to(a, dev)
+        B[1:1 + rb, :cb] = _to(b, dev)
+        C = torch.full((m + 2, n + 5), float('nan'), device=dev)
+        K.gemm(A[1:1 + ra, :ca], B[1:1 + rb, :cb], ta=bool(ta), tb=bool(tb), out=C[1:1 + m, :n], mode='f32')
+        ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+        got = C.cpu().numpy()
+        np.testing.assert_allclose(got[1:1 + m, :n], ref, rtol=1e-5, atol=1e-5 * k ** 0.5)
+        assert np.isnan(got[0]).all() and np.isnan(got[-1]).all() and np.isnan(got[:, n:]).all()
+
+
 @pytest.mark.parametrize('tall', ['0', '1'])
 def test_f16x3_gemm_every_tile_and_edge(dev, tall):
     """renet_gemm_f32_h3 with the 128-row and the 256-row tile forced (RENET_H3_TALL) over ragged shapes, one k-tile,
@@ -651,6 +703,24 @@ def test_exact_fp32_mode_in_a_subprocess(dev):
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-x', '-k',
                         'gru_matches_torch_cpu or training_step or global_model'], env=env, capture_output=True,
                        text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'no tests ran' not in r.stdout
+
+
+def test_f16x3_fast_mode_in_a_subprocess(dev):
+    """RENET_GEMM=f16x3 (22-bit operand split, the opt-in fast mode since round 4; the default is the 24-bit bf16x6
+    split): the GRU / training-step / global-model parity tests and the stream / operand-bound tests re-run in a child
+    process with the switch set (it is read once per process)."""
+    import subprocess
+    import sys
+    if os.environ.get('RENET_GEMM') == 'f16x3':
+        pytest.skip('already running in f16x3 mode')
+    env = dict(os.environ, RENET_GEMM='f16x3')
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), os.path.join(here, 'test_gpu_streams.py'),
+                        '-q', '-m', 'gpu', '-x', '-k',
+                        'gru_matches_torch_cpu or training_step or global_model or stream or bounds or dual_head'],
+                       env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout and 'no tests ran' not in r.stdout
 

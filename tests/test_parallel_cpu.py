@@ -323,3 +323,28 @@ def test_exact_split_shares_graph_site_dropout_seeds_across_ranks(monkeypatch):
     assert all(x != y for x, y in zip(c, d))
     assert len(set(a)) == 4
     ops.reset_seed_counter(0)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (what a driver does that does not wrap the
+    command in torch.distributed.run): the script re-executes itself under torch.distributed.run with 2 ranks on
+    127.0.0.1; RENET_BENCH_LAUNCH_CHECK=1 makes the ranks rendezvous over gloo and print the launch fields instead of
+    measuring (no GPU here).  Under a launcher (WORLD_SIZE set) it must NOT spawn again."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR',
+                                                             'MASTER_PORT')}
+    env['RENET_BENCH_LAUNCH_CHECK'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line == {'launcher_check': True, 'n_gpus': 2, 'rccl_ranks_seen': 2, 'gpus_arg': 2}
+    # a rank of an existing launch: no re-spawn (one process, reports its own world)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'],
+                       env=dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['gpus_arg'] == 2
