@@ -102,6 +102,9 @@ class RENet(nn.Module):
         # behaviour (which entity shadows depends on the device's unsorted top-k order; `shadow_pick(side, cands)`
         # may override the choice -- the golden test drives it with the entities the reference run recorded).
         self.reference_shadowing = False
+        # inference advance: one history per sampled entity, relation segment of the GRU input broadcast (see
+        # _joint_topk_many); False builds the R-fold batches of rounds 1-3 (A/B runs, tests)
+        self.broadcast_relations = os.environ.get('RENET_ADVANCE_BROADCAST', '1') != '0'
         self.shadow_pick = None
         self._shadow = {}
 
@@ -468,7 +471,37 @@ def _joint_topk_many(self, ents, prob, subject=True):
         s_h = torch.zeros(n * R, H, device=dev)
         s_q = torch.zeros(n, H, device=dev)
         have = [i for i, e in enumerate(es) if len(hist_all[e]) != 0]
-        if have:
+        if have and self.broadcast_relations:
+            # ONE history per entity (round 4).  The R sequences of an entity share graph, RGCN rows, entity and global
+            # segments of X; only the relation segment differs, and it is constant over the steps.  So the batch is built
+            # for len(have) sequences instead of len(have) * R (the host-side construction of the R-fold batches was
+            # what an advance spent its time on: profiles/r03_c_infer_advance.txt), and the GRU input projection is
+            #     Gi[(e, r), step] = ([h2 | ent | . | glob] W_ih^T + b_ih)[e, step]  +  (rel[r] W_ih[:, 2H:3H]^T)
+            # a broadcast sum of a [S, 3H] and an [R, 3H] matrix; encoder_r's input has no relation segment at all.
+            # The recurrence runs over all len(have) * R sequences as before (h depends on r through Gi).
+            ents_h = np.asarray([es[i] for i in have], dtype=np.int64)
+            hists = [hist_all[e] for e in ents_h]
+            hts = [hist_t_all[e] for e in ents_h]
+            px, pxr = self.aggregator.forward_grouped((hists, hts), ents_h, np.zeros(len(have), dtype=np.int64),
+                                                      self.ent_embeds, rel_embeds, self.graph_dict, self.global_emb,
+                                                      reverse, ents_h)
+            nh = len(have)
+            x = px.data                                                              # [S, 4H] packed, time-major
+            w_ih, b_ih = self.encoder.weight_ih_l0, self.encoder.bias_ih_l0
+            p_base = K.gemm(x[:, :2 * H], w_ih[:, :2 * H], tb=True, bias=b_ih)        # [h2 | ent] part + bias
+            K.gemm(x[:, 3 * H:], w_ih[:, 3 * H:], tb=True, out=p_base, beta=1.0)      # + glob part
+            q_rel = K.gemm(rel_embeds.contiguous(), w_ih[:, 2 * H:3 * H], tb=True)    # [R, 3H]
+            gi = (p_base.view(-1, 1, 3 * H) + q_rel.view(1, R, 3 * H)).reshape(-1, 3 * H)
+            bs = px.batch_sizes.numpy()
+            off = ops.host_offsets(np.concatenate(([0], np.cumsum(bs))) * R)          # every step R times as wide
+            hh, _ = K.gru_fwd(gi, off, H, self.encoder.weight_hh_l0.contiguous(), self.encoder.bias_hh_l0.contiguous(),
+                              out_rows=nh * R)                                        # [nh * R, H], sorted position major
+            _, qq = self.encoder_r(pxr, total_rows=nh)
+            perm = torch.from_numpy(self.aggregator.last_batch.host.perm).to(dev)   # sorted position -> sequence
+            have_t = torch.as_tensor(have, device=dev)
+            s_h.view(n, R, H)[have_t[perm]] = hh.view(nh, R, H)
+            s_q[have_t[perm]] = qq[0]
+        elif have:
             seq_ent = np.repeat(np.asarray([es[i] for i in have], dtype=np.int64), R)
             seq_rel = np.tile(np.arange(R, dtype=np.int64), len(have))
             hists = [hist_all[e] for e in seq_ent]
