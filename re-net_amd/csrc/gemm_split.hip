@@ -282,6 +282,9 @@ __device__ __forceinline__ void mfma_tile_ld(const __bf16* __restrict__ sA, cons
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 __device__ __forceinline__ void store_tile(const SplitArgs& g, int m0, int n0, int z, int wm, int wn, int lane,
                                            const f32x16 (&acc)[2][2]) {
+#ifdef RENET_PROBE_NOSTORE          // probe builds only (tools/gemm_split_probe.py): what the C-store epilogue costs
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
     const bool split = g.split_k > 1;
     float* Cout = split ? g.partial + (size_t)z * g.M * g.N : g.C;
     const int ldo = split ? g.N : g.ldc;
@@ -1401,15 +1404,20 @@ int launch_tall(const SplitArgs& g, dim3 grid, hipStream_t st) {
 
 // 256-row tiles when the output has enough of them to fill the chip a few times (RENET_GEMM_TALL=0 disables,
 // =<n> sets the minimum tile count)
-bool use_tall(int M, int nbx, int split_k) {
+bool use_tall(int ta, int M, int nbx, int split_k) {
     static int min_tiles = -1;
+    static bool forced = false;
     if (min_tiles < 0) {
         const char* e = getenv("RENET_GEMM_TALL");
+        forced = e != nullptr;
         min_tiles = e ? atoi(e) : 1000;             // measured: logits 2048 x 23033 x 600 (1440 tiles) 395 -> 362 us;
                                                     // dW 23033 x 600 x 2048 (450 tiles: 1.76 rounds) 447 -> 480 us
         if (e && min_tiles == 0) min_tiles = 0x7fffffff;
     }
-    return (long)nbx * ((M + BMT - 1) / BMT) * split_k >= min_tiles;
+    const long tiles = (long)nbx * ((M + BMT - 1) / BMT) * split_k;
+    if (forced) return tiles >= min_tiles;
+    // round 4: as for the f16x3 kernels (use_tall_h3), K-contiguous A with a split k range from 200 tiles on (dfeat)
+    return tiles >= min_tiles || (!ta && split_k >= 4 && tiles >= 200);
 }
 
 // f16x3 kernels: the 256-row tile from RENET_H3_TALL tiles on (default 1000, as for the bf16x6 kernels; 0 disables).
@@ -1539,7 +1547,7 @@ static int gemm_planes_launch(bool bf16_mode, int ta, int tb, int M, int N, int 
         else if (!ta && tb) RENET_LAUNCH((gemm_bf16_kernel<false, true>), grid, dim3(THREADS), 0, st, g);
         else if (ta && !tb) RENET_LAUNCH((gemm_bf16_kernel<true, false>), grid, dim3(THREADS), 0, st, g);
         else RENET_LAUNCH((gemm_bf16_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
-    } else if (use_tall(M, nbx, split_k)) {
+    } else if (use_tall(ta, M, nbx, split_k)) {
         dim3 grid(nbx, (M + BMT - 1) / BMT, split_k);
         if (!ta && !tb) e = launch_tall<false, false>(g, grid, st);
         else if (!ta && tb) e = launch_tall<false, true>(g, grid, st);

@@ -248,6 +248,73 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* logits,
     }
 }
 
+// Same for fp32 output with the row held in REGISTERS (round 4): 512 threads, thread t owns columns t, t + 512, ...
+// (NQ <= 48 of them), every load of the row is in flight at once, max / exp / sum / write run on registers, LDS only
+// carries the two 8-value reductions.  No 92 KB of LDS per workgroup and <= 128 VGPRs => TWO workgroups (rows) per CU,
+// so the load of one row overlaps the exp / store of another (the LDS kernel below runs its phases back to back, one
+// row per CU at a time).  In place (dlogits == logits) is safe by construction: a thread reads all of its own columns
+// before it writes any, and nobody else touches them.
+template <int NQ>
+__global__ __launch_bounds__(512, 4) void softmax_ce_reg_kernel(const float* logits, const int32_t* __restrict__ target,
+                                                                int C, int ld, float grad_scale,
+                                                                float* __restrict__ row_loss, float* dlogits) {
+    __shared__ float red_m[8], red_s[8];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = target[b];
+    // the row through a raw buffer descriptor of exactly C floats: ONE vector offset (thread * 4) for all NQ accesses, the
+    // column block in the scalar offset; columns >= C read 0 and their stores are dropped by the range check
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(logits + (size_t)b * ld), (short)0, C * 4, 0x00020000);
+    const int voff = (int)threadIdx.x * 4;
+    float v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        v[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rin, voff, 2048 * q, 0));
+    float m = -INFINITY, xt = 0.f;
+    const int tq = t >> 9;                              // column t is element tq of thread t & 511
+    const bool mine = (int)threadIdx.x == (t & 511);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        // column threadIdx.x + 512 q < C, written against a SCALAR bound (the compiler otherwise keeps all NQ column
+        // indices alive, and spills them); the only use of the tail mask: exp(-inf) = 0 below
+        v[q] = (int)threadIdx.x < C - 512 * q ? v[q] : -INFINITY;
+        m = fmaxf(m, v[q]);
+        xt = (mine && q == tq) ? v[q] : xt;
+    }
+    m = wave_max(m);
+    if (lane == 0) red_m[wave] = m;
+    __syncthreads();
+    m = red_m[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fmaxf(m, red_m[w]);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        v[q] = expf(v[q] - m);
+        s += v[q];
+        // eight expf at a time: scheduled all at once the NQ expansions' temporaries overflow the 128-register budget
+        if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    s = wave_sum(s);
+    if (lane == 0) red_s[wave] = s;
+    __syncthreads();
+    s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += red_s[w];
+    if (mine) row_loss[b] = logf(s) + m - xt;                                   // the owner of column t
+    if (dlogits) {
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(dlogits + (size_t)b * ld, (short)0, C * 4,
+                                                                             0x00020000);
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const float o = (v[q] * inv - ((mine && q == tq) ? 1.f : 0.f)) * grad_scale;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), rout, voff, 2048 * q, 0);
+        }
+    }
+}
+
 // Same, with the row staged in LDS (C * 4 <= 128 KB: 23 033 entities = 92 KB): the three passes of the kernel above
 // re-read the row from the fabric (all 1024 rows are in flight at once, 94 MB against 32 MB of L2); here the row is
 // read ONCE by 1024 threads (16 waves keep enough loads in flight for one workgroup per CU) and the max / sum / write
@@ -556,7 +623,18 @@ static int softmax_ce_impl(const float* logits, const int32_t* target, int B, in
     if (B < 0 || C <= 0 || ld < C) return RENET_ERR_BADARG;
     if (B == 0) return RENET_OK;
     const size_t lds = (size_t)C * sizeof(float);
-    if (lds <= 128 * 1024 && C >= 4096) {
+    static int reg_ok = -1;                 // RENET_SOFTMAX_REG=0: the LDS-staged kernel for every wide row (A/B runs)
+    if (reg_ok < 0) {
+        const char* e_ = getenv("RENET_SOFTMAX_REG");
+        reg_ok = (e_ && e_[0] == '0') ? 0 : 1;
+    }
+    if (reg_ok && !dl16 && C >= 4096 && C <= 48 * 512) {
+        const dim3 grid(B), blk(512);
+        hipStream_t st = (hipStream_t)stream;
+        if (C <= 16 * 512) RENET_LAUNCH((softmax_ce_reg_kernel<16>), grid, blk, 0, st, logits, target, C, ld, grad_scale, row_loss, dlogits);
+        else if (C <= 32 * 512) RENET_LAUNCH((softmax_ce_reg_kernel<32>), grid, blk, 0, st, logits, target, C, ld, grad_scale, row_loss, dlogits);
+        else RENET_LAUNCH((softmax_ce_reg_kernel<48>), grid, blk, 0, st, logits, target, C, ld, grad_scale, row_loss, dlogits);
+    } else if (lds <= 128 * 1024 && C >= 4096) {
         static bool attr_set = false;      // benign race: the attribute is idempotent
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute((const void*)softmax_ce_lds_kernel,

@@ -94,6 +94,18 @@ __global__ __launch_bounds__(1024) void joint_softmax_kernel(float* x, int ld, i
 }
 
 // ---- radix select ---------------------------------------------------------------------------------------------
+// Order-preserving key of a float: unsigned comparison of keys == comparison of the values for EVERY finite input
+// (the raw bit pattern ranks negatives, and -0.0, above all positives).  Non-negative values get the sign
+// bit set, negative values are inverted; -0.0 is treated as +0.0 and a NaN as the SMALLEST key (never selected
+// before any number) -- the joint probabilities this kernel is used on are >= 0, for which the key is the raw bit
+// pattern with the top bit set, i.e. the selection is what it was.
+__device__ __forceinline__ unsigned topk_key(float v) {
+    unsigned u = __float_as_uint(v);
+    if (v != v) return 0u;
+    if (u == 0x80000000u) u = 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 struct SelState {          // per row of the [n, M] matrix
     unsigned prefix;       // the key bits decided so far (high bits), 0 before pass 1
     int remaining;         // results still to be taken from the undecided elements
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_hist_kernel(const float* __re
     const int per = (M + gridDim.x - 1) / gridDim.x;
     const int i0 = blockIdx.x * per, i1 = min(M, i0 + per);
     for (int i = i0 + threadIdx.x; i < i1; i += TK_THREADS) {
-        const unsigned key = __float_as_uint(xr[i]);
+        const unsigned key = topk_key(xr[i]);
         if (PASS == 0) atomicAdd(&h[key >> 20], 1u);
         else if (PASS == 1) { if ((key >> 20) == prefix) atomicAdd(&h[(key >> 8) & 0xFFFu], 1u); }
         else { if ((key >> 8) == prefix) atomicAdd(&h[key & 0xFFu], 1u); }
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_collect_kernel(const float* _
     const int i0 = blockIdx.x * per, i1 = min(M, i0 + per);
     for (int i = i0 + threadIdx.x; i < i1; i += TK_THREADS) {
         const float v = xr[i];
-        const unsigned key = __float_as_uint(v);
+        const unsigned key = topk_key(v);
         if (key > T) {
             const int slot = atomicAdd(&st[rowid].cnt_gt, 1);
             if (slot < n_gt) { out_val[(size_t)rowid * k + slot] = v; out_idx[(size_t)rowid * k + slot] = i; }

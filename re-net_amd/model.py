@@ -463,7 +463,9 @@ def _joint_topk_many(self, ents, prob, subject=True):
     else:
         hist_all, hist_t_all, rel_embeds, reverse = self.o_hist_test, self.o_hist_test_t, self.rel_embeds[R:], True
     out = {}
-    chunk = max(1, (1 << 26) // max(R * self.in_dim, 1))               # bound the [n*R, N_ent] score block
+    # bound the [n*R, N_ent] score block: 2^28 floats = 1 GiB (of 288 GB), ~45 entities at ICEWS18 sizes -- an advance
+    # at num_k 1000 is ~44 chunks instead of the ~180 of the 2^26 bound of rounds 1-3 (fixed cost per chunk ~1.5 ms)
+    chunk = max(1, (1 << int(os.environ.get('RENET_ADVANCE_BLOCK_LOG2', '28'))) // max(R * self.in_dim, 1))
     ents = [int(e) for e in ents]
     for c0 in range(0, len(ents), chunk):
         es = ents[c0:c0 + chunk]
@@ -557,19 +559,39 @@ def _advance_side(self, picks, prob, subject):
     cands = [int(picks_np[c // self.num_k]) for c in best_np]          # model.py:254-255: s = s_to_id[idx.item()]
     side = 's' if subject else 'o'
     self._shadow[side] = self.shadow_pick(side, cands) if self.shadow_pick is not None else cands[-1]
-    for c in best_np:
-        e = int(picks_np[c // self.num_k])
-        code = int(per_ent[e][1][c % self.num_k])
+    # the winners' (r, o) codes in ONE gather + ONE copy (an int(tensor[i]) per winner is a device sync each)
+    win_ent = picks_np[best_np // self.num_k]
+    codes = torch.stack([per_ent[int(e)][1] for e in uniq])                # [n_uniq, num_k]
+    rows = torch.from_numpy(np.searchsorted(uniq, win_ent)).to(codes.device)
+    codes_np = codes[rows, torch.from_numpy(best_np % self.num_k).to(codes.device)].cpu().numpy().astype(np.int64)
+    touched = self._touched_sets()[0 if subject else 1]
+    for e, code in zip(win_ent.tolist(), codes_np.tolist()):
         rr, other = code // self.in_dim, code % self.in_dim
         cache[e] = self.update_cache(cache[e], rr, np.asarray([other]))
         cache_t[e] = now
+        touched.add(e)
+
+
+def _touched_sets(self):
+    """(subjects, objects) whose prediction cache is non-empty, kept by _advance_side so that rolling the histories and
+    collecting the predicted facts walk ~2 * num_k entities instead of all 2 * N_ent.  The sets belong to the CURRENT
+    cache lists: when a caller replaced them (test.py restores s_his_cache / o_his_cache from a checkpoint,
+    test.py:70-81; init_history resets them) they are rebuilt by one full scan."""
+    key = (id(self.s_his_cache), id(self.o_his_cache))
+    if getattr(self, '_touched_key', None) != key:
+        self._touched = tuple({e for e in range(self.in_dim) if len(c[e]) != 0}
+                              for c in (self.s_his_cache, self.o_his_cache))
+        self._touched_key = key
+    return self._touched
 
 
 def _roll_histories(self):
     """model.py:305-321: move every non-empty prediction cache into the entity's rolling window."""
-    for hist, hist_t, cache, cache_t in ((self.s_hist_test, self.s_hist_test_t, self.s_his_cache, self.s_his_cache_t),
-                                         (self.o_hist_test, self.o_hist_test_t, self.o_his_cache, self.o_his_cache_t)):
-        for e in range(self.in_dim):
+    touched = self._touched_sets()
+    for k, (hist, hist_t, cache, cache_t) in enumerate(
+            ((self.s_hist_test, self.s_hist_test_t, self.s_his_cache, self.s_his_cache_t),
+             (self.o_hist_test, self.o_hist_test_t, self.o_his_cache, self.o_his_cache_t))):
+        for e in sorted(touched[k]):
             if len(cache[e]) != 0:
                 while len(hist[e]) >= self.seq_len:
                     hist[e].pop(0)
@@ -578,6 +600,25 @@ def _roll_histories(self):
                 hist_t[e].append(cache_t[e])
                 cache[e] = []
                 cache_t[e] = None
+        touched[k].clear()
+
+
+def _cached_facts(self):
+    """utils.get_data (utils.py:95-113) restricted to the entities whose caches are non-empty: the same unique
+    (s, r, o) rows."""
+    touched = self._touched_sets()
+    rows = []
+    for e in sorted(touched[0]):
+        a = np.asarray(self.s_his_cache[e], dtype=np.int64).reshape(-1, 2)
+        if len(a):
+            rows.append(np.stack((np.full(len(a), e), a[:, 0], a[:, 1]), axis=1))
+    for e in sorted(touched[1]):
+        a = np.asarray(self.o_his_cache[e], dtype=np.int64).reshape(-1, 2)
+        if len(a):
+            rows.append(np.stack((a[:, 1], a[:, 0], np.full(len(a), e)), axis=1))
+    if not rows:
+        return None
+    return np.unique(np.concatenate(rows), axis=0)
 
 
 def _advance_time(self, t, global_model):
@@ -588,7 +629,7 @@ def _advance_time(self, t, global_model):
     prob_ob = torch.softmax(ob.view(-1), dim=0)
     self._advance_side(self.sample_entities(prob_ob), prob_ob, subject=False)
     now = _as_int(self.latest_time)
-    self.data = get_data(self.s_his_cache, self.o_his_cache)
+    self.data = self._cached_facts()                                                 # = get_data(s_his_cache, o_his_cache)
     if self.data is not None:
         self.graph_dict[now] = get_big_graph(self.data, self.num_rels)               # model.py:301
     emb, _, _ = global_model.predict(self.latest_time, self.graph_dict, subject=True)
@@ -783,6 +824,8 @@ RENet.sample_entities = _sample
 RENet._joint_topk_many = _joint_topk_many
 RENet._advance_side = _advance_side
 RENet._roll_histories = _roll_histories
+RENet._touched_sets = _touched_sets
+RENet._cached_facts = _cached_facts
 RENet._advance_time = _advance_time
 RENet.predict = _predict
 RENet.evaluate = _evaluate

@@ -1273,7 +1273,10 @@ def joint_softmax(logits, num_rels, logits_r, prob_e):
 
 
 def topk_positive(x, k):
-    """Top-k of every row of a non-negative fp32 matrix [n, M] -> (values [n, k], int64 indices [n, k]), unsorted."""
+    """Top-k of every row of an fp32 matrix [n, M] -> (values [n, k], int64 indices [n, k]).  Exact selection by an
+    order-preserving key (any sign; -0.0 == +0.0; NaNs rank below every number).  The k results come back UNSORTED and
+    their slot order -- and which of several elements EQUAL to the k-th value is taken -- depends on the arrival order of
+    atomics: sort the result where a deterministic order matters (model.py does not depend on it)."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
         raise RenetHipError('topk_positive needs a 2-D float32 device tensor with unit inner stride')
     n, m = x.shape

@@ -115,7 +115,7 @@ def test_config5_training_step_in_bf16_mode(dev, mode):
     for tag, loss in (('s', loss_s), ('o', loss_o)):
         ref = float(gold['loss_' + tag])
         report['loss_' + tag] = abs(loss.item() - ref) / abs(ref)
-        assert report['loss_' + tag] < 2e-3, (tag, loss.item(), ref)
+        assert report['loss_' + tag] < 5e-5, (tag, loss.item(), ref)          # observed 4e-7 / 6e-7 (bench: 4e-6 - 1.3e-5)
     per_dir = {'s': taps[:4], 'o': taps[4:8]}
     for tag in ('s', 'o'):
         lens = np.diff(np.asarray(gold['hist_%s_seq_ptr' % tag]))
@@ -124,7 +124,7 @@ def test_config5_training_step_in_bf16_mode(dev, mode):
             a = t.cpu().numpy()
             full = np.zeros_like(a)
             full[perm] = a
-            ok, err, scale = C.compare_packed(gold, '%s_%s' % (tag, key), full, rel=2e-2)
+            ok, err, scale = C.compare_packed(gold, '%s_%s' % (tag, key), full, rel=8e-3)      # observed 2.7e-3 of max
             report['%s_%s' % (tag, key)] = err / scale
             assert ok, (tag, key, err, scale)
     worst = 0.0
@@ -136,7 +136,7 @@ def test_config5_training_step_in_bf16_mode(dev, mode):
         scale = float(np.abs(ref_s).max())
         err = float(np.abs(got_s - ref_s).max())
         worst = max(worst, err / scale)
-        assert err <= 0.15 * scale, (k, err, scale)
+        assert err <= 0.15 * scale, (k, err, scale)                 # observed worst entry 7.3 % of its tensor's max: 2x
         if ('grad.' + k + '__norm') in gold:
             nr = float(gold['grad.' + k + '__norm'])
             assert abs(float(np.linalg.norm(g.astype(np.float64))) - nr) <= 5e-2 * nr, k

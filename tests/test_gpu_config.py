@@ -350,7 +350,7 @@ def test_inference_at_config_scale_matches_reference(dev, shadowing):
     assert len(samples) == 0 and len(gd) - n_graphs0 == int(gold['n_new_graphs'])
     # predicted graphs of the timestamps advanced over: top-1000 of ~970 x 5.9 M joint probabilities per side.
     # The candidate SET may differ from the reference's at its boundary (the 1000th and 1001st value can sit
-    # closer than the fp32 rounding of two different summation orders): allow 0.5 % of the facts to differ.
+    # closer than the fp32 rounding of two different summation orders): allow ONE swapped pair (2 facts) of 3781.
     mine = []
     for t in list(gd.keys())[n_graphs0:]:
         s_, r_, o_ = gd[t].global_triples()
@@ -359,7 +359,7 @@ def test_inference_at_config_scale_matches_reference(dev, shadowing):
     b = set(map(tuple, gold['new_graph_quads'].tolist()))
     diff = len(a ^ b)
     print('predicted facts: mine %d, reference %d, symmetric difference %d' % (len(a), len(b), diff))
-    assert diff <= 0.005 * len(b), (len(a), len(b), diff)
+    assert diff <= 2, (len(a), len(b), diff)          # observed on MI355X (rounds 3-4, every GEMM mode): 0 of 3781
     first_of_t = np.nonzero(np.diff(case['valid'][eval_idx, 3]) != 0)[0] + 1
     keep = np.ones(len(eval_idx), dtype=bool)
     if shadowing:
@@ -370,7 +370,7 @@ def test_inference_at_config_scale_matches_reference(dev, shadowing):
     dr = np.abs(ranks[keep] - gold['ranks'][keep])
     print('rank differences:', dr.reshape(-1).tolist())
     # filtered ranks among 23 033 entities: fp32 near-ties may move a rank by a few positions
-    assert float(np.mean(dr == 0)) >= 0.9 and dr.max() <= 3, dr         # observed on MI355X: all equal
+    assert float(np.mean(dr == 0)) >= 0.97 and dr.max() <= 1, dr        # observed on MI355X: all equal
     from oracle import renet_oracle as O
     m1, m2 = O.mrr_hits(ranks[keep].reshape(-1)), O.mrr_hits(gold['ranks'][keep].reshape(-1))
     assert abs(m1['mrr'] - m2['mrr']) < 2e-3

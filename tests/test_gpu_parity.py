@@ -170,6 +170,50 @@ def test_f16x3_gemm_is_fp32_class_at_any_tensor_magnitude(dev, scale_a, scale_b)
     assert errs['f16x3'] <= 3.0 * max(errs['f32'], errs['bf16x6'], 0.5), errs
 
 
+def test_f16x3_gemm_on_sparse_magnitude_operands(dev):
+    """Review r3 (weak 1e): the f16x3 split's element accuracy is per TENSOR (an ABSOLUTE 2^-39 max|x| below 2^-29 max|x|),
+    so the operands to worry about are the ones whose magnitudes are sparse: a late-training CE gradient (softmax -
+    onehot: one entry of O(1/B) per row among thousands of 1e-9..1e-6) and a mostly-zero embedding gradient.  For
+    both, every output's error against fp64 must stay within a small multiple of that dot product's OWN fp32 rounding
+    bound sum_k |a b| 2^-24 plus the absolute floor the header states (k 2^-39 max|a| max|b|) -- and within 3x of what
+    the 24-bit split and the exact-fp32 kernel give."""
+    import renet_hip as K
+    rng = np.random.RandomState(21)
+    b_, c_, d_ = 512, 6000, 600
+    # dlogits of a confident model: probabilities ~1e-9..1e-5 except a handful per row, minus the one-hot, over B
+    logit = rng.standard_normal((b_, c_)) * 4.0
+    logit[np.arange(b_), rng.randint(0, c_, b_)] += 25.0
+    p_ = np.exp(logit - logit.max(1, keepdims=True))
+    p_ /= p_.sum(1, keepdims=True)
+    tgt = rng.randint(0, c_, b_)
+    dl = p_.copy()
+    dl[np.arange(b_), tgt] -= 1.0
+    dl = (dl / b_).astype(np.float32)
+    w = (rng.standard_normal((c_, d_)) * 0.05).astype(np.float32)
+    feat = rng.standard_normal((b_, d_)).astype(np.float32)
+    feat[rng.uniform(size=feat.shape) < 0.5] = 0.0                      # dropout zeros
+    # a mostly-zero gradient matrix (rows of entities the batch never touched) times a dense weight
+    sparse = np.zeros((4000, 200), dtype=np.float32)
+    rows = rng.choice(4000, 60, replace=False)
+    sparse[rows] = (rng.standard_normal((60, 200)) * np.exp2(rng.uniform(-30, 0, (60, 1)))).astype(np.float32)
+    wl = (rng.standard_normal((200, 200)) * 0.1).astype(np.float32)
+    cases = [('dfeat = dlogits W', dl, w, False, False), ('dW = dlogits^T feat', dl, feat, True, False),
+             ('sparse rows x W', sparse, wl, False, False)]
+    for name, a, b, ta, tb in cases:
+        a64 = (a.T if ta else a).astype(np.float64)
+        b64 = (b.T if tb else b).astype(np.float64)
+        ref = a64 @ b64
+        bound = (np.abs(a64) @ np.abs(b64)) * 2.0 ** -24 + a64.shape[1] * 2.0 ** -39 * np.abs(a).max() * np.abs(b).max()
+        errs = {}
+        for mode in ('f32', 'bf16x6', 'f16x3'):
+            out = K.gemm(_to(a, dev), _to(b, dev), ta=ta, tb=tb, mode=mode, split_k=1).cpu().numpy().astype(np.float64)
+            errs[mode] = float((np.abs(out - ref) / np.maximum(bound, 1e-300)).max())
+        print('%-22s worst error in units of the dot product\'s fp32 bound: %s' % (name, {k: round(v, 2) for k, v in
+                                                                                      errs.items()}))
+        assert errs['f16x3'] <= 6.0, (name, errs)
+        assert errs['f16x3'] <= 3.0 * max(errs['f32'], errs['bf16x6'], 1.0), (name, errs)
+
+
 def test_f16x3_gemm_bounds_and_special_values(dev):
     """Operand handles: a bound larger than the true maximum (by 2^10) only costs binades; zero operands; NaN flows
     through; a registered weight's maxima are cached and refreshed when the weight changes."""
@@ -1069,6 +1113,26 @@ def test_topk_positive_equals_torch_topk(dev, n, m, k):
     wide[:, :m] = x
     v2, i2 = K.topk_positive(wide[:, :m], k)
     assert torch.equal(torch.sort(v2, dim=1, descending=True)[0], ref_v)
+
+
+def test_topk_orders_signed_values_zeros_and_nans(dev):
+    """the radix select orders by an order-preserving key, not by the raw bit pattern -- negative values,
+    -0.0 and NaNs (which the raw pattern ranks ABOVE every positive number) must not be selected before larger numbers."""
+    import renet_hip as K
+    g = torch.Generator(device='cpu').manual_seed(3)
+    x = torch.randn(5, 6000, generator=g)
+    x[:, ::11] = -0.0
+    x[:, 5::13] = 0.0
+    x[1] = -x[1].abs() - 1.0                                     # an all-negative row
+    x[2, 100:140] = float('nan')                                # NaNs: never taken while a number is left
+    x = x.to(dev)
+    for k in (1, 7, 300):
+        vals, idx = K.topk_positive(x, k)
+        assert not torch.isnan(vals).any()
+        ref_v, _ = torch.topk(torch.nan_to_num(x, nan=float('-inf')), k, dim=1, sorted=True)
+        got_v, _ = torch.sort(vals, dim=1, descending=True)
+        assert torch.equal(got_v + 0.0, ref_v + 0.0)            # (+0.0: -0.0 and 0.0 compare equal, their bits may differ)
+        assert torch.equal(torch.gather(x, 1, idx), vals)
 
 
 def test_joint_softmax_matches_the_reference_expression(dev):
