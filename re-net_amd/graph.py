@@ -832,13 +832,28 @@ class _HostView(object):
         self.__dict__.update(pb.host_small)
 
 
+def h2d(a, device):
+    """numpy array -> device tensor without blocking the host on the stream: staged through a pinned buffer of torch's
+    caching host allocator and copied asynchronously (a copy from pageable memory waits for everything queued on the
+    stream -- in the inference advance that serialised host batch building and device work chunk by chunk).  Arrays
+    above 1 MiB keep the blocking copy: their transfer time dominates, and first-touch pinning of large size classes costs
+    milliseconds (measured: it tripled the 3-timestamp stream evaluation).  RENET_ASYNC_H2D=0: always blocking."""
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if torch.device(device).type != 'cuda' or _os.environ.get('RENET_ASYNC_H2D', '1') == '0' or t.numel() == 0 or \
+            t.numel() * t.element_size() > (1 << 20):
+        return t.to(device)
+    pinned = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    pinned.copy_(t)
+    return pinned.to(device, non_blocking=True)
+
+
 class DeviceGraph(object):
     """Device-resident view of a HostBatch / PackedBatch: ONE int32 upload + ONE float32 upload, sliced
     into views."""
 
     def __init__(self, hb, device):
         pb = hb if isinstance(hb, PackedBatch) else PackedBatch(hb)
-        dev = torch.from_numpy(pb.ints).to(device, non_blocking=False)
+        dev = h2d(pb.ints, device)
         self._buf = dev
         views = {nm: dev[o_:o_ + n] for nm, o_, n in zip(pb.names, pb.offs, pb.sizes)}
         for nm in pb.names:
@@ -849,7 +864,7 @@ class DeviceGraph(object):
             p.order, p.seg_ptr, p.target = views[pn + '.order'], views[pn + '.seg_ptr'], views[pn + '.target']
             p.num_segments = nseg
             setattr(self, pn, p)
-        self.norm = torch.from_numpy(pb.norm).to(device)
+        self.norm = h2d(pb.norm, device)
         self.ndata = {}                  # 'h' lives here, as on the reference's DGL graph
         self.heavy_thresh = pb.scalars.get('heavy_thresh', HEAVY)
         for f in ('heavy_rows', 'heavy_rows_out'):

@@ -499,8 +499,8 @@ def _joint_topk_many(self, ents, prob, subject=True):
             hh, _ = K.gru_fwd(gi, off, H, self.encoder.weight_hh_l0.contiguous(), self.encoder.bias_hh_l0.contiguous(),
                               out_rows=nh * R)                                        # [nh * R, H], sorted position major
             _, qq = self.encoder_r(pxr, total_rows=nh)
-            perm = torch.from_numpy(self.aggregator.last_batch.host.perm).to(dev)   # sorted position -> sequence
-            have_t = torch.as_tensor(have, device=dev)
+            perm = G.h2d(self.aggregator.last_batch.host.perm, dev)                 # sorted position -> sequence
+            have_t = G.h2d(np.asarray(have, dtype=np.int64), dev)
             s_h.view(n, R, H)[have_t[perm]] = hh.view(nh, R, H)
             s_q[have_t[perm]] = qq[0]
         elif have:
@@ -522,11 +522,12 @@ def _joint_topk_many(self, ents, prob, subject=True):
             q_seq[perm] = qq[0]
             s_h[rows] = h_seq
             s_q[torch.as_tensor(have, device=dev)] = q_seq[::R]                      # the R copies are identical
-        ent_rows = self.ent_embeds[torch.as_tensor(es, device=dev)]                   # [n, H]
+        es_t = G.h2d(np.asarray(es, dtype=np.int64), dev)                              # (async: the host runs ahead)
+        ent_rows = self.ent_embeds[es_t]                                              # [n, H]
         feat = torch.cat((ent_rows.repeat_interleave(R, dim=0), s_h, rel_embeds.repeat(n, 1)), dim=1)
         logits = _linear_eval(self.linear, feat)                                     # [n*R, N_ent]
         logits_r = _linear_eval(self.linear_r, torch.cat((ent_rows, s_q), dim=1))    # [n, R]
-        prob_e = prob[torch.as_tensor(es, device=dev)].contiguous()
+        prob_e = prob[es_t].contiguous()
         if self.reference_shadowing or self.in_dim * 4 > 128 * 1024 or R > 1024 or not logits.is_cuda or \
                 os.environ.get('RENET_TOPK') == 'torch':
             # the ORDER of an unsorted torch.topk result is observable through the shadowing quirk: keep
@@ -565,11 +566,36 @@ def _advance_side(self, picks, prob, subject):
     rows = torch.from_numpy(np.searchsorted(uniq, win_ent)).to(codes.device)
     codes_np = codes[rows, torch.from_numpy(best_np % self.num_k).to(codes.device)].cpu().numpy().astype(np.int64)
     touched = self._touched_sets()[0 if subject else 1]
+    if getattr(self.update_cache, '__func__', None) is not _update_cache:
+        # update_cache was overridden: one call per winner, as the reference does (model.py:254-258)
+        for e, code in zip(win_ent.tolist(), codes_np.tolist()):
+            rr, other = code // self.in_dim, code % self.in_dim
+            cache[e] = self.update_cache(cache[e], rr, np.asarray([other]))
+            cache_t[e] = now
+            touched.add(e)
+        return
+    per = {}
     for e, code in zip(win_ent.tolist(), codes_np.tolist()):
-        rr, other = code // self.in_dim, code % self.in_dim
-        cache[e] = self.update_cache(cache[e], rr, np.asarray([other]))
+        per.setdefault(e, []).append((code // self.in_dim, code % self.in_dim))
+    for e, pairs in per.items():
+        cache[e] = _bulk_update_cache(cache[e], pairs)
         cache_t[e] = now
         touched.add(e)
+
+
+def _bulk_update_cache(cache_e, pairs):
+    """The result of `for (r, o) in pairs: cache_e = update_cache(cache_e, r, [o])` (model.py:421-446: a pair is appended
+    unless the cache already holds it) with ONE array rebuild instead of an np.isin + np.stack per pair."""
+    old = np.asarray(cache_e, dtype=np.int64).reshape(-1, 2)
+    seen = set(map(tuple, old.tolist()))
+    add = []
+    for pr in pairs:
+        if pr not in seen:
+            seen.add(pr)
+            add.append(pr)
+    if not add:
+        return old
+    return np.concatenate((old, np.asarray(add, dtype=np.int64).reshape(-1, 2)), axis=0)
 
 
 def _touched_sets(self):

@@ -151,6 +151,12 @@ def test_train_mode_filtered_mrr_matches_reference_statistically(mode):
           '(%.0f s)' % (mode, np.array2string(mine, precision=4), mine.mean(), np.array2string(ref, precision=4),
                         ref.mean(), diff, se, out['seconds']))
     assert abs(diff) <= 0.002 + 2.0 * se, (mode, mine.tolist(), ref.tolist())
+    # PAIRED by seed (the sharper statement: a seed fixes initialisation and batch order on both sides, only the dropout
+    # masks differ): observed per-seed differences on MI355X +0.0007 / -0.0018 / -0.0029 in every fp32-class mode
+    d = mine - ref[:len(mine)]
+    se_p = float(d.std(ddof=1) / np.sqrt(len(d)))
+    print('   paired by seed: differences %s, mean %+.6f, s.e. %.6f' % (np.array2string(d, precision=4), d.mean(), se_p))
+    assert abs(d.mean()) <= 0.002 + 2.0 * se_p, (mode, d.tolist())
     # the epoch losses (means over dropout noise as well) must agree much more tightly than the ranks
     el_ref = np.asarray(gold['epoch_loss'], dtype=np.float64)[:, -1]
     el = np.asarray(out['epoch_loss'], dtype=np.float64)[:, -1]

@@ -174,9 +174,9 @@ def test_f16x3_gemm_on_sparse_magnitude_operands(dev):
     """Review r3 (weak 1e): the f16x3 split's element accuracy is per TENSOR (an ABSOLUTE 2^-39 max|x| below 2^-29 max|x|),
     so the operands to worry about are the ones whose magnitudes are sparse: a late-training CE gradient (softmax -
     onehot: one entry of O(1/B) per row among thousands of 1e-9..1e-6) and a mostly-zero embedding gradient.  For
-    both, every output's error against fp64 must stay within a small multiple of that dot product's OWN fp32 rounding
-    bound sum_k |a b| 2^-24 plus the absolute floor the header states (k 2^-39 max|a| max|b|) -- and within 3x of what
-    the 24-bit split and the exact-fp32 kernel give."""
+    both, every output's error against fp64 -- in units of that dot product's OWN fp32 rounding bound sum_k |a b| 2^-24 plus
+    the absolute floor the header states (k 2^-39 max|a| max|b|) -- must stay within 3x of what the 24-bit split and the
+    exact-fp32 kernel give on the same operands."""
     import renet_hip as K
     rng = np.random.RandomState(21)
     b_, c_, d_ = 512, 6000, 600
@@ -210,8 +210,10 @@ def test_f16x3_gemm_on_sparse_magnitude_operands(dev):
             errs[mode] = float((np.abs(out - ref) / np.maximum(bound, 1e-300)).max())
         print('%-22s worst error in units of the dot product\'s fp32 bound: %s' % (name, {k: round(v, 2) for k, v in
                                                                                       errs.items()}))
-        assert errs['f16x3'] <= 6.0, (name, errs)
+        # (fp32 ACCUMULATION over K = 6000 / 512 terms alone puts the exact-fp32 kernel at tens of these units: observed on
+        # MI355X f32 47.8 / bf16x6 31.7 / f16x3 27.0 for dfeat -- the split modes are not the limiting error here)
         assert errs['f16x3'] <= 3.0 * max(errs['f32'], errs['bf16x6'], 1.0), (name, errs)
+        assert errs['f16x3'] <= 0.25 * a64.shape[1], (name, errs)
 
 
 def test_f16x3_gemm_bounds_and_special_values(dev):

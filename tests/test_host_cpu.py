@@ -614,3 +614,23 @@ def test_thread_prefetcher_keeps_order_and_propagates_errors():
         for x in pipeline.BatchPrefetcher(bad, range(10), 4, threads=True):
             got.append(x)
     assert got == [0, 1, 2, 3, 4]
+
+
+def test_bulk_cache_update_equals_one_update_cache_call_per_winner():
+    """model._bulk_update_cache (round 4: the inference advance groups the winners of a timestamp by entity) against the
+    reference-shaped sequence of update_cache calls (model.py:421-446 / 254-258): same rows in the same order, for empty
+    and pre-filled caches, repeated pairs and repeated relations."""
+    import model as M
+
+    class Dummy(object):
+        in_dim = 50
+    rng = np.random.RandomState(0)
+    for trial in range(200):
+        n0 = int(rng.randint(0, 6))
+        start = np.unique(rng.randint(0, 4, (n0, 2)) * np.array([1, 7]), axis=0) if n0 else []
+        pairs = [(int(r), int(o)) for r, o in zip(rng.randint(0, 4, 12), rng.randint(0, 5, 12) * 7)]
+        seq = start
+        for r, o in pairs:
+            seq = M._update_cache(Dummy(), seq, r, np.asarray([o]))
+        got = M._bulk_update_cache(start, pairs)
+        assert np.array_equal(np.asarray(seq, dtype=np.int64).reshape(-1, 2), got), (trial, start, pairs)
