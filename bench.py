@@ -135,11 +135,13 @@ def main():
         dist.all_reduce(ones)                        # RCCL is really connecting `world` ranks
         ranks_seen = int(round(float(ones.item())))
 
+    if args.dtype == 'bf16':
+        # bf16 STORAGE mode (renet_gemm_bf16s); RENET_BF16_STORAGE=0 keeps fp32 tensors and rounds inside the GEMMs.
+        # Selected through the environment BEFORE the library wrapper is imported (it reads RENET_GEMM once): the
+        # benchmark does not reach into the module's state
+        os.environ['RENET_GEMM'] = 'bf16' if os.environ.get('RENET_BF16_STORAGE') == '0' else 'bf16s'
     import renet_hip as K
     K.lib()
-    if args.dtype == 'bf16':
-        # bf16 STORAGE mode (renet_gemm_bf16s); RENET_BF16_STORAGE=0 keeps fp32 tensors and rounds inside the GEMMs
-        K.GEMM_MODE = 'bf16' if os.environ.get('RENET_BF16_STORAGE') == '0' else 'bf16s'
     import model as M
     import parallel
     import preprocess as P
@@ -203,7 +205,6 @@ def main():
             return net.loss_prepared_pair(*preps)       # the four GRU recurrences of the two passes share one launch
 
         def train_step(self, *preps):
-            ops_mod_.SHARED_GRAPH_SEEDS = self.exact         # one replicated graph: same RGCN dropout masks on every rank
             with opt.step_scope(head_passes=1 if len(preps) == 1 else 2, average=not self.exact):
                 loss = self.step_loss(*preps)
                 loss.backward()

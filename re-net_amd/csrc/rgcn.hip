@@ -404,7 +404,12 @@ __device__ __forceinline__ void row_epilogue(const GatherArgs& g, int row, bool 
     }
 }
 
-template <int SI, int NCH, int UNR, bool TR, int MX>
+// COMPACT (the pruned backward launch, round 4): that launch walks the item stream of ALL rows for the edges whose source
+// lies in the row prefix (src < src_limit: 150 k of the 268 k edges of the bench batch), and a skipped edge still
+// occupied one of the UNR slots of a batch (no memory traffic, but a third of the loop iterations).  The wave now
+// ballots which of its <= 64 items are live (flush items always; edges by their source) and pops the set bits of that
+// mask instead of counting 0..n: only live items reach the load pipe; order, and therefore the result, is unchanged.
+template <int SI, int NCH, int UNR, bool TR, int MX, bool COMPACT = false>
 __device__ __forceinline__ void gather_item_group(const ItemArgs& a, int grp) {
     constexpr bool XB = MX == 2, WB = MX >= 1;
     constexpr int D = 100 * SI;
@@ -440,15 +445,30 @@ __device__ __forceinline__ void gather_item_group(const ItemArgs& a, int grp) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    for (int k = 0; k < n; k += UNR) {
+    unsigned long long live = 0ull;
+    if constexpr (COMPACT) live = __builtin_amdgcn_ballot_w64(lane < n && (my_t < 0 || my_src < g.src_limit));
+    for (int k = 0; COMPACT ? live != 0ull : k < n; k += UNR) {
         float4 xv[UNR][NCH];
         float4 wv[UNR][NCH][WCH];
         float scv[UNR];
+        int pick[UNR];                                   // item index of slot u (63 + "nop" when the batch runs short)
+        bool have[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int idx = min(k + u, 63);
+            if constexpr (COMPACT) {
+                have[u] = live != 0ull;
+                pick[u] = have[u] ? __builtin_ctzll(live) : 63;
+                live &= live - 1ull;                     // (0 stays 0)
+            } else {
+                have[u] = (k + u) < n;
+                pick[u] = min(k + u, 63);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = pick[u];
             const int src = __builtin_amdgcn_readlane(my_src, idx);            // wave-uniform (SGPR)
-            const int t = (k + u) < n ? __builtin_amdgcn_readlane(my_t, idx) : kItemNop;   // (n may be 64)
+            const int t = have[u] ? __builtin_amdgcn_readlane(my_t, idx) : kItemNop;       // (n may be 64)
             const bool edge = t >= 0 && src < g.src_limit;
             const bool flush = t == kItemFlush || t <= kItemFlushMap;
             const bool flush_ad = flush && g.addend != nullptr && src < g.addend_rows;
@@ -479,9 +499,9 @@ __device__ __forceinline__ void gather_item_group(const ItemArgs& a, int grp) {
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const int idx = min(k + u, 63);
+            const int idx = pick[u];
             const int src = __builtin_amdgcn_readlane(my_src, idx);
-            const int t = (k + u) < n ? __builtin_amdgcn_readlane(my_t, idx) : kItemNop;
+            const int t = have[u] ? __builtin_amdgcn_readlane(my_t, idx) : kItemNop;
             if (t >= 0) {                                     // (a skipped edge multiplied zeros: harmless)
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) blockmul<SI, TR>(xv[u][c], wv[u][c], acc[c]);
@@ -498,7 +518,7 @@ __device__ __forceinline__ void gather_item_group(const ItemArgs& a, int grp) {
 // One workgroup per hub row: 64 edge indices per coalesced fetch, wave w takes entries w, w + WAVES, ... of
 // the window UNR at a time (unconditional buffer loads as above); wave 0 prefetches the row's addend;
 // fixed-order LDS combine => deterministic.
-template <int SI, int NCH, int UNR, bool TR, int WAVES, int MX>
+template <int SI, int NCH, int UNR, bool TR, int WAVES, int MX, bool COMPACT = false>
 __device__ __forceinline__ void gather_hub_row(const GatherArgs& a, int v) {
     constexpr bool XB = MX == 2, WB = MX >= 1;
     constexpr int D = 100 * SI;
@@ -535,15 +555,31 @@ __device__ __forceinline__ void gather_hub_row(const GatherArgs& a, int v) {
             my_t = a.etype[base + lane] + a.shift;
             if (my_t >= a.T) my_t -= a.T;
         }
-        for (int k = wave; k < cnt; k += WAVES * UNR) {
+        // COMPACT (pruned backward): only the window's LIVE edges (source inside the row prefix) are dealt to the waves --
+        // lane l's rank among the live lanes is mbcnt(live); wave w takes ranks w, w + WAVES, ...; the lane holding a
+        // rank is found with one ballot.  Otherwise: entries w, w + WAVES, ... of the window, skipped ones included.
+        const bool lv = COMPACT && lane < cnt && my_col < a.src_limit;
+        const unsigned long long live = COMPACT ? __builtin_amdgcn_ballot_w64(lv) : 0ull;
+        const int rank = COMPACT ? (int)__builtin_amdgcn_mbcnt_hi((unsigned)(live >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)live, 0u)) : 0;
+        const int n_walk = COMPACT ? __builtin_popcountll(live) : cnt;
+        for (int k = wave; k < n_walk; k += WAVES * UNR) {
             float4 xv[UNR][NCH];
             float4 wv[UNR][NCH][WCH];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
-                const int kk = min(k + u * WAVES, 63);
+                int kk;
+                bool in_walk = (k + u * WAVES) < n_walk;
+                if constexpr (COMPACT) {
+                    const unsigned long long sel = __builtin_amdgcn_ballot_w64(lv && rank == k + u * WAVES);
+                    kk = sel ? __builtin_ctzll(sel) : 63;
+                    in_walk = sel != 0ull;
+                } else {
+                    kk = min(k + u * WAVES, 63);
+                }
                 const int src = __builtin_amdgcn_readlane(my_col, kk);      // lanes >= cnt hold INT_MAX => skipped
                 const int t = __builtin_amdgcn_readlane(my_t, kk);
-                const bool ok = (k + u * WAVES) < cnt && src < a.src_limit;
+                const bool ok = in_walk && src < a.src_limit;
                 const uint32_t xs = ok ? (uint32_t)src * XROWB : 0u;
                 const uint32_t ws = ok ? (uint32_t)t * WROWB : 0u;
 #pragma unroll
@@ -580,28 +616,28 @@ __device__ __forceinline__ void gather_hub_row(const GatherArgs& a, int v) {
     }
 }
 
-template <int SI, int NCH, int UNR, bool TR, int MX>
+template <int SI, int NCH, int UNR, bool TR, int MX, bool COMPACT = false>
 __device__ __forceinline__ void gather_items_body(const ItemArgs& a) {
     if ((int)blockIdx.x < a.g.n_heavy) {
-        gather_hub_row<SI, NCH, UNR, TR, kWaves, MX>(a.g, a.g.heavy[blockIdx.x]);
+        gather_hub_row<SI, NCH, UNR, TR, kWaves, MX, COMPACT>(a.g, a.g.heavy[blockIdx.x]);
         return;
     }
     const int nb = gridDim.x - a.g.n_heavy;
     const int vb = renet_xcd_block(blockIdx.x - a.g.n_heavy, nb);
     const int grp = vb * kWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // neighbouring rows share an XCD
-    if (grp < a.n_groups) gather_item_group<SI, NCH, UNR, TR, MX>(a, grp);
+    if (grp < a.n_groups) gather_item_group<SI, NCH, UNR, TR, MX, COMPACT>(a, grp);
 }
 
 // Four entry kernels with distinct names so that a rocprof kernel trace separates the launch classes of a
 // training step: forward over the full batch graph (layer 1), forward over the subject-row prefix (layer 2),
 // and their backward-wrt-h counterparts (transposed relation blocks).
-#define RENET_GATHER_KERNEL(NAME, TRV)                                                                  \
-    template <int SI, int NCH, int UNR, int MX = 0>                                                     \
-    __global__ __launch_bounds__(kThreads) void NAME(ItemArgs a) { gather_items_body<SI, NCH, UNR, TRV, MX>(a); }
-RENET_GATHER_KERNEL(rgcn_gather_fwd_full, false)
-RENET_GATHER_KERNEL(rgcn_gather_fwd_pruned, false)
-RENET_GATHER_KERNEL(rgcn_gather_bwdh_full, true)
-RENET_GATHER_KERNEL(rgcn_gather_bwdh_pruned, true)
+#define RENET_GATHER_KERNEL(NAME, TRV, COMPACTV)                                                                       \
+    template <int SI, int NCH, int UNR, int MX = 0>                                                                    \
+    __global__ __launch_bounds__(kThreads) void NAME(ItemArgs a) { gather_items_body<SI, NCH, UNR, TRV, MX, COMPACTV>(a); }
+RENET_GATHER_KERNEL(rgcn_gather_fwd_full, false, false)
+RENET_GATHER_KERNEL(rgcn_gather_fwd_pruned, false, false)
+RENET_GATHER_KERNEL(rgcn_gather_bwdh_full, true, false)
+RENET_GATHER_KERNEL(rgcn_gather_bwdh_pruned, true, true)       // the only class with a source limit: compacted item walk
 #undef RENET_GATHER_KERNEL
 
 template <int SI, int NCH, int UNR, int MX = 0>

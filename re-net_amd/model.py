@@ -183,13 +183,14 @@ class RENet(nn.Module):
             full = hb.B
             hb = G.shard_sequences(hb, int(shard[0]), int(shard[1]))
             share = hb.B / float(full)
-        return {'both': True, 'b': hb.B, 'share': share, 'pb': G.PackedBatch(hb)}
+        return {'both': True, 'b': hb.B, 'share': share, 'sharded': shard is not None, 'pb': G.PackedBatch(hb)}
 
     def prepare_both_from_host(self, hbatch):
         dev = self.ent_embeds.device
         prep = PreparedBatch()
         prep.subject, prep.b = None, hbatch['b']
         prep.share = hbatch.get('share', 1.0)
+        prep.sharded = bool(hbatch.get('sharded', False))
         g = G.DeviceGraph(hbatch['pb'], dev)
         g.glob = self.aggregator.glob_table.get(self.global_emb, self.h_dim, dev).mat
         prep.g, prep.perm = g, g.host.perm
@@ -242,7 +243,10 @@ class RENet(nn.Module):
         with M (or K) doubled.  Each CE is a mean over its B rows: the sum of the two is 2 x the mean over 2B."""
         g = prep.g
         self.aggregator.last_batch = g
-        x, xr = self.aggregator.encode(g, self.ent_embeds, self.rel_embeds, reverse=False, _lazy_bf16=True)
+        # a shard of a batch whose graph every rank replicates (prepare_both(shard=...)): rank-independent dropout
+        # masks at the graph-side sites, so that the N-rank step equals the 1-rank step
+        with ops.shared_graph_seeds(getattr(prep, 'sharded', False) or ops.SHARED_GRAPH_SEEDS):
+            x, xr = self.aggregator.encode(g, self.ent_embeds, self.rel_embeds, reverse=False, _lazy_bf16=True)
         s_h, s_q = ops.dual_gru(x, xr, self.encoder, self.encoder_r, prep.step_off, prep.b)
         # [1, rows, H] -> [rows, H] as a VIEW: indexing with [0] would make autograd fill and copy a zeros tensor per
         # encoder in the backward pass (select_backward)
@@ -337,7 +341,7 @@ class RENet(nn.Module):
 class PreparedBatch(object):
     """Device-resident inputs of one direction of one step (see RENet.prepare)."""
     __slots__ = ('g', 'subject', 'b', 'perm', 's_idx', 'r_idx', 'o_idx', 'plan_s', 'plan_r', 'batch_sizes',
-                 'step_off', 'r_label', 'share')
+                 'step_off', 'r_label', 'share', 'sharded')
 
 
 def _device_plan(idx, device):

@@ -53,7 +53,23 @@ def _rank():
 # batch graph, so the dropout masks of the graph-side sites (the RGCN layers' self-loop dropout) must be the same on
 # every rank for the N-rank step to equal the 1-rank step; the per-sequence sites (sequence assembly, score heads) act
 # on rows only this rank owns and keep rank-dependent seeds.  Set by the caller that shards a batch that way.
-SHARED_GRAPH_SEEDS = False
+SHARED_GRAPH_SEEDS = False       # process default; a sharded batch sets it for ITS forward pass only (shared_graph_seeds)
+_shared_tls = None
+
+
+@contextlib.contextmanager
+def shared_graph_seeds(flag):
+    """Forward pass of a batch whose GRAPH is replicated on every rank (RENet.loss_prepared_both on a batch prepared
+    with shard=(rank, world)): the graph-side dropout sites draw rank-independent seeds inside this scope.  Seeds are
+    only drawn in forward (the backward pass replays them from ctx), so a scope around the forward call suffices; the
+    flag travels with the prepared batch instead of a module global that a caller has to set per step (review r3)."""
+    global _shared_tls
+    old = _shared_tls
+    _shared_tls = bool(flag)
+    try:
+        yield
+    finally:
+        _shared_tls = old
 
 
 def next_seed(graph_site=False):
@@ -62,7 +78,8 @@ def next_seed(graph_site=False):
     correlate the ranks' dropout noise) and a per-process site counter.  graph_site: a site on the batch GRAPH --
     rank-independent when the ranks replicate one graph (SHARED_GRAPH_SEEDS)."""
     _seed_state['counter'] += 1
-    rank = 0 if (graph_site and SHARED_GRAPH_SEEDS) else _rank()
+    shared = SHARED_GRAPH_SEEDS if _shared_tls is None else _shared_tls
+    rank = 0 if (graph_site and shared) else _rank()
     x = torch.initial_seed() * 0x9E3779B1 + (rank + 1) * 0xC2B2AE3D27D4EB4F + _seed_state['counter'] * 0x85EBCA77
     return x & 0x7FFFFFFFFFFFFFFF
 
@@ -523,6 +540,8 @@ def _head_backward(dlogits, feat, feat_op, weight, t_w, t_b, bias_side=None, bou
         with bias_side():
             d_b = bias_grad()
     dfeat = K.gemm(dl_op, weight)                                    # [B, parts*D]
+    # (the weight gradient stays BEHIND dfeat on this stream: next to it on the side stream the two chip-filling GEMMs
+    # were measured 2 % slower per step than back to back, tools/sessions/r04_s11.sh)
     if t_w is not None:
         K.gemm(dl_op, f_op, ta=True, out=t_w, beta=1.0)
         d_w = None

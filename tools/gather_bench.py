@@ -82,6 +82,15 @@ def bench_graph(hb, nr, dev, d=None, legacy=True, label=''):
     def items_fwd(s):
         K.rgcn_gather_items(s['x'], g, w, 0, False, s['ad'], 0.0, 0, True, s['out'], use_norm=True)
 
+    # layer 1 as the product runs it (ops.RGCNTableLayerFn): source rows AND the self-loop addend read through the node ->
+    # entity map from two [N_ent, d] tables (cache resident) instead of [N, d] tensors
+    n_ent = int(hb.node_ent.max()) + 1
+    tab = torch.randn(n_ent, d, device=dev)
+    tab_ad = torch.randn(n_ent, d, device=dev)
+
+    def items_table_fwd(s):
+        K.rgcn_gather_items_table(tab, g, w, 0, tab_ad, 0.0, 0, True, s['out'])
+
     def items_bwd(s):       # in place: addend == out, as in ops.RGCNLayerFn.backward
         K.rgcn_gather_items(s['x'], g, w, nr, True, s['out'], 0.0, 0, False, s['out'], use_norm=False)
 
@@ -102,7 +111,8 @@ def bench_graph(hb, nr, dev, d=None, legacy=True, label=''):
 
     full_b = K.gather_bytes(hb.E, n, d, w.numel(), True)
     full_strict = K.gather_bytes(hb.E, n, d, w.numel(), False)
-    cases = [('items_fwd_full', items_fwd, full_b, full_strict), ('items_bwdh_full', items_bwd, full_b, full_strict)]
+    cases = [('items_fwd_full', items_fwd, full_b, full_strict), ('items_bwdh_full', items_bwd, full_b, full_strict),
+             ('items_table_fwd', items_table_fwd, full_b, full_strict)]
     if nA < n:
         e_out = hb.E_out
         cases += [('items_fwd_pruned', items_fwd_pruned, K.gather_bytes(e_out, nA, d, w.numel(), True),
