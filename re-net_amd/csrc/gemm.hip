@@ -449,12 +449,11 @@ __global__ __launch_bounds__(THREADS, WPE) void gemm_f32_kernel(GemmArgs g) {
     const int kt_total = (g.K + KT - 1) / KT;
     const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
 
-    // Known loss (profiles/r04_f32_gemm_probes.md): the co-resident workgroups of a CU start together, share the matrix
-    // pipe evenly, therefore finish, store and are replaced together -- prologue + epilogue of a round of tiles never
-    // overlap anybody's k-loop (2048 x 23033 x 600: 510 us with an empty loop body around the MFMAs against 414 us of
-    // sustained matrix-pipe time).  A static s_setprio by hardware wave slot does not break the symmetry (measured: no
-    // change -- the other wave's MFMAs slip in whenever the favoured one issues an LDS / memory instruction); the fix
-    // is a persistent tile loop with a second accumulator set (epilogue of tile i under the k-loop of tile i+1).
+    // Known loss (profiles/r04_f32_gemm_probes.md): ~17 us per round of 512 tiles on the short-K shapes that is neither
+    // k-loop nor tile quantisation (2048 x 23033 x 600: 510 us with an empty loop body around the MFMAs against 414 us
+    // of sustained matrix-pipe time).  Tried and measured without gain: a static s_setprio by hardware wave slot, and a
+    // one-time start stagger of half a tile for the slot-1 workgroup of every CU (a workgroup alone on its CU does not
+    // run at twice the paired rate, so the waiting time is not given back).
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
