@@ -16,6 +16,8 @@ over ALL sequences of the batch, of {subject} U {objects in the history step at 
 1/in-degree of that induced subgraph.  Node order inside a member graph is by entity id (the
 reference's is set-iteration order; results do not depend on it).
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -832,14 +834,30 @@ class _HostView(object):
         self.__dict__.update(pb.host_small)
 
 
+_async_h2d = [False]
+
+
+@contextlib.contextmanager
+def async_uploads(on=True):
+    """Scope in which h2d() stages small arrays through pinned buffers and copies asynchronously (the inference advance:
+    RENet._joint_topk_many).  Off by default: pinned staging buffers come from torch's caching host allocator, and a
+    loop that uploads hundreds of batches without ever synchronising (bench.py preparing its steps, the prefetch
+    pipeline) finds no free cached block and pays a hipHostMalloc per upload (measured: host_build_ms 13 -> 43)."""
+    old = _async_h2d[0]
+    _async_h2d[0] = bool(on) and _os.environ.get('RENET_ASYNC_H2D', '1') != '0'
+    try:
+        yield
+    finally:
+        _async_h2d[0] = old
+
+
 def h2d(a, device):
-    """numpy array -> device tensor without blocking the host on the stream: staged through a pinned buffer of torch's
-    caching host allocator and copied asynchronously (a copy from pageable memory waits for everything queued on the
-    stream -- in the inference advance that serialised host batch building and device work chunk by chunk).  Arrays
-    above 1 MiB keep the blocking copy: their transfer time dominates, and first-touch pinning of large size classes costs
-    milliseconds (measured: it tripled the 3-timestamp stream evaluation).  RENET_ASYNC_H2D=0: always blocking."""
+    """numpy array -> device tensor.  Inside an async_uploads() scope arrays up to 1 MiB go through a pinned staging
+    buffer and are copied asynchronously, so that the host is not blocked on the stream (a copy from pageable memory
+    waits for everything queued on the stream -- in the inference advance that serialised host batch building and
+    device work chunk by chunk); larger arrays, and everything outside such a scope, use the plain blocking copy."""
     t = torch.from_numpy(np.ascontiguousarray(a))
-    if torch.device(device).type != 'cuda' or _os.environ.get('RENET_ASYNC_H2D', '1') == '0' or t.numel() == 0 or \
+    if not _async_h2d[0] or torch.device(device).type != 'cuda' or t.numel() == 0 or \
             t.numel() * t.element_size() > (1 << 20):
         return t.to(device)
     pinned = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)

@@ -457,6 +457,11 @@ def _sample(self, prob):
 
 
 def _joint_topk_many(self, ents, prob, subject=True):
+    with G.async_uploads():
+        return _joint_topk_many_body(self, ents, prob, subject)
+
+
+def _joint_topk_many_body(self, ents, prob, subject=True):
     """pred_r_rank2 + the per-entity top-k of model.py:229-258 for SEVERAL entities in one batch:
     one batch graph with separate member graphs per entity (build_batch group=entity: identical to one call per
     entity), one GRU launch, one [n*R, 3h] x [3h, N_ent] GEMM.  Returns {entity: (values[num_k], flat indices
