@@ -44,6 +44,26 @@ class _Side(object):
             self.main.wait_stream(self.side)
 
 
+# Deferred joins (round 4).  Some side-stream work has no consumer inside the backward pass at all -- the weight / bias
+# gradients of the GRU input projections and recurrences feed nothing but the optimizer -- so its join can wait until
+# the optimizer step instead of the end of the Function: the main stream goes on into sequence-assembly and RGCN
+# backward (~0.5 ms of small, latency-bound kernels) while the side stream runs the dW GEMMs.  Only a caller that
+# PROMISES the final join may turn this on: parallel.HipAdam's step_scope sets `DEFER_WEIGHT_GRADS` for the step and
+# HipAdam.step() calls join_deferred() before it reads a gradient.  Outside such a scope (train.py's own loop with
+# clip_grad_norm_ + torch Adam) every Function joins before it returns, as before.  Tensors the deferred kernels read
+# are handed to the allocator with record_stream, so that freeing them on the main stream cannot recycle their memory
+# under the side stream.
+DEFER_WEIGHT_GRADS = False
+_deferred = []             # (main stream, side stream) pairs with un-joined side work
+
+
+def join_deferred():
+    """Make every stream that forked deferred work wait for it (no-op if nothing is pending)."""
+    while _deferred:
+        main, side = _deferred.pop()
+        main.wait_stream(side)
+
+
 def _rank():
     import torch.distributed as dist
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
@@ -426,12 +446,12 @@ class MultiGRUFn(Function):
         xs, w_ihs, w_hhs, svs = sv_[:n], sv_[n:2 * n], sv_[2 * n:3 * n], sv_[3 * n:4 * n]
         d_gis, d_ghs = K.gru_bwd_layouts([_c(dh[0, :nz]) for dh, nz in zip(dhs, ctx.nnz)], ctx.step_offs, hdim,
                                          list(w_hhs), list(svs), out_bf16=(K.GEMM_MODE == 'bf16s'))
-        def problem(k):
+        def param_grads(k, dgi_op):
+            """dW_ih, dW_hh, db_ih, db_hh of problem k: consumed by the optimizer only."""
             t_ih, t_hh = (grad_target(t) for t in ctx.src_w[k])
             t_bi, t_bh = (grad_target(t) for t in ctx.src_b[k])
             dgi, dgh, xx, s_ = d_gis[k], d_ghs[k], xs[k], svs[k]
             x_op = ctx.x_ops[k] if ctx.x_ops is not None else xx
-            dgi_op = K.operand(dgi)                                    # consumed by dW_ih and dX
             dwi = dwh = dbi = dbh = None
             if t_ih is not None:
                 K.gemm(dgi_op, x_op, ta=True, out=t_ih, beta=1.0)
@@ -453,6 +473,10 @@ class MultiGRUFn(Function):
                 K.colsum(dgh, out=t_bh, beta=1.0)
             else:
                 dbh = K.colsum(dgh)
+            return [dwi, dwh, dbi, dbh]
+
+        def input_grad(k, dgi_op):
+            xx = xs[k]
             live = ctx.live_cols[k] if ctx.live_cols is not None else None
             if live is not None and live < xx.shape[1]:
                 # the caller never reads dX beyond column `live` (RE-Net: the last D input columns are the global
@@ -461,9 +485,40 @@ class MultiGRUFn(Function):
                 dxx = torch.empty_like(xx)
                 K.gemm(dgi_op, w_ihs[k][:, :live], out=dxx[:, :live])
                 dxx[:, live:].zero_()         # defined values for any other consumer (hooks, detect_anomaly): 6 MB
-            else:
-                dxx = K.gemm(dgi_op, w_ihs[k])
-            return [dxx, dwi, dwh, dbi, dbh]
+                return dxx
+            return K.gemm(dgi_op, w_ihs[k])
+
+        def problem(k):
+            dgi_op = K.operand(d_gis[k])                               # consumed by dW_ih and dX
+            return [input_grad(k, dgi_op)] + param_grads(k, dgi_op)
+
+        all_in_place = all(grad_target(t) is not None for k in range(n) for t in ctx.src_w[k] + ctx.src_b[k])
+        sd0 = _Side(d_gis[0].device if not isinstance(d_gis[0], K.BF16Mat) else d_gis[0].p.device)
+        if DEFER_WEIGHT_GRADS and sd0.on and all_in_place and K.GEMM_MODE != 'bf16s':
+            # every parameter gradient accumulates in place and somebody joins before the optimizer reads it: dX of all
+            # problems on this stream (what the rest of the backward pass waits for), all parameter gradients on the side
+            # stream, NOT joined here
+            ops_ = [K.operand(d_gis[k]) for k in range(n)]
+            if K.GEMM_MODE == 'f16x3':
+                for o in ops_:
+                    o.bound()                                          # measured on THIS stream, before the fork
+            sd = _Side(sd0.main.device)                                # (fork: the side stream sees d_gis / bounds)
+            res = [None] * n
+            with sd():
+                for k in range(n):
+                    param_grads(k, ops_[k])
+            live_ops = ops_ + (list(ctx.x_ops) if ctx.x_ops is not None else [])
+            for t in list(d_gis) + list(d_ghs) + list(xs) + list(svs) + \
+                    [getattr(o, 'part', None) for o in live_ops] + [getattr(o, 't', None) for o in live_ops]:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(sd.side)
+            for k in range(n):
+                res[k] = [input_grad(k, ops_[k]), None, None, None, None]
+            _deferred.append((sd.main, sd.side))
+            out = [None, None, None]
+            for k in range(n):
+                out += res[k]
+            return tuple(out)
 
         # problems with DIFFERENT parameters are independent of each other (encoder / encoder_r; two problems of the
         # same encoder accumulate into the same gradient buffers and stay on one stream): the second parameter set's
@@ -472,7 +527,7 @@ class MultiGRUFn(Function):
         uniq = list(dict.fromkeys(keys))
         on_side = [len(uniq) > 1 and keys[k] == uniq[1] for k in range(n)]
         res = [None] * n
-        sd = _Side(d_gis[0].device if not isinstance(d_gis[0], K.BF16Mat) else d_gis[0].p.device)
+        sd = sd0
         with sd():
             for k in range(n):
                 if on_side[k]:
@@ -678,6 +733,9 @@ class DualHeadCEFn(Function):
         dl2 = b2_ if b2_ is not None else dl2
         bound1 = _scale_ce_gradient(dl1, g, ctx.grad_scales[0])      # upstream scalar (1 in RE-Net's training step)
         sd = _Side(feat1.device)
+        # (deferring the entity head's dW / db to the side stream until opt.step(), like the GRU parameter gradients, was
+        # measured: no gain -- 2.975 vs 2.987 ms per step, tools/sessions/r04_s18.sh: a chip-filling GEMM only competes
+        # with the GRU / RGCN backward kernels it would run beside)
         with sd():
             bound2 = _scale_ce_gradient(dl2, g, ctx.grad_scales[1])
             dfeat2, d_w2, d_b2 = _head_backward(dl2, feat2, fop2, w2, t_w2, t_b2, bound=bound2)

@@ -269,6 +269,8 @@ class HipAdam(object):
         """all-reduce (if distributed; the score head's bucket was started during backward) -> clip -> Adam ->
         zero_grad.  The 1/world of the gradient average is folded into the optimizer kernel (no pass over 81 MB)."""
         scale = 1.0
+        import ops
+        ops.join_deferred()                  # deferred side-stream gradient work (ops.DEFER_WEIGHT_GRADS) ends here
         if self.reducer is not None:
             self.reducer.finish(fold_scale=True)
             scale = self.reducer.pending_scale
@@ -291,9 +293,17 @@ class _StepScope(object):
     def __enter__(self):
         if self.opt.reducer is not None:
             self.opt.reducer.begin_step(self.head_passes, self.average)
+        # inside a declared step the optimizer's step() is the one consumer of the parameter gradients: side-stream
+        # work that only feeds them may stay un-joined until then (ops.DEFER_WEIGHT_GRADS; RENET_DEFER_GRADS=0 turns it off)
+        import ops
+        self._defer_old = ops.DEFER_WEIGHT_GRADS
+        ops.DEFER_WEIGHT_GRADS = os.environ.get('RENET_DEFER_GRADS', '1') != '0'
         return self.opt
 
     def __exit__(self, exc_type, exc, tb):
+        import ops
+        ops.DEFER_WEIGHT_GRADS = self._defer_old
+        ops.join_deferred()                  # (a step abandoned before step(): nothing stays pending)
         r = self.opt.reducer
         if r is not None and r.armed:
             # the step was abandoned before step() (exception, early exit): complete a launched collective so that

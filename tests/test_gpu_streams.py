@@ -124,6 +124,59 @@ def test_side_stream_changes_no_value(dev, monkeypatch):
     assert torch.equal(pa, pb)
 
 
+def test_deferred_weight_gradients_change_no_value(dev, monkeypatch):
+    """Inside `with opt.step_scope(...)` the GRU parameter-gradient GEMMs run on the side stream and are joined only in
+    opt.step() (ops.DEFER_WEIGHT_GRADS, round 4): three declared steps -- merged pass and the pair of passes -- against
+    the same steps with RENET_DEFER_GRADS=0: bit-identical losses and parameters (same kernels, same order per gradient
+    buffer; only the interleaving with the rest of the backward pass differs).  The intermediate tensors of the backward
+    pass are freed while the side stream may still read them: record_stream must keep the allocator from recycling
+    them early -- a wrong value here would show up as a mismatch."""
+    import model as M
+    import ops
+    import parallel
+    import preprocess as P
+    import synth
+    quads, num_ent, num_rels, _ = synth.make_stream('ICEWS18', seed=5, num_t=40)
+    gd = P.build_graph_dict(quads, num_rels)
+    hs, ho = P.HistoryIndex(quads, 's', 10), P.HistoryIndex(quads, 'o', 10)
+    perm = np.random.RandomState(1).permutation(len(quads))
+    for passes in ('merged', 'pair'):
+        results = []
+        for defer in ('1', '0'):
+            monkeypatch.setenv('RENET_DEFER_GRADS', defer)
+            torch.manual_seed(7)
+            ops.reset_seed_counter()
+            net = M.RENet(num_ent, 200, num_rels, dropout=0.5, seq_len=10, num_k=10)
+            gen = torch.Generator().manual_seed(3)
+            net.global_emb = {int(t): torch.randn(1, 1, 200, generator=gen) * 0.1 for t in gd}
+            net.to(dev).train()
+            opt = parallel.HipAdam(net, lr=1e-3, weight_decay=1e-5, max_norm=1.0)
+            losses = []
+            for k in range(3):
+                idx = perm[k * 512:(k + 1) * 512]
+                fs, fo = hs.take(idx), ho.take(idx)
+                with opt.step_scope(head_passes=1 if passes == 'merged' else 2):
+                    if passes == 'merged':
+                        loss = net.loss_prepared_both(net.prepare_both(quads[idx], fs, fo, gd))
+                    else:
+                        loss = net.loss_prepared_pair(net.prepare(quads[idx], fs, gd, subject=True),
+                                                      net.prepare(quads[idx], fo, gd, subject=False))
+                    loss.backward()
+                    # churn the allocator while the deferred kernels may still be running
+                    junk = [torch.full((n_, 600), float('nan'), device=dev) for n_ in (4000, 9000, 16000)]
+                    del junk
+                    opt.step()
+                losses.append(loss.item())
+            torch.cuda.synchronize()
+            assert not ops._deferred
+            results.append((losses, torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()))
+            opt.close()
+        (la, pa), (lb, pb) = results
+        assert la == lb, (passes, la, lb)
+        assert torch.isfinite(pa).all()
+        assert torch.equal(pa, pb), passes
+
+
 @pytest.mark.parametrize('d', [100, 200, 400])
 @pytest.mark.parametrize('n_rows,n_tgt,zipf', [(5000, 900, 1.2), (40, 4000, 0.0), (3000, 3, 0.0), (1, 1, 0.0),
                                                (70000, 23033, 1.1)])

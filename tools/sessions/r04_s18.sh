@@ -1,0 +1,22 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r4s18
+mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_streams.py -m gpu -x -q > $O/t.log 2>&1; tail -5 $O/t.log
+B="--steps 100 --cpu-steps 0 --e2e-steps 0 --f32-steps 0 --enc-steps 0 --other-steps 0"
+for v in 1 0 1 0; do
+RENET_DEFER_HEAD=$v timeout 600 python bench.py $B > $O/bench_h$v.json 2> $O/bench_h$v.err
+python - <<PY
+import json
+j=json.loads(open('gpurun_out/r4s18/bench_h$v.json').read().strip().splitlines()[-1])
+print('defer_head=$v', round(j['value']), round(j['ms_per_step'],4), j.get('last_loss'))
+PY
+done
+RENET_GEMM=f16x3 timeout 600 python bench.py $B > $O/bench_f16.json 2> $O/bench_f16.err
+RENET_GEMM=f16x3 RENET_DEFER_GRADS=0 timeout 600 python bench.py $B > $O/bench_f16_nodefer.json 2> $O/bench_f16_nodefer.err
+python - <<PY
+import json
+for f in ('bench_f16','bench_f16_nodefer'):
+    j=json.loads(open('gpurun_out/r4s18/%s.json' % f).read().strip().splitlines()[-1])
+    print(f, round(j['value']), round(j['ms_per_step'],4), j.get('last_loss'))
+PY
