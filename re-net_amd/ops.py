@@ -57,6 +57,21 @@ DEFER_WEIGHT_GRADS = False
 _deferred = []             # (main stream, side stream) pairs with un-joined side work
 
 
+def _deferred_scope(device, tensors):
+    """-> a _Side whose stream takes gradient-only work that stays UN-JOINED until join_deferred() (None when deferral
+    is off or no side stream exists).  `tensors`: what that work reads and the caller frees afterwards."""
+    if not DEFER_WEIGHT_GRADS:
+        return None
+    sd = _Side(device)
+    if not sd.on:
+        return None
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            t.record_stream(sd.side)
+    _deferred.append((sd.main, sd.side))
+    return sd
+
+
 def join_deferred():
     """Make every stream that forked deferred work wait for it (no-op if nothing is pending)."""
     while _deferred:
@@ -244,17 +259,34 @@ class RGCNLayerFn(Function):
         K.gemm(gl_op, loop_weight, tb=True, out=dh[:n_out], beta=1.0)      # += g_loop @ W_loop^T (rows < n_out)
         acc = tgt_w is not None                                        # straight into weight.grad (beta = 1)
         d_w = tgt_w if acc else torch.empty_like(weight)
-        if pruned:
-            K.rgcn_bwd_w(h, gn, g.e_src2, g.e_dst2, g.chunk_ptr2, g.chunk_type2, g.n_chunks2, g.type_chunk_ptr2,
-                         g.num_types, ctx.shift, d_w, beta=1.0 if acc else 0.0)
-        else:
-            K.rgcn_bwd_w(h, gn, g.e_src, g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr,
-                         g.num_types, ctx.shift, d_w, beta=1.0 if acc else 0.0)
-        if tgt_loop is not None:                                       # h^T @ g_loop (auto split-K), accumulated
-            K.gemm(h_op, gl_op, ta=True, out=tgt_loop, beta=1.0)
+
+        def weight_grads():
+            if pruned:
+                K.rgcn_bwd_w(h, gn, g.e_src2, g.e_dst2, g.chunk_ptr2, g.chunk_type2, g.n_chunks2, g.type_chunk_ptr2,
+                             g.num_types, ctx.shift, d_w, beta=1.0 if acc else 0.0)
+            else:
+                K.rgcn_bwd_w(h, gn, g.e_src, g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr,
+                             g.num_types, ctx.shift, d_w, beta=1.0 if acc else 0.0)
+            if tgt_loop is not None:                                   # h^T @ g_loop (auto split-K), accumulated
+                K.gemm(h_op, gl_op, ta=True, out=tgt_loop, beta=1.0)
+                return None
+            return K.gemm(h_op, gl_op, ta=True)
+        # the relation-block and self-loop weight gradients feed only the optimizer, and nothing else writes their
+        # buffers: inside a declared step they run on the side stream, un-joined, under the rest of the backward pass
+        sd = _deferred_scope(h.device, (h, gn, g_loop, getattr(gl_op, 'p', None), getattr(gl_op, 'part', None),
+                                        getattr(h_op, 'p', None))) \
+            if (acc and tgt_loop is not None and K.GEMM_MODE != 'bf16s') else None
+        if sd is not None:
+            if isinstance(gl_op, K.F32Op):
+                gl_op.bound()                                          # (measured on this stream: before the fork below)
+            if isinstance(h_op, K.F32Op):
+                h_op.bound()
+            sd.side.wait_stream(sd.main)
+            with sd():
+                weight_grads()
             d_loop = None
         else:
-            d_loop = K.gemm(h_op, gl_op, ta=True)
+            d_loop = weight_grads()
         return dh, None if acc else d_w, d_loop, None, None, None, None, None, None
 
 
@@ -309,8 +341,11 @@ class RGCNTableLayerFn(Function):
                             w16=K.gather_weight_bf16(weight))
         acc = tgt_w is not None
         d_w = tgt_w if acc else torch.empty_like(weight)
-        K.rgcn_bwd_w(table, gn, g.table_items()[3], g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr,
-                     g.num_types, ctx.shift, d_w, beta=1.0 if acc else 0.0)
+        e_src_t = g.table_items()[3]
+        sd = _deferred_scope(dev, (gn,)) if acc else None               # (see RGCNLayerFn.backward)
+        with (sd() if sd is not None else contextlib.nullcontext()):
+            K.rgcn_bwd_w(table, gn, e_src_t, g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr,
+                         g.num_types, ctx.shift, d_w, beta=1.0 if acc else 0.0)
         # per-entity sums of the self-loop gradient, then the two self-loop GEMMs on N_ent rows
         gs = torch.zeros(table.shape, device=dev, dtype=torch.float32)
         d_tab = tgt_tab if tgt_tab is not None else torch.zeros(table.shape, device=dev, dtype=torch.float32)
