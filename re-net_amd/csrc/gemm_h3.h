@@ -187,7 +187,7 @@ __global__ __launch_bounds__(TALL ? 512 : 256) __attribute__((amdgpu_waves_per_e
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by);
     const int m0 = by * TBM, n0 = bx * BN;
     const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;

@@ -46,7 +46,7 @@ struct SplitArgs {
     int k_tiles_per_split;
     int split_k;
     float* partial;
-    int xcd_order;          // 1: XCD-aware virtual tile order (tile_of_block)
+    int xcd_order;          // 0: plain order; w >= 1: XCD-aware virtual tile order with panels of <= w tiles (tile_of_block)
 };
 
 
@@ -75,7 +75,7 @@ __device__ __forceinline__ void trace_put(int wave8, int step, int slot, unsigne
 // 1/8 of the tile sequence, and in that sequence the SHORT grid dimension runs fastest, so the tiles that share
 // a slab of the long operand are consecutive on one XCD and the slab is fetched once.  RENET_GEMM_TILE_ORDER=0
 // in the environment restores the plain order (tools/gemm_bench.py).
-__device__ __forceinline__ void tile_of_block(int nbx, int nby, bool xcd_order, int& bx, int& by) {
+__device__ __forceinline__ void tile_of_block(int nbx, int nby, int xcd_order, int& bx, int& by) {
     if (!xcd_order) { bx = blockIdx.x; by = blockIdx.y; return; }
     const int nb = nbx * nby, per = nb >> 3;
     const int L = blockIdx.x + nbx * blockIdx.y;
@@ -83,7 +83,7 @@ __device__ __forceinline__ void tile_of_block(int nbx, int nby, bool xcd_order, 
     // sequence: panels of <= 8 tiles across the SHORT dimension, the long dimension sweeping each panel
     // (a square problem becomes 8 x 8 blocks of concurrently resident tiles per XCD instead of 2 x 32)
     const int ns = min(nbx, nby), nl = max(nbx, nby);
-    const int w = min(ns, 8);
+    const int w = min(ns, xcd_order);
     const int p = t / (w * nl), r = t - p * (w * nl);
     const int wp = min(w, ns - p * w);                       // width of this (possibly last, narrower) panel
     const int l = r / wp, sh = p * w + (r - l * wp);
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(THREADS) void gemm_split_kernel(SplitArgs g) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by);
     const int m0 = by * BM, n0 = bx * BN;
     const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(THREADS_T) void gemm_split_tall_kernel(SplitArgs g)
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by);
     const int m0 = by * BMT, n0 = bx * BN;
     const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(THREADS) void gemm_split_fused_kernel(SplitArgs g) 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by);
     const int m0 = by * BM, n0 = bx * BN;
     const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(SplitArgs g) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by);
     const int m0 = by * BM, n0 = bx * BN;
     const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(P3_THREADS) void gemm_planes_kernel(PlanesArgs pa) 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by);
     const int m0 = by * BM, n0 = bx * BN;
     const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(TALL ? 768 : P3_THREADS) void gemm_bf16s_kernel(Bf1
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by);
     const int m0 = by * TBM, n0 = bx * BN;
     const int z = blockIdx.z;
     const int st_total = (g.K + B1_BK - 1) / B1_BK;
@@ -1365,11 +1365,13 @@ __global__ __launch_bounds__(256) void split_reduce4_kernel(const float* __restr
     }
 }
 
+// RENET_GEMM_TILE_ORDER=0: plain order; =w: panel width of the XCD-aware order (default 8)
 int tile_order() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("RENET_GEMM_TILE_ORDER");
-        v = (e && e[0] == '0') ? 0 : 1;
+        v = e ? atoi(e) : 8;
+        if (v < 0) v = 0;
     }
     return v;
 }
