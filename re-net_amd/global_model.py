@@ -8,7 +8,7 @@ import torch.nn as nn
 
 import ops
 from Aggregator import RGCNAggregator_global
-from model import GRU
+from model import GRU, _moded
 from utils import soft_cross_entropy
 
 
@@ -29,10 +29,12 @@ class RENet_global(nn.Module):
         self.linear_s = nn.Linear(h_dim, in_dim)
         self.linear_o = nn.Linear(h_dim, in_dim)
         self.global_emb = None
+        self.gemm_mode = None           # see model.RENet.gemm_mode
 
     def _head(self, subject):
         return (self.linear_s, False) if subject else (self.linear_o, True)
 
+    @_moded
     def forward(self, t_list, true_prob_s, true_prob_o, graph_dict, subject=True):
         """global_model.py:35-55: soft cross-entropy between the predicted entity distribution at each
         timestamp and the empirical one (subject=True scores against true_prob_o, as the reference)."""
@@ -45,6 +47,7 @@ class RENet_global(nn.Module):
         pred = ops.LinearFn.apply(s_q[0], linear.weight, linear.bias)
         return soft_cross_entropy(pred, torch.as_tensor(true_prob)[torch.from_numpy(idx)])
 
+    @_moded
     def predict(self, t, graph_dict, subject=True):
         """global_model.py:79-92: (s_q[1,1,h], logits[1,1,N_ent], prob[N_ent]) for predicting at time t
         from the <= seq_len graphs strictly before t."""
@@ -55,6 +58,7 @@ class RENet_global(nn.Module):
         sub = ops.LinearFn.apply(s_q[0], linear.weight, linear.bias).view(1, 1, -1)
         return s_q, sub, torch.softmax(sub.view(-1), dim=0)
 
+    @_moded
     def get_global_emb(self, t_list, graph_dict):
         """global_model.py:57-73: {t: embedding used when predicting the step after t}."""
         out = dict()

@@ -27,6 +27,18 @@ from utils import *        # noqa: F401,F403  (the reference's model.py re-expor
 DUAL_HEAD = os.environ.get('RENET_DUAL_HEAD', '1') != '0'
 
 
+def _moded(fn):
+    """Runs a model method inside the model's own GEMM-mode scope (`self.gemm_mode`: None = the process default,
+    'bf16x6' / 'f16x3' = this model's choice; renet_hip.gemm_mode).  Nested calls re-enter the same scope."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with K.gemm_mode(getattr(self, 'gemm_mode', None)):
+            return fn(self, *a, **k)
+    return wrapped
+
+
 class GRU(nn.Module):
     """Drop-in for nn.GRU(input_size, hidden_size, batch_first=True), one layer, h0 = 0, on the HIP
     recurrence.  Same parameter names/shapes/init as torch (weight_ih_l0 [3H,I], weight_hh_l0 [3H,H],
@@ -101,6 +113,8 @@ class RENet(nn.Module):
         # False (default): score the quadruple's own entities.  True: reproduce the reference bit for bit in
         # behaviour (which entity shadows depends on the device's unsorted top-k order; `shadow_pick(side, cands)`
         # may override the choice -- the golden test drives it with the entities the reference run recorded).
+        # fp32-class GEMM mode of THIS model: None = the process default (RENET_GEMM), or 'bf16x6' / 'f16x3'
+        self.gemm_mode = None
         self.reference_shadowing = False
         # inference advance: one history per sampled entity, relation segment of the GRU input broadcast (see
         # _joint_topk_many); False builds the R-fold batches of rounds 1-3 (A/B runs, tests)
@@ -234,6 +248,7 @@ class RENet(nn.Module):
         hbatch = self.host_batch_both(triplets, s_hist, o_hist, graph_dict, shard=shard)
         return None if hbatch is None else self.prepare_both_from_host(hbatch)
 
+    @_moded
     def loss_prepared_both(self, prep):
         """loss_prepared(prep_s) + loss_prepared(prep_o) evaluated as ONE pass over the 2B sequences of the merged
         batch (extension of the reference API; train.py:136-138 adds the two losses of the same quadruples).  The
@@ -298,6 +313,7 @@ class RENet(nn.Module):
         self.aggregator.last_batch = prep.g
         return self.aggregator.encode(prep.g, self.ent_embeds, rel_embeds, reverse=not prep.subject, _lazy_bf16=True)
 
+    @_moded
     def loss_prepared(self, prep):
         """Device half (model.py:82-103): RGCN x2 -> sequence assembly -> GRU x2 -> heads -> loss."""
         dev = self.ent_embeds.device
@@ -312,6 +328,7 @@ class RENet(nn.Module):
             s_h, s_q = s_h.view(s_h.shape[1:]), s_q.view(s_q.shape[1:])
         return self._heads(prep, s_h, s_q)
 
+    @_moded
     def loss_prepared_pair(self, prep_s, prep_o):
         """loss_prepared(prep_s) + loss_prepared(prep_o) -- the subject and the object pass of one training step
         (train.py:136-138) -- with the four GRU recurrences of the two passes in ONE launch per direction of time
@@ -331,6 +348,7 @@ class RENet(nn.Module):
                                               xs, *w, xrs, *wr, xo, *w, xro, *wr)
         return self._heads(prep_s, hs[0], qs[0]) + self._heads(prep_o, ho[0], qo[0])
 
+    @_moded
     def forward(self, triplets, s_hist, o_hist, graph_dict, subject=True):
         """Training loss of one direction (model.py:64-104): CE over objects + 0.1 * CE over relations.
         triplets: int tensor [B, >=3]; s_hist / o_hist: (histories, timestamps) in the reference's nested
@@ -854,17 +872,17 @@ def _evaluate_filter_stream(self, total_data, s_history, o_history, global_model
 
 RENet.init_history = _init_history
 RENet.update_cache = _update_cache
-RENet.pred_r_rank2 = _pred_r_rank2
+RENet.pred_r_rank2 = _moded(_pred_r_rank2)
 RENet.sample_entities = _sample
-RENet._joint_topk_many = _joint_topk_many
+RENet._joint_topk_many = _moded(_joint_topk_many)
 RENet._advance_side = _advance_side
 RENet._roll_histories = _roll_histories
 RENet._touched_sets = _touched_sets
 RENet._cached_facts = _cached_facts
-RENet._advance_time = _advance_time
-RENet.predict = _predict
-RENet.evaluate = _evaluate
-RENet.evaluate_filter = _evaluate_filter
-RENet.predict_batch = _predict_batch
-RENet.evaluate_filter_batch = _evaluate_filter_batch
-RENet.evaluate_filter_stream = _evaluate_filter_stream
+RENet._advance_time = _moded(_advance_time)
+RENet.predict = _moded(_predict)
+RENet.evaluate = _moded(_evaluate)
+RENet.evaluate_filter = _moded(_evaluate_filter)
+RENet.predict_batch = _moded(_predict_batch)
+RENet.evaluate_filter_batch = _moded(_evaluate_filter_batch)
+RENet.evaluate_filter_stream = _moded(_evaluate_filter_stream)

@@ -2,6 +2,7 @@
 run hand-written HIP kernels; torch only owns the tensors and wires the graph.  No CPU / eager
 fallback exists: on a non-HIP tensor these raise."""
 import contextlib
+import functools
 import ctypes
 import os
 
@@ -169,6 +170,25 @@ def grad_done(param):
 debug_tap = None
 
 
+def _fwd_mode(fwd):
+    """Function.forward wrapper: remembers the GEMM mode the forward pass ran in (renet_hip.gemm_mode scopes are entered
+    by the MODEL around its forward code; autograd runs backward later, on its own thread, outside any such scope)."""
+    @functools.wraps(fwd)
+    def forward(ctx, *a, **k):
+        ctx.gemm_mode = K.current_mode()
+        return fwd(ctx, *a, **k)
+    return forward
+
+
+def _bwd_mode(bwd):
+    """Function.backward wrapper: runs the backward pass in the mode its forward pass ran in."""
+    @functools.wraps(bwd)
+    def backward(ctx, *g):
+        with K.gemm_mode(getattr(ctx, 'gemm_mode', None)):
+            return bwd(ctx, *g)
+    return backward
+
+
 def grad_target(t):
     """The slice of a leaf parameter's existing .grad that corresponds to tensor `t` (the parameter itself or
     a contiguous row-slice view of it), or None if there is nothing to accumulate into.
@@ -197,11 +217,13 @@ class GatherRowsFn(Function):
     """out = table[idx]  (utils.py:239 h0 = ent_embeds[id]); backward = deterministic segmented add."""
 
     @staticmethod
+    @_fwd_mode
     def forward(ctx, table, idx, plan):
         ctx.plan, ctx.shape, ctx.src = plan, table.shape, table
         return K.gather_rows(_c(table), idx)
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, g):
         tgt = grad_target(ctx.src)
         if tgt is not None:
@@ -218,6 +240,7 @@ class RGCNLayerFn(Function):
     are read afterwards -- the subject rows, Aggregator.py:139-140 -- first); exact for those rows."""
 
     @staticmethod
+    @_fwd_mode
     def forward(ctx, h, weight, loop_weight, g, reverse, relu, drop_p, seed, n_out):
         ctx.src_w, ctx.src_loop = weight, loop_weight
         h, weight, loop_weight = _c(h), _c(weight), _c(loop_weight)
@@ -235,6 +258,7 @@ class RGCNLayerFn(Function):
         return out
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, g_out):
         h, weight, loop_weight, out = ctx.saved_tensors
         g, n_out = ctx.g, ctx.n_out
@@ -275,7 +299,7 @@ class RGCNLayerFn(Function):
         # buffers: inside a declared step they run on the side stream, un-joined, under the rest of the backward pass
         sd = _deferred_scope(h.device, (h, gn, g_loop, getattr(gl_op, 'p', None), getattr(gl_op, 'part', None),
                                         getattr(h_op, 'p', None))) \
-            if (acc and tgt_loop is not None and K.GEMM_MODE != 'bf16s') else None
+            if (acc and tgt_loop is not None and K.current_mode() != 'bf16s') else None
         if sd is not None:
             if isinstance(gl_op, K.F32Op):
                 gl_op.bound()                                          # (measured on this stream: before the fork below)
@@ -312,6 +336,7 @@ class RGCNTableLayerFn(Function):
     dW_loop = ent^T @ segsum(g_loop) -- again GEMMs over N_ent rows."""
 
     @staticmethod
+    @_fwd_mode
     def forward(ctx, table, weight, loop_weight, g, reverse, relu, drop_p, seed):
         ctx.src_tab, ctx.src_w, ctx.src_loop = table, weight, loop_weight
         table, weight, loop_weight = _c(table), _c(weight), _c(loop_weight)
@@ -325,6 +350,7 @@ class RGCNTableLayerFn(Function):
         return out
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, g_out):
         table, weight, loop_weight, out = ctx.saved_tensors
         g = ctx.g
@@ -364,10 +390,11 @@ class SeqAssembleFn(Function):
     """Aggregator.py:139-165: packed GRU inputs X [S,4D], Xr [S,3D] with fused dropout."""
 
     @staticmethod
+    @_fwd_mode
     def forward(ctx, h2, ent, rel, glob, g, drop_p, seed_x, seed_xr, _lazy_bf16=False):
         ctx.src_ent, ctx.src_rel = ent, rel
         h2, ent, rel, glob = _c(h2), _c(ent), _c(rel), _c(glob)
-        if _lazy_bf16 and K.GEMM_MODE == 'bf16s':
+        if _lazy_bf16 and K.current_mode() == 'bf16s':
             # bf16-storage mode, internal callers only (RENet.loss_prepared*): X / Xr exist ONLY as bf16 operand
             # matrices; the fp32 tensors returned to autograd are uninitialised shells that carry them (K.operand
             # picks the attribute up) -- their values must never be read
@@ -382,6 +409,7 @@ class SeqAssembleFn(Function):
         return x, xr
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dx, dxr):
         g = ctx.g
         d = ctx.shapes[0][1]
@@ -410,6 +438,7 @@ class GRUFn(Function):
     (model.py:86-88).  x: [S, I] packed time-major; step_off: ctypes int32[L+1] on the host."""
 
     @staticmethod
+    @_fwd_mode
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, step_off, total_rows):
         x, w_ih, w_hh, b_ih, b_hh = _c(x), _c(w_ih), _c(w_hh), _c(b_ih), _c(b_hh)
         hdim = w_hh.shape[1]
@@ -421,6 +450,7 @@ class GRUFn(Function):
         return full.unsqueeze(0)                 # h_n layout of nn.GRU: [1, B, H]
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dh):
         x, w_ih, w_hh, saved = ctx.saved_tensors
         hdim, nnz = ctx.hdim, ctx.nnz
@@ -445,6 +475,7 @@ class MultiGRUFn(Function):
     live_cols: None, or per problem the number of leading columns of dX the caller reads (None = all)."""
 
     @staticmethod
+    @_fwd_mode
     def forward(ctx, step_offs, total_rows, live_cols, *ts):
         n = len(ts) // 5
         ctx.live_cols = live_cols
@@ -475,12 +506,13 @@ class MultiGRUFn(Function):
         return tuple(h.unsqueeze(0) for h in hs)
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, *dhs):
         n, hdim = ctx.n, ctx.hdim
         sv_ = ctx.saved_tensors
         xs, w_ihs, w_hhs, svs = sv_[:n], sv_[n:2 * n], sv_[2 * n:3 * n], sv_[3 * n:4 * n]
         d_gis, d_ghs = K.gru_bwd_layouts([_c(dh[0, :nz]) for dh, nz in zip(dhs, ctx.nnz)], ctx.step_offs, hdim,
-                                         list(w_hhs), list(svs), out_bf16=(K.GEMM_MODE == 'bf16s'))
+                                         list(w_hhs), list(svs), out_bf16=(K.current_mode() == 'bf16s'))
         def param_grads(k, dgi_op):
             """dW_ih, dW_hh, db_ih, db_hh of problem k: consumed by the optimizer only."""
             t_ih, t_hh = (grad_target(t) for t in ctx.src_w[k])
@@ -529,12 +561,12 @@ class MultiGRUFn(Function):
 
         all_in_place = all(grad_target(t) is not None for k in range(n) for t in ctx.src_w[k] + ctx.src_b[k])
         sd0 = _Side(d_gis[0].device if not isinstance(d_gis[0], K.BF16Mat) else d_gis[0].p.device)
-        if DEFER_WEIGHT_GRADS and sd0.on and all_in_place and K.GEMM_MODE != 'bf16s':
+        if DEFER_WEIGHT_GRADS and sd0.on and all_in_place and K.current_mode() != 'bf16s':
             # every parameter gradient accumulates in place and somebody joins before the optimizer reads it: dX of all
             # problems on this stream (what the rest of the backward pass waits for), all parameter gradients on the side
             # stream, NOT joined here
             ops_ = [K.operand(d_gis[k]) for k in range(n)]
-            if K.GEMM_MODE == 'f16x3':
+            if K.current_mode() == 'f16x3':
                 for o in ops_:
                     o.bound()                                          # measured on THIS stream, before the fork
             sd = _Side(sd0.main.device)                                # (fork: the side stream sees d_gis / bounds)
@@ -595,7 +627,7 @@ def _head_forward(a, ia, hmid, c, ic, weight, bias, target, drop_p, seed, grad_s
     if debug_tap is not None:
         debug_tap('logits', logits)
     dl_bf16 = None
-    if need_grad and K.GEMM_MODE == 'bf16s':
+    if need_grad and K.current_mode() == 'bf16s':
         # bf16-storage mode: the gradient is written as a bf16 operand matrix, the fp32 logits are dropped
         row_loss, dl_bf16 = K.softmax_ce_bf16(logits, target, grad_scale, row_loss=row_loss)
         logits = feat.new_empty(0)
@@ -608,7 +640,7 @@ def _scale_ce_gradient(dlogits, g, grad_scale):
     """dlogits *= g (the upstream scalar, device memory) -> the bound |g| * grad_scale on max |dlogits| as a 1-element
     device tensor in f16x3 mode (those GEMMs scale their operands by a bound on the tensor's magnitude; |softmax -
     onehot| <= 1, so this one is known without a pass over the 188 MB), else None."""
-    if K.GEMM_MODE == 'f16x3' and not isinstance(dlogits, K.BF16Mat) and dlogits.is_cuda:
+    if K.current_mode() == 'f16x3' and not isinstance(dlogits, K.BF16Mat) and dlogits.is_cuda:
         return K.scale_by_device_scalar(dlogits, g, bound_in=float(grad_scale))
     K.scale_by_device_scalar(dlogits, g)
     return None
@@ -648,6 +680,7 @@ class HeadCEFn(Function):
     into (softmax - onehot)/B in place, which the backward GEMMs then consume."""
 
     @staticmethod
+    @_fwd_mode
     def forward(ctx, a, ia, hmid, c, ic, weight, bias, target, plan_a, plan_c, drop_p, seed, loss_scale=1.0):
         ctx.srcs = (a, c, weight, bias)
         a, hmid, weight, bias = _c(a), _c(hmid), _c(weight), _c(bias)
@@ -668,6 +701,7 @@ class HeadCEFn(Function):
         return row_loss.mean() if loss_scale == 1.0 else row_loss.mean() * float(loss_scale)
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, g):
         feat, dlogits, weight = ctx.saved_tensors
         d, parts, drop_p, seed, plan_a, plan_c, a_shape, c_shape = ctx.meta
@@ -727,6 +761,7 @@ class DualHeadCEFn(Function):
     weight rel_weight is folded into the relation head's CE gradient instead of being applied by autograd)."""
 
     @staticmethod
+    @_fwd_mode
     def forward(ctx, a, ia, h1, c, ic, w1, b1, target1, h2, w2, b2, target2, plan_a, plan_c, drop_p, seed1, seed2,
                 loss_scale=1.0, rel_weight=0.1):
         ctx.srcs = (a, c, w1, b1, w2, b2)
@@ -755,6 +790,7 @@ class DualHeadCEFn(Function):
         return torch.dot(rl, _loss_weight_vector(b, s1, s2, h1.device))
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, g):
         feat1, dl1, w1, feat2, dl2, w2 = ctx.saved_tensors
         d, drop_p, seed1, seed2, plan_a, plan_c, a_shape, c_shape = ctx.meta
@@ -803,6 +839,7 @@ class SegmentPoolFn(Function):
     """dgl.max_nodes / mean_nodes over the member graphs (Aggregator.py:58-61)."""
 
     @staticmethod
+    @_fwd_mode
     def forward(ctx, h, seg_ptr, num_graphs, is_max):
         h = _c(h)
         out, arg = K.segment_pool_fwd(h, seg_ptr, num_graphs, is_max)
@@ -810,6 +847,7 @@ class SegmentPoolFn(Function):
         return out
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, dout):
         seg_ptr, arg, num_graphs, is_max, n = ctx.meta
         return K.segment_pool_bwd(_c(dout), seg_ptr, arg, num_graphs, is_max, n), None, None, None
@@ -819,11 +857,13 @@ class DropoutFn(Function):
     """Counter-based inverted dropout (Aggregator.py:69); the mask is regenerated in backward."""
 
     @staticmethod
+    @_fwd_mode
     def forward(ctx, x, drop_p, seed):
         ctx.meta = (drop_p, seed)
         return K.dropout(_c(x), drop_p, seed)
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, g):
         return K.dropout(_c(g), *ctx.meta), None, None
 
@@ -832,12 +872,14 @@ class LinearFn(Function):
     """y = x @ W^T + b on the MFMA GEMM (nn.Linear forward/backward; global_model.py:52)."""
 
     @staticmethod
+    @_fwd_mode
     def forward(ctx, x, weight, bias):
         x, weight = _c(x), _c(weight)
         ctx.save_for_backward(x, weight)
         return K.gemm(x, weight, tb=True, bias=_c(bias))
 
     @staticmethod
+    @_bwd_mode
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g = _c(g)

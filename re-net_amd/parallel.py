@@ -224,6 +224,7 @@ class HipAdam(object):
     def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=0.0):
         import renet_hip as K
         self.K = K
+        self._module = module          # (its `gemm_mode` attribute is read at every step)
         self.params = FlatParams(module)
         self.grads = FlatGrads(module)            # same layout (flat_layout) as the parameters
         self.m = torch.zeros_like(self.params.flat)
@@ -283,7 +284,8 @@ class HipAdam(object):
         self.K.weights_changed()
         # f16x3 mode: the magnitude bounds of all registered weights, measured HERE on the step's stream (one launch), so
         # that no GEMM of the next step -- on whichever stream ops._Side puts it -- is the one that triggers the pass
-        self.K.prefetch_weight_bounds(self.params.flat.device)
+        with self.K.gemm_mode(getattr(self._module, 'gemm_mode', None)):
+            self.K.prefetch_weight_bounds(self.params.flat.device)
 
 
 class _StepScope(object):

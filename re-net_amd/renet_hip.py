@@ -4,6 +4,7 @@ and passes raw device pointers + the current stream to the C ABI.
 
 There is NO fallback: if the library is missing or a call fails, this raises.
 """
+import contextlib
 import ctypes
 import os
 
@@ -405,7 +406,7 @@ def gather_weight_bf16(weight):
     """bf16 copy of an fp32 matrix the gather kernels read (the relation-block table, the entity table) in
     bf16-storage mode, else None.  Registered weights come from the per-optimizer-step cache (_as_bf16).
     RENET_BF16_GATHER=0 keeps the gathers on fp32 operands."""
-    if GEMM_MODE != 'bf16s' or os.environ.get('RENET_BF16_GATHER', '1') == '0':
+    if current_mode() != 'bf16s' or os.environ.get('RENET_BF16_GATHER', '1') == '0':
         return None
     if weight.numel() * 2 >= (1 << 31):
         return None
@@ -531,6 +532,35 @@ def auto_split_k(m, n, k):
 # Default since round 4: 'bf16x6', the 24-bit split (fp32-class: every operand bit enters the product).  'f16x3' (22-bit
 # operands, the round-3 default) is the opt-in FAST mode, 'f32' the exact-product mode; bench.py reports all three.
 GEMM_MODE = os.environ.get('RENET_GEMM', 'bf16x6')
+
+# Per-MODEL choice between the two split modes (round 4; review r3 "weak 8"): a model may carry `gemm_mode = 'f16x3'` (or
+# 'bf16x6') and its forward / backward passes then run inside `with gemm_mode(...)`; everything below reads the mode
+# through current_mode().  GEMM_MODE stays the PROCESS default, and the two modes that change more than the GEMM entry
+# point -- 'f32' (the GRU recurrences pick their exact kernels inside the library from RENET_GEMM) and 'bf16s' (operand
+# storage) -- remain process-wide: gemm_mode() accepts them only when they equal the process default.
+_mode_override = [None]
+_PER_MODEL_MODES = ('bf16x6', 'f16x3')
+
+
+def current_mode():
+    return _mode_override[0] or GEMM_MODE
+
+
+@contextlib.contextmanager
+def gemm_mode(mode):
+    """Scope in which the fp32-class GEMMs run in `mode` (None: no change)."""
+    if mode is None or mode == current_mode():
+        yield
+        return
+    if mode not in _PER_MODEL_MODES or GEMM_MODE not in _PER_MODEL_MODES:
+        raise RenetHipError('gemm_mode(%r): only %s can be chosen per model, and only in a process whose default is one '
+                            'of them (RENET_GEMM=%s)' % (mode, ' / '.join(_PER_MODEL_MODES), GEMM_MODE))
+    old = _mode_override[0]
+    _mode_override[0] = mode
+    try:
+        yield
+    finally:
+        _mode_override[0] = old
 
 
 class BF16Mat(object):
@@ -707,7 +737,7 @@ def _measure_all_weights(device):
 def prefetch_weight_bounds(device):
     """Measure every registered weight NOW, on the current stream (parallel.HipAdam.step calls this right behind the
     update, on the stream the step runs on): the f16x3 GEMMs of the next step then only ever hit the cache."""
-    if GEMM_MODE == 'f16x3' and _weight_ptrs:
+    if current_mode() == 'f16x3' and _weight_ptrs:
         _weight_max.update(_measure_all_weights(device))
 
 
@@ -759,7 +789,7 @@ def const_bound(value, device):
 def operand_like(x, other):
     """Operand handle for x that reuses the magnitude bound of handle `other` (the caller knows |x| <= max |other|
     elementwise: the GRU's dGh against dGi); plain x outside f16x3 mode."""
-    if GEMM_MODE != 'f16x3' or not isinstance(other, F32Op):
+    if current_mode() != 'f16x3' or not isinstance(other, F32Op):
         return operand(x)
     part, n = other.bound()
     return F32Op(x, part, n)
@@ -778,7 +808,7 @@ def _skinny_shape(ta, m, n, k, a, b, split_k):
 # renet_maxabs_partials pass; a tensor that arrives without the attribute (re-wrapped by autograd, a view, a copy) is
 # simply measured.  The producers' outputs are never modified in place.  RENET_FUSED_BOUNDS=0 turns this off.
 def _fused_bounds(t):
-    return GEMM_MODE == 'f16x3' and t.is_cuda and t.numel() > 0 and os.environ.get('RENET_FUSED_BOUNDS', '1') != '0'
+    return current_mode() == 'f16x3' and t.is_cuda and t.numel() > 0 and os.environ.get('RENET_FUSED_BOUNDS', '1') != '0'
 
 
 def _note_bound(t, part, n):
@@ -822,9 +852,9 @@ def operand(x, bound=None):
         _lazy_shells.pop((x.data_ptr(), tuple(x.shape)), None)
     if lazy is not None:
         return lazy
-    if GEMM_MODE == 'bf16s':
+    if current_mode() == 'bf16s':
         return pack_bf16(x)
-    if GEMM_MODE == 'f16x3' and x.is_cuda and x.dim() == 2:
+    if current_mode() == 'f16x3' and x.is_cuda and x.dim() == 2:
         noted = getattr(x, '_renet_bound', None)
         if noted is not None and bound is None:
             return F32Op(x, noted[0], noted[1])
@@ -872,9 +902,9 @@ def gemm_bf16s(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.
 def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, split_k=None, mode=None):
     """out = alpha * op(a) @ op(b) + bias + beta * out.  a/b may be row-strided views.
     split_k=None picks the deterministic split-K factor automatically."""
-    if (mode or GEMM_MODE) == 'bf16s' or isinstance(a, BF16Mat) or isinstance(b, BF16Mat):
+    if (mode or current_mode()) == 'bf16s' or isinstance(a, BF16Mat) or isinstance(b, BF16Mat):
         return gemm_bf16s(a, b, ta=ta, tb=tb, out=out, bias=bias, alpha=alpha, beta=beta, split_k=split_k)
-    md = mode or GEMM_MODE
+    md = mode or current_mode()
     opa, opb = a, b
     if isinstance(a, F32Op):
         a = a.t
@@ -1149,7 +1179,7 @@ def gru_fwd_layouts(gis, step_offs, hdim, w_hhs, b_hhs, out_rows):
     ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
     so, ls = _offs(step_offs)
     t0 = _timer.begin() if _timer is not None else None
-    fn = lib().renet_gru_fwd_layouts_bf16 if GEMM_MODE == 'bf16s' else lib().renet_gru_fwd_layouts
+    fn = lib().renet_gru_fwd_layouts_bf16 if current_mode() == 'bf16s' else lib().renet_gru_fwd_layouts
     _check(fn(n, _ptrs(gis), so, ls, hdim, _ptrs(w_hhs), _ptrs(b_hhs), _ptrs(hs),
                                        (ctypes.c_int * n)(*rows), _ptrs(svs), ws.data_ptr(), nbytes, _stream()),
            'gru_fwd_layouts')
@@ -1163,7 +1193,7 @@ def gru_bwd_layouts(dh_lasts, step_offs, hdim, w_hhs, saveds, out_bf16=False):
     n = len(dh_lasts)
     dev = saveds[0].device
     if out_bf16:
-        if GEMM_MODE != 'bf16s':
+        if current_mode() != 'bf16s':
             raise RenetHipError('bf16 GRU gradients exist in bf16-storage mode only')
         d_gis = [bf16_empty(s_.shape[0], 3 * hdim, dev) for s_ in saveds]
         d_ghs = [bf16_empty(s_.shape[0], 3 * hdim, dev) for s_ in saveds]
@@ -1209,7 +1239,7 @@ def gru_bwd_layouts(dh_lasts, step_offs, hdim, w_hhs, saveds, out_bf16=False):
         elif rc != -2:                                   # RENET_ERR_UNSUPPORTED: another recurrence is selected
             _check(rc, 'gru_bwd_layouts_bounds')
     if not done:
-        fn = lib().renet_gru_bwd_layouts_bf16 if GEMM_MODE == 'bf16s' else lib().renet_gru_bwd_layouts
+        fn = lib().renet_gru_bwd_layouts_bf16 if current_mode() == 'bf16s' else lib().renet_gru_bwd_layouts
         _check(fn(n, _ptrs(dh_lasts), so, ls, hdim, _ptrs(w_hhs), _ptrs(saveds), _ptrs(d_gis),
                   _ptrs(d_ghs), ws.data_ptr(), nbytes, _stream()), 'gru_bwd_layouts')
     if t0 is not None:

@@ -124,6 +124,70 @@ def test_side_stream_changes_no_value(dev, monkeypatch):
     assert torch.equal(pa, pb)
 
 
+def test_two_models_with_different_gemm_modes_in_one_process(dev, monkeypatch):
+    """Review r3 (weak 8): the fp32-class GEMM mode was one process-wide switch.  Since round 4 a model carries its own
+    (`net.gemm_mode = 'f16x3' | 'bf16x6' | None`), forward and backward run inside that scope (autograd Functions remember
+    the mode of their forward pass) and HipAdam measures the f16x3 weight bounds under it.  Two models with different
+    modes, stepped ALTERNATELY in one process, must each end bit-identical to the same model trained alone with that mode
+    as the process default."""
+    import model as M
+    import ops
+    import parallel
+    import preprocess as P
+    import renet_hip as K
+    import synth
+    if K.GEMM_MODE not in ('bf16x6', 'f16x3'):
+        pytest.skip('per-model modes exist for the two split modes only')
+    quads, num_ent, num_rels, _ = synth.make_stream('ICEWS18', seed=5, num_t=40)
+    gd = P.build_graph_dict(quads, num_rels)
+    hs, ho = P.HistoryIndex(quads, 's', 10), P.HistoryIndex(quads, 'o', 10)
+    perm = np.random.RandomState(1).permutation(len(quads))
+
+    def make(mode):
+        torch.manual_seed(7)
+        net = M.RENet(num_ent, 200, num_rels, dropout=0.5, seq_len=10, num_k=10)
+        gen = torch.Generator().manual_seed(3)
+        net.global_emb = {int(t): torch.randn(1, 1, 200, generator=gen) * 0.1 for t in gd}
+        net.to(dev).train()
+        net.gemm_mode = mode
+        return net, parallel.HipAdam(net, lr=1e-3, weight_decay=1e-5, max_norm=1.0)
+
+    def step(net, opt, k, seed_base):
+        idx = perm[k * 512:(k + 1) * 512]
+        ops.reset_seed_counter(seed_base + 100 * k)            # same dropout masks whoever else runs in between
+        with opt.step_scope(head_passes=1):
+            loss = net.loss_prepared_both(net.prepare_both(quads[idx], hs.take(idx), ho.take(idx), gd))
+            loss.backward()
+            opt.step()
+        return loss.item()
+
+    def flat(net):
+        return torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
+
+    # alternately, each with its own mode
+    (na, oa), (nb, ob) = make('f16x3'), make('bf16x6')
+    la, lb = [], []
+    for k in range(3):
+        la.append(step(na, oa, k, 1000))
+        lb.append(step(nb, ob, k, 5000))
+    torch.cuda.synchronize()
+    pa, pb = flat(na), flat(nb)
+    oa.close(); ob.close()
+    # alone, the mode as the process default
+    solo = {}
+    for mode, base in (('f16x3', 1000), ('bf16x6', 5000)):
+        monkeypatch.setattr(K, 'GEMM_MODE', mode)
+        net, opt = make(None)
+        solo[mode] = ([step(net, opt, k, base) for k in range(3)], flat(net))
+        opt.close()
+    assert la == solo['f16x3'][0] and lb == solo['bf16x6'][0], (la, solo['f16x3'][0], lb, solo['bf16x6'][0])
+    assert torch.equal(pa, solo['f16x3'][1]) and torch.equal(pb, solo['bf16x6'][1])
+    assert not torch.equal(pa, pb)                              # (the two modes do differ in the last bits)
+    with pytest.raises(K.RenetHipError):
+        with K.gemm_mode('bf16s'):                              # storage / exact modes stay process-wide
+            pass
+
+
 def test_deferred_weight_gradients_change_no_value(dev, monkeypatch):
     """Inside `with opt.step_scope(...)` the GRU parameter-gradient GEMMs run on the side stream and are joined only in
     opt.step() (ops.DEFER_WEIGHT_GRADS, round 4): three declared steps -- merged pass and the pair of passes -- against
