@@ -129,11 +129,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     ranks_seen = 1
-    if world > 1:
+    force_rccl = os.environ.get('RENET_FORCE_REDUCER') == '1'
+    if world > 1 or force_rccl:
+        # RENET_FORCE_REDUCER=1 on a one-GPU box: a ONE-rank RCCL group, so that the reducer's call sequence (early bucket
+        # on its side stream, tail buckets, waits) really goes through RCCL instead of being skipped
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        os.environ.setdefault('RANK', str(rank))
+        os.environ.setdefault('WORLD_SIZE', str(world))
         dist.init_process_group('nccl', device_id=dev)
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)                        # RCCL is really connecting `world` ranks
         ranks_seen = int(round(float(ones.item())))
+    dist_on = world > 1 or force_rccl
 
     if args.dtype == 'bf16':
         # bf16 STORAGE mode (renet_gemm_bf16s); RENET_BF16_STORAGE=0 keeps fp32 tensors and rounds inside the GEMMs.
@@ -389,7 +397,7 @@ def main():
         e2e_threads = args.batch * world * done / (time.perf_counter() - t0)
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -613,7 +621,7 @@ def main():
     if world > 1 and not companions:
         out['multi_gpu_note'] = 'companion scaling modes skipped (--companions 0)'
     print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
