@@ -401,13 +401,13 @@ def test_ctypes_signatures_match_the_header():
         assert (restype is None) == (ret == 'void') and (ret == 'void' or ckind[restype] in (kinds[ret], 'u64'))
 
 
-def _tile_of_block(L, nbx, nby):
+def _tile_of_block(L, nbx, nby, panel=8):
     """Python restatement of tile_of_block (csrc/gemm_split.hip): linear dispatch index -> (bx, by)."""
     nb = nbx * nby
     per = nb >> 3
     t = (L & 7) * per + (L >> 3) if L < 8 * per else L
     ns, nl = min(nbx, nby), max(nbx, nby)
-    w = min(ns, 8)
+    w = min(ns, panel)
     p, r = divmod(t, w * nl)
     wp = min(w, ns - p * w)
     l, sh = r // wp, p * w + r % wp
@@ -419,13 +419,14 @@ def test_gemm_virtual_tile_order_is_a_bijection():
     formula here mirrors the device code line by line; the GPU tests cover a handful of shapes, this covers all
     small ones), and consecutive workgroups of one XCD must share a slab of the long operand."""
     src = open(os.path.join(ROOT, 're-net_amd', 'csrc', 'gemm_split.hip')).read()
-    for frag in ('(L & 7) * per + (L >> 3)', 'const int w = min(ns, 8);', 'const int wp = min(w, ns - p * w);',
+    for frag in ('(L & 7) * per + (L >> 3)', 'const int w = min(ns, xcd_order);', 'const int wp = min(w, ns - p * w);',
                  'const int l = r / wp, sh = p * w + (r - l * wp);'):
         assert frag in src, 'tile_of_block changed: update the restatement in this test (%s)' % frag
     for nbx in list(range(1, 41)) + [180, 181, 360]:
         for nby in list(range(1, 41)) + [8, 180]:
-            seen = {_tile_of_block(L, nbx, nby) for L in range(nbx * nby)}
-            assert len(seen) == nbx * nby and all(0 <= x < nbx and 0 <= y < nby for x, y in seen), (nbx, nby)
+            for panel in ((8,) if nbx > 24 or nby > 24 else (1, 2, 3, 4, 8, 16)):      # (round 4: the panel width is a knob)
+                seen = {_tile_of_block(L, nbx, nby, panel) for L in range(nbx * nby)}
+                assert len(seen) == nbx * nby and all(0 <= x < nbx and 0 <= y < nby for x, y in seen), (nbx, nby, panel)
     # logits GEMM of the bench (8 x 180 tiles): the 8 row tiles of one column tile are consecutive on one XCD
     nbx, nby = 180, 8
     xcd0 = [_tile_of_block(L, nbx, nby) for L in range(0, nbx * nby, 8)]
