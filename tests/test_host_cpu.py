@@ -635,3 +635,32 @@ def test_bulk_cache_update_equals_one_update_cache_call_per_winner():
             seq = M._update_cache(Dummy(), seq, r, np.asarray([o]))
         got = M._bulk_update_cache(start, pairs)
         assert np.array_equal(np.asarray(seq, dtype=np.int64).reshape(-1, 2), got), (trial, start, pairs)
+
+
+def test_gemm_mode_scopes():
+    """renet_hip.gemm_mode (round 4): nesting, restoration after an exception, None = no change, and the two modes that
+    stay process-wide ('f32', 'bf16s') are refused unless they ARE the process default."""
+    import renet_hip as K
+    base = K.GEMM_MODE
+    if base not in ('bf16x6', 'f16x3'):
+        pytest.skip('process default is not a split mode')
+    other = 'f16x3' if base == 'bf16x6' else 'bf16x6'
+    assert K.current_mode() == base
+    with K.gemm_mode(None):
+        assert K.current_mode() == base
+    with K.gemm_mode(other):
+        assert K.current_mode() == other
+        with K.gemm_mode(base):
+            assert K.current_mode() == base
+        assert K.current_mode() == other
+    assert K.current_mode() == base
+    with pytest.raises(ValueError):
+        with K.gemm_mode(other):
+            raise ValueError('boom')
+    assert K.current_mode() == base
+    for refused in ('f32', 'bf16s', 'bf16', 'nonsense'):
+        with pytest.raises(K.RenetHipError):
+            with K.gemm_mode(refused):
+                pass
+    with K.gemm_mode(base):                      # the process default itself is always accepted
+        pass
