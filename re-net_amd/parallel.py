@@ -263,8 +263,17 @@ class HipAdam(object):
             pass
 
     def step_scope(self, head_passes=2, average=True):
-        """Context manager around ONE training step (forward, backward, step())."""
+        """Context manager around ONE training step (forward, backward, step()).  Inside it the parameter-gradient
+        kernels that feed nothing but the optimizer may still be running on a side stream when backward() returns
+        (ops.DEFER_WEIGHT_GRADS): step() waits for them; code that reads `.grad` BEFORE step() -- gradient logging, a
+        custom clip -- calls sync_grads() first."""
         return _StepScope(self, head_passes, average)
+
+    @staticmethod
+    def sync_grads():
+        """Orders the current stream behind every deferred gradient kernel (no-op when nothing is pending)."""
+        import ops
+        ops.join_deferred()
 
     def step(self):
         """all-reduce (if distributed; the score head's bucket was started during backward) -> clip -> Adam ->
