@@ -183,6 +183,10 @@ int renet_rgcn_bwd_w64(const float* x, const float* gn, const int32_t* e_src, co
  * (model.py:89-90,98-99) and their autograd backward GEMMs.
  * split_k > 1 runs the deterministic two-pass split-K (partials in `workspace`,
  * renet_gemm_workspace bytes) for the tall-skinny weight-gradient shapes.
+ * Products are EXACT fp32 (no operand rounding: integer-valued operands give integer-exact results), accumulation is
+ * fp32 in a fixed k order.  Since round 4 the kernel addresses its operands through raw buffer descriptors (32-bit byte
+ * offsets, branch-free k-loop; csrc/gemm.hip); operands it cannot reach that way (>= 4 GiB) run the round-1 kernel
+ * with 64-bit addressing -- same contract, same results up to summation order.
  * ---------------------------------------------------------------------------------------------- */
 size_t renet_gemm_workspace(int M, int N, int split_k);
 int renet_gemm_f32(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
