@@ -51,67 +51,8 @@ __device__ __forceinline__ float h3_wave_max(const float* __restrict__ part, int
     return m;
 }
 
-// Loader of the f16x3 kernels: raw buffer loads -- a descriptor of the operand (SGPRs) plus a per-lane 32-bit byte
-// offset computed once and advanced by the tile's uniform k offset (one v_add per load): no 64-bit address arithmetic and
-// NO BRANCH inside the MFMA phase.  (tools/gemm_trace.py: with the generic ItemLoader -- clamped addresses, a
-// uniform branch per item -- every load piece cost the issuing wave ~180 cycles between two MFMAs, 2.4x the
-// matrix-pipe time of the 24-MFMA phase.)  Nothing is clamped along k: the descriptor's num_records is the operand's
-// exact extent, every dword beyond it reads as 0 without touching memory (raw buffers are range-checked per dword:
-// tests/test_gpu_parity.py runs K % 4 != 0 with odd row strides, where the last row's last 16-byte load straddles the
-// end), reads beyond K inside it (the next row) are zeroed by store_items_h's EDGE path like the clamped rows.
-// Requires rows * ld * 4 < 2^32 (checked on the host; larger operands run the bf16x6 kernels).
-typedef uint32_t h3_u32x4 __attribute__((ext_vector_type(4)));
-
-template <bool CONTIG_K, int NT, int ROWS, int NI>
-struct TileLoaderH {
-    __amdgpu_buffer_rsrc_t rs;
-    uint32_t off[NI];          // bytes: CONTIG_K: (row * ld + kk) * 4      else: (row + kk * ld) * 4
-    uint32_t ldb;              // row stride in bytes
-
-    __device__ __forceinline__ void init(const float* P, int ld, int rows, int K, int row0, int tid) {
-        const uint32_t extent = CONTIG_K ? (uint32_t)(rows - 1) * (uint32_t)ld + (uint32_t)K
-                                         : (uint32_t)(K - 1) * (uint32_t)ld + (uint32_t)rows;
-        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), (short)0, (int)(extent * 4u),
-                                               0x00020000);
-        ldb = (uint32_t)ld * 4u;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            int row, k;
-            item_pos<CONTIG_K, ROWS>(tid + NT * i, row, k);
-            row = min(row0 + row, rows - 1);
-            off[i] = (CONTIG_K ? (uint32_t)row * (uint32_t)ld + (uint32_t)k : (uint32_t)row + (uint32_t)k * (uint32_t)ld) * 4u;
-        }
-    }
-
-    __device__ __forceinline__ void load_item(int i, int k0, float4& r) const {
-        if constexpr (CONTIG_K) {
-            const h3_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off[i] + (uint32_t)k0 * 4u), 0, 0);
-            r = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-        } else {
-            const uint32_t b0 = off[i] + (uint32_t)k0 * ldb;
-            r.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)b0, 0, 0));
-            r.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(b0 + ldb), 0, 0));
-            r.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(b0 + 2u * ldb), 0, 0));
-            r.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(b0 + 3u * ldb), 0, 0));
-        }
-    }
-
-    __device__ __forceinline__ void load(int k0, float4 (&r)[NI]) const {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) load_item(i, k0, r[i]);
-    }
-};
-
-// out-of-range fix-up of one UNCLAMPED item: rows past the operand and k past K become zeros
-__device__ __forceinline__ float4 fix_item_h(float4 v, int rows, int K, int row0, int k0, int row, int k) {
-    const int kg = k0 + k;
-    const bool rok = row0 + row < rows;
-    if (!rok || kg >= K) v.x = 0.f;
-    if (!rok || kg + 1 >= K) v.y = 0.f;
-    if (!rok || kg + 2 >= K) v.z = 0.f;
-    if (!rok || kg + 3 >= K) v.w = 0.f;
-    return v;
-}
+// (TileLoaderH and fix_item_h -- the raw-buffer loader these kernels were first written for -- now live in gemm_split.hip:
+// the bf16x6 two-phase kernels use them too.)
 
 // registers -> two f16 planes in LDS (same [row][k] image and item order as store_items)
 template <bool CONTIG_K, bool EDGE, int NT, int ROWS, int NI>

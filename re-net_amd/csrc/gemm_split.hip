@@ -178,10 +178,72 @@ __device__ __forceinline__ float4 fix_item(float4 v, int rows, int K, int row0, 
     return v;
 }
 
+// Raw-buffer loader (f16x3 kernels since round 3, bf16x6 two-phase kernels since round 4): raw buffer loads -- a descriptor of the operand (SGPRs) plus a per-lane 32-bit byte
+// offset computed once and advanced by the tile's uniform k offset (one v_add per load): no 64-bit address arithmetic and
+// NO BRANCH inside the MFMA phase.  (tools/gemm_trace.py: with the generic ItemLoader -- clamped addresses, a
+// uniform branch per item -- every load piece cost the issuing wave ~180 cycles between two MFMAs, 2.4x the
+// matrix-pipe time of the 24-MFMA phase.)  Nothing is clamped along k: the descriptor's num_records is the operand's
+// exact extent, every dword beyond it reads as 0 without touching memory (raw buffers are range-checked per dword:
+// tests/test_gpu_parity.py runs K % 4 != 0 with odd row strides, where the last row's last 16-byte load straddles the
+// end), reads beyond K inside it (the next row) are zeroed by store_items_h's EDGE path like the clamped rows.
+// Requires rows * ld * 4 < 2^32 (checked on the host; larger operands run the bf16x6 kernels).
+typedef uint32_t h3_u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool CONTIG_K, int NT, int ROWS, int NI>
+struct TileLoaderH {
+    __amdgpu_buffer_rsrc_t rs;
+    uint32_t off[NI];          // bytes: CONTIG_K: (row * ld + kk) * 4      else: (row + kk * ld) * 4
+    uint32_t ldb;              // row stride in bytes
+
+    __device__ __forceinline__ void init(const float* P, int ld, int rows, int K, int row0, int tid) {
+        const uint32_t extent = CONTIG_K ? (uint32_t)(rows - 1) * (uint32_t)ld + (uint32_t)K
+                                         : (uint32_t)(K - 1) * (uint32_t)ld + (uint32_t)rows;
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), (short)0, (int)(extent * 4u),
+                                               0x00020000);
+        ldb = (uint32_t)ld * 4u;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int row, k;
+            item_pos<CONTIG_K, ROWS>(tid + NT * i, row, k);
+            row = min(row0 + row, rows - 1);
+            off[i] = (CONTIG_K ? (uint32_t)row * (uint32_t)ld + (uint32_t)k : (uint32_t)row + (uint32_t)k * (uint32_t)ld) * 4u;
+        }
+    }
+
+    __device__ __forceinline__ void load_item(int i, int k0, float4& r) const {
+        if constexpr (CONTIG_K) {
+            const h3_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off[i] + (uint32_t)k0 * 4u), 0, 0);
+            r = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        } else {
+            const uint32_t b0 = off[i] + (uint32_t)k0 * ldb;
+            r.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)b0, 0, 0));
+            r.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(b0 + ldb), 0, 0));
+            r.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(b0 + 2u * ldb), 0, 0));
+            r.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(b0 + 3u * ldb), 0, 0));
+        }
+    }
+
+    __device__ __forceinline__ void load(int k0, float4 (&r)[NI]) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) load_item(i, k0, r[i]);
+    }
+};
+
+// out-of-range fix-up of one UNCLAMPED item: rows past the operand and k past K become zeros
+__device__ __forceinline__ float4 fix_item_h(float4 v, int rows, int K, int row0, int k0, int row, int k) {
+    const int kg = k0 + k;
+    const bool rok = row0 + row < rows;
+    if (!rok || kg >= K) v.x = 0.f;
+    if (!rok || kg + 1 >= K) v.y = 0.f;
+    if (!rok || kg + 2 >= K) v.z = 0.f;
+    if (!rok || kg + 3 >= K) v.w = 0.f;
+    return v;
+}
+
 // registers -> three bf16 planes in LDS.  EDGE (workgroup-uniform: the tile touches the end of the matrix
 // in either dimension) enables the out-of-range fix-up of the clamped loads; interior tiles -- almost all of
 // them -- run the bare split: 6 v_cvt_pk_bf16_f32, 4 packed subtractions and 3 ds_write_b64 per item.
-template <bool CONTIG_K, bool EDGE, int NT = 256, int ROWS = 128, int NI = 4>
+template <bool CONTIG_K, bool EDGE, int NT = 256, int ROWS = 128, int NI = 4, bool RAW = false>
 __device__ __forceinline__ void store_items(__bf16* __restrict__ S, int rows, int K, int row0, int k0, int tid,
                                             const float4 (&r)[NI]) {
     constexpr int PLANE = ROWS * LDS_ROW;
@@ -190,7 +252,10 @@ __device__ __forceinline__ void store_items(__bf16* __restrict__ S, int rows, in
         int row, k;
         item_pos<CONTIG_K, ROWS>(tid + NT * i, row, k);
         float4 v = r[i];
-        if constexpr (EDGE) v = fix_item<CONTIG_K>(v, rows, K, row0, k0, row, k);
+        if constexpr (EDGE) {
+            if constexpr (RAW) v = fix_item_h(v, rows, K, row0, k0, row, k);      // unclamped loads (TileLoaderH)
+            else v = fix_item<CONTIG_K>(v, rows, K, row0, k0, row, k);
+        }
         f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
         __bf16* dst = S + row * LDS_ROW + k;
 #pragma unroll
@@ -323,7 +388,9 @@ __device__ __forceinline__ void store_tile(const SplitArgs& g, int m0, int n0, i
         }
 }
 
-template <bool TA, bool TB>
+// RAW: operands addressed through raw buffer descriptors (TileLoaderH; both operands below 2^30 elements of reach, checked
+// on the host) -- the generic ItemLoader otherwise.
+template <bool TA, bool TB, bool RAW>
 __global__ __launch_bounds__(THREADS) void gemm_split_kernel(SplitArgs g) {
     __shared__ __attribute__((aligned(16))) __bf16 sA[3 * PLANE];
     __shared__ __attribute__((aligned(16))) __bf16 sB[3 * PLANE];
@@ -349,8 +416,8 @@ __global__ __launch_bounds__(THREADS) void gemm_split_kernel(SplitArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[4], rb[4];
-    ItemLoader<A_CK> la;
-    ItemLoader<B_CK> lb;
+    std::conditional_t<RAW, TileLoaderH<A_CK, THREADS, BM, 4>, ItemLoader<A_CK>> la;
+    std::conditional_t<RAW, TileLoaderH<B_CK, THREADS, BN, 4>, ItemLoader<B_CK>> lb;
     la.init(g.A, g.lda, g.M, g.K, m0, tid);
     lb.init(g.B, g.ldb, g.N, g.K, n0, tid);
     if (kt0 < kt1) {
@@ -368,10 +435,10 @@ __global__ __launch_bounds__(THREADS) void gemm_split_kernel(SplitArgs g) {
         __syncthreads();                               // previous tile fully consumed
         TRACE_T(wave, kt - kt0, 0);
         const bool k_edge = (kt + 1) * BK > g.K;
-        if (a_edge || k_edge) store_items<A_CK, true>(sA, g.M, g.K, m0, kt * BK, tid, ra);
-        else store_items<A_CK, false>(sA, g.M, g.K, m0, kt * BK, tid, ra);
-        if (b_edge || k_edge) store_items<B_CK, true>(sB, g.N, g.K, n0, kt * BK, tid, rb);
-        else store_items<B_CK, false>(sB, g.N, g.K, n0, kt * BK, tid, rb);
+        if (a_edge || k_edge) store_items<A_CK, true, THREADS, BM, 4, RAW>(sA, g.M, g.K, m0, kt * BK, tid, ra);
+        else store_items<A_CK, false, THREADS, BM, 4, RAW>(sA, g.M, g.K, m0, kt * BK, tid, ra);
+        if (b_edge || k_edge) store_items<B_CK, true, THREADS, BN, 4, RAW>(sB, g.N, g.K, n0, kt * BK, tid, rb);
+        else store_items<B_CK, false, THREADS, BN, 4, RAW>(sB, g.N, g.K, n0, kt * BK, tid, rb);
         TRACE_T(wave, kt - kt0, 1);
         __syncthreads();
         TRACE_T(wave, kt - kt0, 2);
@@ -397,7 +464,7 @@ constexpr int BMT = 256, THREADS_T = 512;
 constexpr int PLANE_T = BMT * LDS_ROW;
 constexpr size_t TALL_LDS = (size_t)(3 * PLANE_T + 3 * PLANE) * sizeof(__bf16);
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool RAW>
 __global__ __launch_bounds__(THREADS_T) void gemm_split_tall_kernel(SplitArgs g) {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem_t[];
     __bf16* sA = smem_t;
@@ -425,8 +492,8 @@ __global__ __launch_bounds__(THREADS_T) void gemm_split_tall_kernel(SplitArgs g)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[NIA], rb[NIB];
-    ItemLoader<A_CK, THREADS_T, BMT, NIA> la;
-    ItemLoader<B_CK, THREADS_T, BN, NIB> lb;
+    std::conditional_t<RAW, TileLoaderH<A_CK, THREADS_T, BMT, NIA>, ItemLoader<A_CK, THREADS_T, BMT, NIA>> la;
+    std::conditional_t<RAW, TileLoaderH<B_CK, THREADS_T, BN, NIB>, ItemLoader<B_CK, THREADS_T, BN, NIB>> lb;
     la.init(g.A, g.lda, g.M, g.K, m0, tid);
     lb.init(g.B, g.ldb, g.N, g.K, n0, tid);
     if (kt0 < kt1) {
@@ -440,10 +507,10 @@ __global__ __launch_bounds__(THREADS_T) void gemm_split_tall_kernel(SplitArgs g)
     for (int kt = kt0; kt < kt1; ++kt) {
         __syncthreads();                               // previous tile fully consumed
         const bool k_edge = (kt + 1) * BK > g.K;
-        if (a_edge || k_edge) store_items<A_CK, true, THREADS_T, BMT, NIA>(sA, g.M, g.K, m0, kt * BK, tid, ra);
-        else store_items<A_CK, false, THREADS_T, BMT, NIA>(sA, g.M, g.K, m0, kt * BK, tid, ra);
-        if (b_edge || k_edge) store_items<B_CK, true, THREADS_T, BN, NIB>(sB, g.N, g.K, n0, kt * BK, tid, rb);
-        else store_items<B_CK, false, THREADS_T, BN, NIB>(sB, g.N, g.K, n0, kt * BK, tid, rb);
+        if (a_edge || k_edge) store_items<A_CK, true, THREADS_T, BMT, NIA, RAW>(sA, g.M, g.K, m0, kt * BK, tid, ra);
+        else store_items<A_CK, false, THREADS_T, BMT, NIA, RAW>(sA, g.M, g.K, m0, kt * BK, tid, ra);
+        if (b_edge || k_edge) store_items<B_CK, true, THREADS_T, BN, NIB, RAW>(sB, g.N, g.K, n0, kt * BK, tid, rb);
+        else store_items<B_CK, false, THREADS_T, BN, NIB, RAW>(sB, g.N, g.K, n0, kt * BK, tid, rb);
         __syncthreads();
         const int k0n = min(kt + 1, kt1 - 1) * BK;     // next tile (the last step reloads its own: harmless)
         mfma_tile_ld<PLANE_T, PLANE, NIA + NIB>(sA, sB, arow, brow, ksel, acc, [&](auto ic) {
@@ -1390,16 +1457,16 @@ int launch_fused(const SplitArgs& g, dim3 grid, hipStream_t st) {
     return RENET_OK;
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool RAW>
 int launch_tall(const SplitArgs& g, dim3 grid, hipStream_t st) {
     static bool attr_set = false;      // benign race: the attribute is idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_split_tall_kernel<TA, TB>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_split_tall_kernel<TA, TB, RAW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)TALL_LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    RENET_LAUNCH((gemm_split_tall_kernel<TA, TB>), grid, dim3(THREADS_T), TALL_LDS, st, g);
+    RENET_LAUNCH((gemm_split_tall_kernel<TA, TB, RAW>), grid, dim3(THREADS_T), TALL_LDS, st, g);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }
@@ -1509,6 +1576,15 @@ static bool skinny_enabled() {
     return v != 0;
 }
 
+static bool split_raw_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RENET_GEMM_SPLIT_RAW");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v != 0;
+}
+
 static int gemm_planes_launch(bool bf16_mode, int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
                               const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                               int split_k, float* workspace, size_t workspace_bytes, void* stream) {
@@ -1536,6 +1612,10 @@ static int gemm_planes_launch(bool bf16_mode, int ta, int tb, int M, int N, int 
     // the fused kernel addresses with 32-bit element offsets and float4 loads along a contiguous K
     if (choice == 0 && (K < 4 || (size_t)(ta ? K : M) * lda >= (1u << 31) || (size_t)(tb ? N : K) * ldb >= (1u << 31)))
         choice = 1;
+    // two-phase kernels: raw buffer descriptors (32-bit byte offsets) while both operands reach less than 2^30 elements
+    // (RENET_GEMM_SPLIT_RAW=0: the generic 64-bit loader, for A/B runs)
+    const bool raw = split_raw_enabled() && (size_t)(ta ? K : M) * lda < ((size_t)1 << 30) &&
+                     (size_t)(tb ? N : K) * ldb < ((size_t)1 << 30);
     int e = RENET_OK;
     if (choice == 0) {
         dim3 grid(nbx, nby, split_k);
@@ -1551,16 +1631,28 @@ static int gemm_planes_launch(bool bf16_mode, int ta, int tb, int M, int N, int 
         else RENET_LAUNCH((gemm_bf16_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
     } else if (use_tall(ta, M, nbx, split_k)) {
         dim3 grid(nbx, (M + BMT - 1) / BMT, split_k);
-        if (!ta && !tb) e = launch_tall<false, false>(g, grid, st);
-        else if (!ta && tb) e = launch_tall<false, true>(g, grid, st);
-        else if (ta && !tb) e = launch_tall<true, false>(g, grid, st);
-        else e = launch_tall<true, true>(g, grid, st);
+#define RENET_TALL_LAUNCH(RAWV)                                                     \
+        do {                                                                        \
+            if (!ta && !tb) e = launch_tall<false, false, RAWV>(g, grid, st);       \
+            else if (!ta && tb) e = launch_tall<false, true, RAWV>(g, grid, st);    \
+            else if (ta && !tb) e = launch_tall<true, false, RAWV>(g, grid, st);    \
+            else e = launch_tall<true, true, RAWV>(g, grid, st);                    \
+        } while (0)
+        if (raw) RENET_TALL_LAUNCH(true);
+        else RENET_TALL_LAUNCH(false);
+#undef RENET_TALL_LAUNCH
     } else {
         dim3 grid(nbx, nby, split_k);
-        if (!ta && !tb) RENET_LAUNCH((gemm_split_kernel<false, false>), grid, dim3(THREADS), 0, st, g);
-        else if (!ta && tb) RENET_LAUNCH((gemm_split_kernel<false, true>), grid, dim3(THREADS), 0, st, g);
-        else if (ta && !tb) RENET_LAUNCH((gemm_split_kernel<true, false>), grid, dim3(THREADS), 0, st, g);
-        else RENET_LAUNCH((gemm_split_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
+#define RENET_SPLIT_LAUNCH(RAWV)                                                                                    \
+        do {                                                                                                        \
+            if (!ta && !tb) RENET_LAUNCH((gemm_split_kernel<false, false, RAWV>), grid, dim3(THREADS), 0, st, g);   \
+            else if (!ta && tb) RENET_LAUNCH((gemm_split_kernel<false, true, RAWV>), grid, dim3(THREADS), 0, st, g); \
+            else if (ta && !tb) RENET_LAUNCH((gemm_split_kernel<true, false, RAWV>), grid, dim3(THREADS), 0, st, g); \
+            else RENET_LAUNCH((gemm_split_kernel<true, true, RAWV>), grid, dim3(THREADS), 0, st, g);                \
+        } while (0)
+        if (raw) RENET_SPLIT_LAUNCH(true);
+        else RENET_SPLIT_LAUNCH(false);
+#undef RENET_SPLIT_LAUNCH
     }
     if (e != RENET_OK) return e;
     RENET_LAUNCH_CHECK();
