@@ -211,6 +211,9 @@ struct TileLoaderH {
     }
 
     __device__ __forceinline__ void load_item(int i, int k0, float4& r) const {
+#ifdef RENET_PROBE_NOLOAD           // probe builds only (tools/gemm_split_probe.py): the k-loop without its global loads
+        if (k0 > 0) return;
+#endif
         if constexpr (CONTIG_K) {
             const h3_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off[i] + (uint32_t)k0 * 4u), 0, 0);
             r = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
@@ -262,7 +265,14 @@ __device__ __forceinline__ void store_items(__bf16* __restrict__ S, int rows, in
         for (int p = 0; p < 3; ++p) {
             const bf16x2 blo = __builtin_convertvector(lo, bf16x2);        // v_cvt_pk_bf16_f32 (RNE)
             const bf16x2 bhi = __builtin_convertvector(hi, bf16x2);
+#ifdef RENET_PROBE_NOLDSW           // probe builds only: the split without its LDS stores (one plane still written)
+            if (p == 2) *reinterpret_cast<uint2*>(dst) = pack4(blo, bhi);
+#else
             *reinterpret_cast<uint2*>(dst + p * PLANE) = pack4(blo, bhi);
+#endif
+#ifdef RENET_PROBE_NOSPLIT          // probe builds only: three roundings, no residual arithmetic
+            if (false)
+#endif
             if (p < 2) {
                 lo -= __builtin_convertvector(blo, f32x2);                  // exact residuals
                 hi -= __builtin_convertvector(bhi, f32x2);
