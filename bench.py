@@ -239,6 +239,7 @@ def main():
             t0 = time.perf_counter()
             for k in range(args.warmup, n_total):
                 loss = self.train_step(*prepared[k])
+            self.enqueue_s = time.perf_counter() - t0      # host time to ENQUEUE the K steps (no sync inside a step)
             sync_all()
             elapsed = time.perf_counter() - t0
             K.set_timer(None)
@@ -257,6 +258,7 @@ def main():
     # the timed region of `value`: the product configuration (side streams on, no per-kernel events) ...
     elapsed, last_loss, host_build_ms, prepared = mode.run()
     value = mode.global_batch * args.steps / elapsed
+    host_enqueue_ms = mode.enqueue_s * 1e3 / args.steps
     # ... then the SAME K steps once more with HIP events around every C-ABI launch: the per-class kernel table, the
     # roofline's average launch durations and `kernel_only` come from this second pass (its wall time is reported too)
     timer = K.KernelTimer()
@@ -613,6 +615,8 @@ def main():
         'other_configs': other_configs,
         'pmc_source': pmc_file,
         'traffic_source': ('%s: rocprofv3 --pmc passes of this command (tools/pmc_traffic.py), NOT measured in this run' % pmc_file) if pmc_file else None, 'kernels': kernels, 'gemm_shapes': gemm_shapes, 'cpu_baseline': cpu,
+        'host_enqueue_ms_per_step': host_enqueue_ms,       # host time to enqueue a step of the `value` run; close to
+                                                           # ms_per_step = the host, not the GPU, paces the step
         'host_build_ms': host_build_ms, 'e2e_value': e2e, 'e2e_workers': e2e_workers, 'e2e_inline': e2e_inline, 'e2e_threads8': e2e_threads,
         'e2e_device_builder': e2e_device_builder, 'device_build_ms': device_build_ms,
         'last_loss': last_loss,
