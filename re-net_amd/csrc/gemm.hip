@@ -283,13 +283,25 @@ __global__ __launch_bounds__(THREADS) void gemm_f32_generic_kernel(GemmArgs g) {
 // of magnitude below its ceilings (16 ds_read_b128 + 8 ds_write_b128 + 8 buffer loads per wave and 4096 MFMA cycles).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void tile_of_block(int nbx, int nby, bool xcd_order, int& bx, int& by) {
-    // same virtual tile order as gemm_split.hip: XCD x owns one contiguous 1/8 of the tile sequence, in which the SHORT
-    // grid dimension runs fastest in panels of <= 8 tiles (tiles sharing a slab of the long operand share an L2)
+__device__ __forceinline__ void tile_of_block(int nbx, int nby, bool xcd_order, int& bx, int& by, int& bz) {
+    // same virtual tile order as gemm_split.hip: XCD x owns one contiguous 1/8 of the tile sequence (of the (k-slice, tile)
+    // sequence for split-K grids), in which the SHORT grid dimension runs fastest in panels of <= 8 tiles (tiles sharing a
+    // slab of the long operand share an L2)
+    bz = blockIdx.z;
     if (!xcd_order) { bx = blockIdx.x; by = blockIdx.y; return; }
-    const int nb = nbx * nby, per = nb >> 3;
-    const int L = blockIdx.x + nbx * blockIdx.y;
-    const int t = L < 8 * per ? (L & 7) * per + (L >> 3) : L;
+    const int nb = nbx * nby;
+    int t;
+    if (gridDim.z == 1) {
+        const int per = nb >> 3;
+        const int L = blockIdx.x + nbx * blockIdx.y;
+        t = L < 8 * per ? (L & 7) * per + (L >> 3) : L;
+    } else {
+        const int total = nb * (int)gridDim.z, per3 = total >> 3;
+        const int L3 = blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z);
+        const int v = L3 < 8 * per3 ? (L3 & 7) * per3 + (L3 >> 3) : L3;
+        bz = v / nb;
+        t = v - bz * nb;
+    }
     const int ns = min(nbx, nby), nl = max(nbx, nby);
     const int w = min(ns, 8);
     const int p = t / (w * nl), r = t - p * (w * nl);
@@ -441,10 +453,9 @@ __global__ __launch_bounds__(THREADS, WPE) void gemm_f32_kernel(GemmArgs g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by);
+    int bx, by, z;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order != 0, bx, by, z);
     const int m0 = by * BM, n0 = bx * BN;
-    const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;
     const int kt_total = (g.K + KT - 1) / KT;
     const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);

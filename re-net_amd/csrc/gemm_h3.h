@@ -127,10 +127,9 @@ __global__ __launch_bounds__(TALL ? 512 : 256) __attribute__((amdgpu_waves_per_e
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by);
+    int bx, by, z;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by, z);
     const int m0 = by * TBM, n0 = bx * BN;
-    const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;
     const int kt_total = (g.K + BK - 1) / BK;
     const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);

@@ -75,11 +75,27 @@ __device__ __forceinline__ void trace_put(int wave8, int step, int slot, unsigne
 // 1/8 of the tile sequence, and in that sequence the SHORT grid dimension runs fastest, so the tiles that share
 // a slab of the long operand are consecutive on one XCD and the slab is fetched once.  RENET_GEMM_TILE_ORDER=0
 // in the environment restores the plain order (tools/gemm_bench.py).
-__device__ __forceinline__ void tile_of_block(int nbx, int nby, int xcd_order, int& bx, int& by) {
+__device__ __forceinline__ void tile_of_block(int nbx, int nby, int xcd_order, int& bx, int& by, int& bz) {
+    bz = blockIdx.z;
     if (!xcd_order) { bx = blockIdx.x; by = blockIdx.y; return; }
-    const int nb = nbx * nby, per = nb >> 3;
-    const int L = blockIdx.x + nbx * blockIdx.y;
-    const int t = L < 8 * per ? (L & 7) * per + (L >> 3) : L;
+    const int nb = nbx * nby;
+    int t;                                                   // position in the tile sequence of one k-slice
+    if (gridDim.z == 1) {
+        const int per = nb >> 3;
+        const int L = blockIdx.x + nbx * blockIdx.y;
+        t = L < 8 * per ? (L & 7) * per + (L >> 3) : L;
+    } else {
+        // split-K grids (round 4): the dispatcher deals the FLATTENED index (x fastest, then y, then z) to the XCDs, so the
+        // 2-D rule above spreads every k-slice over all eight L2s whenever nbx * nby is not a multiple of 8 -- and even
+        // when it is, each slice's operand slabs are fetched by all XCDs (PMC, tools/pmc_by_shape.py: 600 x 800 x 16000 / 14
+        // read 421 MB for 90 MB of operands, dfeat 2048 x 600 x 23033 / 6 689 MB for 244).  Here XCD x owns one contiguous
+        // eighth of the (k-slice, tile) sequence: whole k-slices, read by one L2 (two where a slice straddles).
+        const int total = nb * (int)gridDim.z, per3 = total >> 3;
+        const int L3 = blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z);
+        const int v = L3 < 8 * per3 ? (L3 & 7) * per3 + (L3 >> 3) : L3;
+        bz = v / nb;
+        t = v - bz * nb;
+    }
     // sequence: panels of <= 8 tiles across the SHORT dimension, the long dimension sweeping each panel
     // (a square problem becomes 8 x 8 blocks of concurrently resident tiles per XCD instead of 2 x 32)
     const int ns = min(nbx, nby), nl = max(nbx, nby);
@@ -407,10 +423,9 @@ __global__ __launch_bounds__(THREADS) void gemm_split_kernel(SplitArgs g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by);
+    int bx, by, z;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by, z);
     const int m0 = by * BM, n0 = bx * BN;
-    const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;
     const int kt_total = (g.K + BK - 1) / BK;
     const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
@@ -482,10 +497,9 @@ __global__ __launch_bounds__(THREADS_T) void gemm_split_tall_kernel(SplitArgs g)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by);
+    int bx, by, z;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by, z);
     const int m0 = by * BMT, n0 = bx * BN;
-    const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;
     const int kt_total = (g.K + BK - 1) / BK;
     const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
@@ -741,10 +755,9 @@ __global__ __launch_bounds__(THREADS) void gemm_split_fused_kernel(SplitArgs g) 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by);
+    int bx, by, z;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by, z);
     const int m0 = by * BM, n0 = bx * BN;
-    const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;
     const int kt_total = (g.K + BK - 1) / BK;
     const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
@@ -834,10 +847,9 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(SplitArgs g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by);
+    int bx, by, z;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by, z);
     const int m0 = by * BM, n0 = bx * BN;
-    const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;
     const int kt_total = (g.K + BK - 1) / BK;
     const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
@@ -979,10 +991,9 @@ __global__ __launch_bounds__(P3_THREADS) void gemm_planes_kernel(PlanesArgs pa) 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by);
+    int bx, by, z;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by, z);
     const int m0 = by * BM, n0 = bx * BN;
-    const int z = blockIdx.z;
     const int kt0 = z * g.k_tiles_per_split;
     const int kt_total = (g.K + BK - 1) / BK;
     const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
@@ -1175,10 +1186,9 @@ __global__ __launch_bounds__(TALL ? 768 : P3_THREADS) void gemm_bf16s_kernel(Bf1
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bx, by;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by);
+    int bx, by, z;
+    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by, z);
     const int m0 = by * TBM, n0 = bx * BN;
-    const int z = blockIdx.z;
     const int st_total = (g.K + B1_BK - 1) / B1_BK;
     const int s0 = z * g.k_tiles_per_split;
     const int s1 = min(st_total, s0 + g.k_tiles_per_split);

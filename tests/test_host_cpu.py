@@ -401,17 +401,25 @@ def test_ctypes_signatures_match_the_header():
         assert (restype is None) == (ret == 'void') and (ret == 'void' or ckind[restype] in (kinds[ret], 'u64'))
 
 
-def _tile_of_block(L, nbx, nby, panel=8):
-    """Python restatement of tile_of_block (csrc/gemm_split.hip): linear dispatch index -> (bx, by)."""
+def _tile_of_block(L, nbx, nby, panel=8, nbz=1):
+    """Python restatement of tile_of_block (csrc/gemm_split.hip): linear dispatch index (x fastest, then y, then z) ->
+    (bx, by) for nbz == 1, (bx, by, bz) for split-K grids."""
     nb = nbx * nby
-    per = nb >> 3
-    t = (L & 7) * per + (L >> 3) if L < 8 * per else L
+    if nbz == 1:
+        per = nb >> 3
+        t = (L & 7) * per + (L >> 3) if L < 8 * per else L
+        bz = 0
+    else:
+        per3 = (nb * nbz) >> 3
+        v = (L & 7) * per3 + (L >> 3) if L < 8 * per3 else L
+        bz, t = divmod(v, nb)
     ns, nl = min(nbx, nby), max(nbx, nby)
     w = min(ns, panel)
     p, r = divmod(t, w * nl)
     wp = min(w, ns - p * w)
     l, sh = r // wp, p * w + r % wp
-    return (l, sh) if nby <= nbx else (sh, l)
+    xy = (l, sh) if nby <= nbx else (sh, l)
+    return xy if nbz == 1 else xy + (bz,)
 
 
 def test_gemm_virtual_tile_order_is_a_bijection():
@@ -420,7 +428,8 @@ def test_gemm_virtual_tile_order_is_a_bijection():
     small ones), and consecutive workgroups of one XCD must share a slab of the long operand."""
     src = open(os.path.join(ROOT, 're-net_amd', 'csrc', 'gemm_split.hip')).read()
     for frag in ('(L & 7) * per + (L >> 3)', 'const int w = min(ns, xcd_order);', 'const int wp = min(w, ns - p * w);',
-                 'const int l = r / wp, sh = p * w + (r - l * wp);'):
+                 'const int l = r / wp, sh = p * w + (r - l * wp);', '(L3 & 7) * per3 + (L3 >> 3)',
+                 'const int L3 = blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z);', 'bz = v / nb;'):
         assert frag in src, 'tile_of_block changed: update the restatement in this test (%s)' % frag
     for nbx in list(range(1, 41)) + [180, 181, 360]:
         for nby in list(range(1, 41)) + [8, 180]:
@@ -431,6 +440,16 @@ def test_gemm_virtual_tile_order_is_a_bijection():
     nbx, nby = 180, 8
     xcd0 = [_tile_of_block(L, nbx, nby) for L in range(0, nbx * nby, 8)]
     assert [t[0] for t in xcd0[:16]] == [0] * 8 + [1] * 8 and [t[1] for t in xcd0[:8]] == list(range(8))
+    # split-K grids: a bijection over (x, y, z), and every XCD (flattened index mod 8) touches as few k-slices as an
+    # eighth of the sequence can: the weight-gradient GEMMs of the bench (5 x 7 x 14, 5 x 2 x 39), dfeat (5 x 8 x 6)
+    for nbx, nby, nbz in [(7, 5, 14), (2, 5, 39), (5, 8, 6), (1, 1, 9), (3, 3, 2), (5, 5, 20), (2, 2, 82), (4, 2, 15)]:
+        n = nbx * nby * nbz
+        seen = {_tile_of_block(L, nbx, nby, 8, nbz) for L in range(n)}
+        assert len(seen) == n and all(0 <= x < nbx and 0 <= y < nby and 0 <= z < nbz for x, y, z in seen), (nbx, nby, nbz)
+        for xcd in range(8):
+            zs = {_tile_of_block(L, nbx, nby, 8, nbz)[2] for L in range(xcd, n, 8)}
+            # a contiguous eighth may straddle one slice boundary more, and the last (n % 8) blocks keep their own index
+            assert len(zs) <= -(-nbz // 8) + 2, (nbx, nby, nbz, xcd, sorted(zs))
 
 
 def test_split_k_cost_model():
