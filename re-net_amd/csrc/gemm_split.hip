@@ -1463,6 +1463,29 @@ int tile_order() {
     return v;
 }
 
+// Panel width for an UN-SPLIT grid that takes several rounds of tiles per XCD.  The short operand is swept once per round
+// by every XCD; when all of it (ns tiles) does not fit the 4 MB L2 next to the streamed long operand, that cyclic sweep
+// misses (PMC, tools/pmc_by_shape.py: the 256-row logits GEMM fetched 313 MB for 60 MB of operands, 258 MB of it the
+// 4.9 MB `feat`).  Narrower panels keep one panel of the short operand resident (<= 2.5 MB) and re-read the long operand
+// once per extra panel: taken when that costs less than the sweep does (so NOT for dW = dlogits^T feat, whose long
+// operand is 189 MB).  An explicit RENET_GEMM_TILE_ORDER, or a split k range, leaves the width alone.
+int panel_width(int base, int nbx, int nby, int tile_m, int K, int split_k, int slots_per_xcd) {
+    if (base != 8 || split_k != 1 || getenv("RENET_GEMM_TILE_ORDER")) return base;
+    const bool short_is_m = nby <= nbx;
+    const int ns = short_is_m ? nby : nbx, nl = short_is_m ? nbx : nby;
+    const double slab = (double)(short_is_m ? tile_m : BN) * K * 4.0;           // short-operand bytes of one tile row / column
+    const double long_total = (double)(short_is_m ? BN : tile_m) * K * 4.0 * nl;
+    const double short_total = slab * ns;
+    const double rounds = (double)nbx * nby / (8.0 * slots_per_xcd);
+    if (short_total <= 3.0e6 || rounds <= 1.0) return base;
+    const int w = max(1, min(8, (int)(2.5e6 / slab)));
+    const int w0 = min(ns, 8);
+    if (w >= w0) return base;
+    const int extra_panels = (ns + w - 1) / w - (ns + w0 - 1) / w0;
+    if (long_total * extra_panels >= short_total * rounds * 8.0) return base;
+    return w;
+}
+
 template <bool TA, bool TB>
 int launch_fused(const SplitArgs& g, dim3 grid, hipStream_t st) {
     static bool attr_set = false;      // benign race: the attribute is idempotent
@@ -1651,6 +1674,7 @@ static int gemm_planes_launch(bool bf16_mode, int ta, int tb, int M, int N, int 
         else RENET_LAUNCH((gemm_bf16_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
     } else if (use_tall(ta, M, nbx, split_k)) {
         dim3 grid(nbx, (M + BMT - 1) / BMT, split_k);
+        g.xcd_order = panel_width(g.xcd_order, nbx, (int)grid.y, BMT, K, split_k, 32);
 #define RENET_TALL_LAUNCH(RAWV)                                                     \
         do {                                                                        \
             if (!ta && !tb) e = launch_tall<false, false, RAWV>(g, grid, st);       \
@@ -1663,6 +1687,7 @@ static int gemm_planes_launch(bool bf16_mode, int ta, int tb, int M, int N, int 
 #undef RENET_TALL_LAUNCH
     } else {
         dim3 grid(nbx, nby, split_k);
+        g.xcd_order = panel_width(g.xcd_order, nbx, nby, BM, K, split_k, 64);
 #define RENET_SPLIT_LAUNCH(RAWV)                                                                                    \
         do {                                                                                                        \
             if (!ta && !tb) RENET_LAUNCH((gemm_split_kernel<false, false, RAWV>), grid, dim3(THREADS), 0, st, g);   \
@@ -1773,9 +1798,11 @@ int renet_gemm_f32_h3(int ta, int tb, int M, int N, int K, float alpha, const fl
     } while (0)
     if (use_tall_h3(ta, M, nbx, split_k)) {
         dim3 grid(nbx, (M + 255) / 256, split_k);
+        g.xcd_order = panel_width(g.xcd_order, nbx, (int)grid.y, 256, K, split_k, 32);
         RENET_H3_LAUNCH(true, 512);
     } else {
         dim3 grid(nbx, (M + BM - 1) / BM, split_k);
+        g.xcd_order = panel_width(g.xcd_order, nbx, (int)grid.y, BM, K, split_k, 64);
         RENET_H3_LAUNCH(false, 256);
     }
 #undef RENET_H3_LAUNCH

@@ -433,7 +433,8 @@ def test_gemm_virtual_tile_order_is_a_bijection():
         assert frag in src, 'tile_of_block changed: update the restatement in this test (%s)' % frag
     for nbx in list(range(1, 41)) + [180, 181, 360]:
         for nby in list(range(1, 41)) + [8, 180]:
-            for panel in ((8,) if nbx > 24 or nby > 24 else (1, 2, 3, 4, 8, 16)):      # (round 4: the panel width is a knob)
+            for panel in ((8, 4, 2) if nbx > 24 or nby > 24 else (1, 2, 3, 4, 8, 16)):   # (round 4: the panel width is a knob,
+                                                                                       # chosen per shape by panel_width())
                 seen = {_tile_of_block(L, nbx, nby, panel) for L in range(nbx * nby)}
                 assert len(seen) == nbx * nby and all(0 <= x < nbx and 0 <= y < nby for x, y in seen), (nbx, nby, panel)
     # logits GEMM of the bench (8 x 180 tiles): the 8 row tiles of one column tile are consecutive on one XCD
