@@ -200,6 +200,19 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
                          const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                          int split_k, float* workspace, size_t workspace_bytes, void* stream);
 
+/* What renet_gemm_f32_split launches for a problem -- the launcher executes exactly this plan (csrc/gemm_split.hip,
+ * plan_split); pure host logic, callable without a GPU.  A / B may be NULL (only their 16-byte alignment is looked at,
+ * for the weight-resident kernel).  plan[8] (host ints):
+ *   [0] kernel: 0 fused k-loop (one workgroup per CU; grids of <= 256 tiles), 1 two-phase 128 x 128 tiles, 2 two-phase
+ *       256 x 128 tiles, 3 weight-resident kernel (N <= 256, K <= 208, gemm_skinny.hip)
+ *   [1] two-phase kernels: 1 = operands through raw buffer descriptors (both reach < 2^30 elements), 0 = 64-bit loader
+ *   [2] tile order: 0 plain (blockIdx.x, blockIdx.y); w >= 1: XCD-aware order with panels of <= w tiles (8 by default,
+ *       narrowed per shape for un-split grids whose short operand does not fit an L2; split-K grids map whole k-slices to
+ *       one XCD)
+ *   [3..5] grid (x = column tiles, y = row tiles, z = k-slices)   [6] the split factor after clamping   [7] 0 */
+int renet_gemm_split_plan(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                          int split_k, int* plan);
+
 /* Same contract as renet_gemm_f32 on the f16 matrix cores ("f16x3", csrc/gemm_h3.h): every operand value, scaled by
  * a power of two of its tensor so that max |x| lands in [2^14, 2^15), is split into two binary16 terms
  * x s = h1 + 2^-11 h2 (22 significant bits) and a b is evaluated as a1 b1 + 2^-11 (a1 b2 + a2 b1) with fp32

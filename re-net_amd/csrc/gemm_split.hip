@@ -1628,53 +1628,88 @@ static bool split_raw_enabled() {
     return v != 0;
 }
 
+// What the bf16x6 / bf16 launcher does for a problem: ONE function decides, the launcher executes it and
+// renet_gemm_split_plan reports it (host logic only -- testable without a GPU).
+struct SplitPlan {
+    int kernel;            // 0 fused (one workgroup per CU), 1 two-phase 128 x 128, 2 two-phase 256 x 128, 3 weight-resident
+                           // (gemm_skinny.hip), 4 single-plane bf16 (renet_gemm_bf16)
+    int raw;               // two-phase kernels: operands through raw buffer descriptors
+    int xcd_order;         // 0 plain tile order, w: XCD-aware order with panels of <= w tiles
+    int gx, gy, gz;        // grid
+    int split_k;           // clamped split
+};
+
+static SplitPlan plan_split(bool bf16_mode, int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B,
+                            int ldb, int split_k) {
+    SplitPlan p;
+    const int kt_total = (K + BK - 1) / BK;
+    if (split_k < 1) split_k = 1;
+    if (split_k > kt_total) split_k = max(kt_total, 1);
+    p.split_k = split_k;
+    p.raw = 0;
+    p.xcd_order = tile_order();
+    const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
+    p.gx = nbx; p.gy = nby; p.gz = split_k;
+    // tall activation x small weight (K <= 208, N <= 256): the weight-resident kernel of gemm_skinny.hip
+    // (RENET_GEMM_SKINNY=0 in the environment keeps the general kernels, for A/B runs)
+    if (!bf16_mode && split_k == 1 && skinny_enabled() && renet_gemm_skinny_eligible(ta, M, N, K, A, lda, B, ldb, tb)) {
+        p.kernel = 3;
+        return p;
+    }
+    const int ntiles = nbx * nby * split_k;
+    int choice = bf16_mode ? 2 : kernel_choice(ntiles);
+    // the fused kernel addresses with 32-bit element offsets and float4 loads along a contiguous K
+    if (choice == 0 && (K < 4 || (size_t)(ta ? K : M) * lda >= (1u << 31) || (size_t)(tb ? N : K) * ldb >= (1u << 31)))
+        choice = 1;
+    if (choice == 0) { p.kernel = 0; return p; }
+    if (choice == 2) { p.kernel = 4; return p; }
+    // two-phase kernels: raw buffer descriptors (32-bit byte offsets) while both operands reach less than 2^30 elements
+    // (RENET_GEMM_SPLIT_RAW=0: the generic 64-bit loader, for A/B runs)
+    p.raw = split_raw_enabled() && (size_t)(ta ? K : M) * lda < ((size_t)1 << 30) &&
+            (size_t)(tb ? N : K) * ldb < ((size_t)1 << 30);
+    if (use_tall(ta, M, nbx, split_k)) {
+        p.kernel = 2;
+        p.gy = (M + BMT - 1) / BMT;
+        p.xcd_order = panel_width(p.xcd_order, nbx, p.gy, BMT, K, split_k, 32);
+    } else {
+        p.kernel = 1;
+        p.xcd_order = panel_width(p.xcd_order, nbx, nby, BM, K, split_k, 64);
+    }
+    return p;
+}
+
 static int gemm_planes_launch(bool bf16_mode, int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
                               const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                               int split_k, float* workspace, size_t workspace_bytes, void* stream) {
     if (M < 0 || N < 0 || K < 1 || lda <= 0 || ldb <= 0 || ldc < N) return RENET_ERR_BADARG;
     if (M == 0 || N == 0) return RENET_OK;
-    if (split_k < 1) split_k = 1;
+    const SplitPlan p = plan_split(bf16_mode, ta, tb, M, N, K, A, lda, B, ldb, split_k);
+    split_k = p.split_k;
     const int kt_total = (K + BK - 1) / BK;
-    if (split_k > kt_total) split_k = max(kt_total, 1);
     if (split_k > 1 && workspace_bytes < renet_gemm_workspace(M, N, split_k)) return RENET_ERR_WORKSPACE;
-    // tall activation x small weight (K <= 208, N <= 256): the weight-resident kernel of gemm_skinny.hip
-    // (RENET_GEMM_SKINNY=0 in the environment keeps the general kernels, for A/B runs)
-    if (!bf16_mode && split_k == 1 && skinny_enabled() && renet_gemm_skinny_eligible(ta, M, N, K, A, lda, B, ldb, tb))
-        return renet_gemm_skinny_launch(tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, stream);
+    if (p.kernel == 3) return renet_gemm_skinny_launch(tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, stream);
     SplitArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha; g.beta = beta;
     g.split_k = split_k;
     g.k_tiles_per_split = max(1, (kt_total + split_k - 1) / split_k);
     g.partial = workspace;
-    g.xcd_order = tile_order();
+    g.xcd_order = p.xcd_order;
     hipStream_t st = (hipStream_t)stream;
-    const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
-    const int ntiles = nbx * nby * split_k;
-    int choice = bf16_mode ? 2 : kernel_choice(ntiles);
-    // the fused kernel addresses with 32-bit element offsets and float4 loads along a contiguous K
-    if (choice == 0 && (K < 4 || (size_t)(ta ? K : M) * lda >= (1u << 31) || (size_t)(tb ? N : K) * ldb >= (1u << 31)))
-        choice = 1;
-    // two-phase kernels: raw buffer descriptors (32-bit byte offsets) while both operands reach less than 2^30 elements
-    // (RENET_GEMM_SPLIT_RAW=0: the generic 64-bit loader, for A/B runs)
-    const bool raw = split_raw_enabled() && (size_t)(ta ? K : M) * lda < ((size_t)1 << 30) &&
-                     (size_t)(tb ? N : K) * ldb < ((size_t)1 << 30);
+    const dim3 grid(p.gx, p.gy, p.gz);
+    const bool raw = p.raw != 0;
     int e = RENET_OK;
-    if (choice == 0) {
-        dim3 grid(nbx, nby, split_k);
+    if (p.kernel == 0) {
         if (!ta && !tb) e = launch_fused<false, false>(g, grid, st);
         else if (!ta && tb) e = launch_fused<false, true>(g, grid, st);
         else if (ta && !tb) e = launch_fused<true, false>(g, grid, st);
         else e = launch_fused<true, true>(g, grid, st);
-    } else if (choice == 2) {
-        dim3 grid(nbx, nby, split_k);
+    } else if (p.kernel == 4) {
         if (!ta && !tb) RENET_LAUNCH((gemm_bf16_kernel<false, false>), grid, dim3(THREADS), 0, st, g);
         else if (!ta && tb) RENET_LAUNCH((gemm_bf16_kernel<false, true>), grid, dim3(THREADS), 0, st, g);
         else if (ta && !tb) RENET_LAUNCH((gemm_bf16_kernel<true, false>), grid, dim3(THREADS), 0, st, g);
         else RENET_LAUNCH((gemm_bf16_kernel<true, true>), grid, dim3(THREADS), 0, st, g);
-    } else if (use_tall(ta, M, nbx, split_k)) {
-        dim3 grid(nbx, (M + BMT - 1) / BMT, split_k);
-        g.xcd_order = panel_width(g.xcd_order, nbx, (int)grid.y, BMT, K, split_k, 32);
+    } else if (p.kernel == 2) {
 #define RENET_TALL_LAUNCH(RAWV)                                                     \
         do {                                                                        \
             if (!ta && !tb) e = launch_tall<false, false, RAWV>(g, grid, st);       \
@@ -1686,8 +1721,6 @@ static int gemm_planes_launch(bool bf16_mode, int ta, int tb, int M, int N, int 
         else RENET_TALL_LAUNCH(false);
 #undef RENET_TALL_LAUNCH
     } else {
-        dim3 grid(nbx, nby, split_k);
-        g.xcd_order = panel_width(g.xcd_order, nbx, nby, BM, K, split_k, 64);
 #define RENET_SPLIT_LAUNCH(RAWV)                                                                                    \
         do {                                                                                                        \
             if (!ta && !tb) RENET_LAUNCH((gemm_split_kernel<false, false, RAWV>), grid, dim3(THREADS), 0, st, g);   \
@@ -1722,6 +1755,16 @@ int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const
                          int split_k, float* workspace, size_t workspace_bytes, void* stream) {
     return gemm_planes_launch(false, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, split_k, workspace,
                               workspace_bytes, stream);
+}
+
+int renet_gemm_split_plan(int ta, int tb, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                          int split_k, int* plan) {
+    if (!plan || M < 1 || N < 1 || K < 1 || lda <= 0 || ldb <= 0) return RENET_ERR_BADARG;
+    const SplitPlan p = plan_split(false, ta, tb, M, N, K, A, lda, B, ldb, split_k);
+    plan[0] = p.kernel; plan[1] = p.raw; plan[2] = p.xcd_order; plan[3] = p.gx; plan[4] = p.gy; plan[5] = p.gz;
+    plan[6] = p.split_k;
+    plan[7] = 0;
+    return RENET_OK;
 }
 
 int renet_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,

@@ -63,6 +63,7 @@ _SIGNATURES = {
                                      c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'renet_gemm_bf16': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                 c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    'renet_gemm_split_plan': (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     'renet_planes_bytes': (c_size_t, [c_int, c_int]),
     'renet_maxabs_blocks': (c_int, [c_int, c_int, c_int]),
     'renet_maxabs_partials_multi': (c_int, [c_void_p, c_int, c_void_p]),
@@ -494,6 +495,21 @@ def _ld(t):
     if t.dim() != 2 or t.stride(1) != 1:
         raise RenetHipError('GEMM operands must be 2-D with unit inner stride')
     return t.stride(0)
+
+
+def gemm_split_plan(ta, tb, m, n, k, lda=None, ldb=None, split_k=1, a_ptr=0, b_ptr=0):
+    """What renet_gemm_f32_split would launch for this problem (host logic only, no GPU needed): dict with `kernel`
+    ('fused' | 'two_phase_128' | 'two_phase_256' | 'weight_resident'), `raw` (raw-buffer loader), `xcd_order` (0 = plain
+    tile order, w = XCD-aware order with panels of <= w tiles), `grid`, `split_k`."""
+    import ctypes
+    lda = (m if ta else k) if lda is None else lda
+    ldb = (k if tb else n) if ldb is None else ldb
+    out = (ctypes.c_int * 8)()
+    _check(lib().renet_gemm_split_plan(int(ta), int(tb), m, n, k, a_ptr, lda, b_ptr, ldb, split_k,
+                                       ctypes.cast(out, ctypes.c_void_p)), 'renet_gemm_split_plan')
+    names = {0: 'fused', 1: 'two_phase_128', 2: 'two_phase_256', 3: 'weight_resident', 4: 'bf16'}
+    return {'kernel': names[out[0]], 'raw': bool(out[1]), 'xcd_order': out[2], 'grid': (out[3], out[4], out[5]),
+            'split_k': out[6]}
 
 
 def auto_split_k(m, n, k):

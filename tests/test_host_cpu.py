@@ -453,6 +453,35 @@ def test_gemm_virtual_tile_order_is_a_bijection():
             assert len(zs) <= -(-nbz // 8) + 2, (nbx, nby, nbz, xcd, sorted(zs))
 
 
+def test_gemm_dispatch_plan_of_the_bench_shapes():
+    """renet_gemm_split_plan: the launcher's own decision function (csrc/gemm_split.hip plan_split), queried without a GPU.
+    Pins what DESIGN / profiles say the step's GEMMs run on: kernel family, loader, tile order, grid."""
+    import renet_hip as K
+    if os.environ.get('RENET_GEMM_TILE_ORDER') or os.environ.get('RENET_GEMM_TALL') or os.environ.get('RENET_GEMM_KERNEL'):
+        pytest.skip('dispatch knobs set in the environment')
+    S = 15439
+    logits = K.gemm_split_plan(0, 1, 2048, 23033, 600)
+    assert logits == {'kernel': 'two_phase_256', 'raw': True, 'xcd_order': 4, 'grid': (180, 8, 1), 'split_k': 1}
+    dfeat = K.gemm_split_plan(0, 0, 2048, 600, 23033, split_k=6)
+    assert dfeat['kernel'] == 'two_phase_256' and dfeat['grid'] == (5, 8, 6) and dfeat['xcd_order'] == 8
+    dw = K.gemm_split_plan(1, 0, 23033, 600, 2048)              # long operand 189 MB: panels stay 8 wide
+    assert dw['kernel'] == 'two_phase_128' and dw['grid'] == (5, 180, 1) and dw['xcd_order'] == 8 and dw['raw']
+    proj = K.gemm_split_plan(0, 1, S, 600, 800)                 # 2 MB short operand: fits an L2, no narrowing
+    assert proj['kernel'] == 'two_phase_128' and proj['xcd_order'] == 8 and proj['grid'] == (5, 121, 1)
+    dwih = K.gemm_split_plan(1, 0, 600, 800, S, split_k=14)
+    assert dwih['kernel'] == 'two_phase_128' and dwih['grid'] == (7, 5, 14)
+    assert K.gemm_split_plan(0, 1, 23033, 200, 200)['kernel'] == 'weight_resident'
+    assert K.gemm_split_plan(0, 0, 2048, 400, 256)['kernel'] == 'fused'                     # <= 256 tiles
+    assert K.gemm_split_plan(1, 0, 256, 400, 2048, split_k=15)['kernel'] == 'fused'
+    assert K.gemm_split_plan(0, 1, 4096, 4096, 4096)['xcd_order'] == 8                      # 67 MB short operand: re-reading
+    # the long one per extra panel would cost more than the sweep
+    big = K.gemm_split_plan(0, 1, 1 << 20, 600, 2048)           # A reaches 2^31 elements: 64-bit loader
+    assert big['raw'] is False and big['kernel'] in ('two_phase_128', 'two_phase_256')
+    assert K.gemm_split_plan(0, 1, 300, 300, 64, split_k=9)['split_k'] == 2                 # clamped to the k-tiles
+    with pytest.raises(K.RenetHipError):
+        K.gemm_split_plan(0, 0, 0, 5, 5)
+
+
 def test_split_k_cost_model():
     import renet_hip as K
     assert K.auto_split_k(1024, 23033, 600) == 1 and K.auto_split_k(23033, 600, 1024) == 1     # full grids
