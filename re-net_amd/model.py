@@ -119,6 +119,12 @@ class RENet(nn.Module):
         # inference advance: one history per sampled entity, relation segment of the GRU input broadcast (see
         # _joint_topk_many); False builds the R-fold batches of rounds 1-3 (A/B runs, tests)
         self.broadcast_relations = os.environ.get('RENET_ADVANCE_BROADCAST', '1') != '0'
+        # inference advance: score the (entity, relation) rows in blocks of descending upper bound p_r * prob and stop at the
+        # first row that cannot reach the top num_k any more (_winners_pruned: exact, same winners).  Opt-in this round
+        # (RENET_ADVANCE_PRUNE=1): the arithmetic is covered on CPU (tests/test_host_cpu.py), the config-scale GPU test and
+        # the timing are next round's first session.
+        self.prune_relations = os.environ.get('RENET_ADVANCE_PRUNE', '0') == '1'
+        self.last_prune = None
         self.shadow_pick = None
         self._shadow = {}
 
@@ -577,12 +583,15 @@ def _advance_side(self, picks, prob, subject):
     """model.py:229-258 (subjects) / 266-297 (objects): rank (r, o) continuations of every sampled entity,
     keep the globally best num_k and write them into the prediction caches."""
     picks_np = picks.detach().cpu().numpy().astype(np.int64)
+    if self.prune_relations and not self.reference_shadowing and \
+            getattr(self.update_cache, '__func__', None) is _update_cache:
+        win_ent, codes_np = self._winners_pruned(picks_np, prob, subject)
+        self._shadow['s' if subject else 'o'] = int(win_ent[-1])          # (read under reference_shadowing only)
+        return self._apply_winners(win_ent, codes_np, subject)
     uniq = np.unique(picks_np)                           # identical entities give identical results: compute once
     per_ent = self._joint_topk_many(uniq, prob, subject=subject)
     all_vals = torch.cat([per_ent[int(e)][0] for e in picks_np])          # sample order, duplicates included
     _, best = torch.topk(all_vals, self.num_k, sorted=False)
-    cache, cache_t = (self.s_his_cache, self.s_his_cache_t) if subject else (self.o_his_cache, self.o_his_cache_t)
-    now = _as_int(self.latest_time)
     best_np = best.cpu().numpy()
     cands = [int(picks_np[c // self.num_k]) for c in best_np]          # model.py:254-255: s = s_to_id[idx.item()]
     side = 's' if subject else 'o'
@@ -592,6 +601,13 @@ def _advance_side(self, picks, prob, subject):
     codes = torch.stack([per_ent[int(e)][1] for e in uniq])                # [n_uniq, num_k]
     rows = torch.from_numpy(np.searchsorted(uniq, win_ent)).to(codes.device)
     codes_np = codes[rows, torch.from_numpy(best_np % self.num_k).to(codes.device)].cpu().numpy().astype(np.int64)
+    self._apply_winners(win_ent, codes_np, subject)
+
+
+def _apply_winners(self, win_ent, codes_np, subject):
+    """model.py:254-258: the winners (entity, code = r * N_ent + other entity) go into the prediction caches."""
+    cache, cache_t = (self.s_his_cache, self.s_his_cache_t) if subject else (self.o_his_cache, self.o_his_cache_t)
+    now = _as_int(self.latest_time)
     touched = self._touched_sets()[0 if subject else 1]
     if getattr(self.update_cache, '__func__', None) is not _update_cache:
         # update_cache was overridden: one call per winner, as the reference does (model.py:254-258)
@@ -608,6 +624,121 @@ def _advance_side(self, picks, prob, subject):
         cache[e] = _bulk_update_cache(cache[e], pairs)
         cache_t[e] = now
         touched.add(e)
+
+
+def _scaled_softmax_topk(logits, scale, k):
+    """top-k of softmax(logits, dim 1) * scale[:, None] over the WHOLE block -> (values [k], flat indices [k]).  The block is
+    overwritten on the GPU (fused joint-softmax with one "relation" per row, then the radix select over the block as one row)."""
+    rows, n = logits.shape
+    if logits.is_cuda and n * 4 <= 128 * 1024 and os.environ.get('RENET_TOPK') != 'torch':
+        K.joint_softmax(logits, 1, torch.zeros(rows, 1, device=logits.device), scale.contiguous())
+        vals, idx = K.topk_positive(logits.view(1, rows * n), k)
+        return vals[0], idx[0]
+    joint = torch.softmax(logits, dim=1) * scale.view(rows, 1)
+    return torch.topk(joint.view(-1), k, sorted=False)
+
+
+def _winners_pruned(self, picks_np, prob, subject):
+    """The winners of _advance_side WITHOUT scoring every (entity, relation) row (RENet.prune_relations; exact).
+    Every candidate of row (e, r) is  softmax_o(...) * p_r[e, r] * prob[e]  <=  bound[e, r] = p_r[e, r] * prob[e],  and the
+    bound needs no relation-specific work (p_r comes from encoder_r, one sequence per entity).  Rows are scored in blocks of
+    DESCENDING bound; after each block the num_k-th largest candidate found so far is a lower bound of the final
+    threshold (the reference takes the top num_k of the candidate multiset in which an entity sampled m times counts m
+    times: its num_k-th largest value is >= the num_k-th largest DISTINCT candidate), so scoring stops at the first row whose
+    bound lies below it -- no candidate of an unscored row can be among the winners.  Per block: GRU over the block's
+    (entity, relation) sequences (input projection = entity part + relation part, as in the broadcast path), ONE
+    [rows, 3h] x [3h, N_ent] GEMM, fused softmax * bound, radix-select top-k over the block.  Returns (entity of every
+    winner [num_k], code = r * N_ent + other entity [num_k]), multiplicities expanded."""
+    R, dev, H, N = self.num_rels, self.ent_embeds.device, self.h_dim, self.in_dim
+    if subject:
+        hist_all, hist_t_all, rel_embeds, reverse = self.s_hist_test, self.s_hist_test_t, self.rel_embeds[:R], False
+    else:
+        hist_all, hist_t_all, rel_embeds, reverse = self.o_hist_test, self.o_hist_test_t, self.rel_embeds[R:], True
+    uniq, counts = np.unique(picks_np, return_counts=True)
+    n = len(uniq)
+    with G.async_uploads():
+        # ---- everything that does not depend on the relation, for ALL sampled entities in one batch ----
+        have = np.asarray([i for i, e in enumerate(uniq) if len(hist_all[e]) != 0], dtype=np.int64)
+        s_q = torch.zeros(n, H, device=dev)
+        pos_of = np.full(n, -1, dtype=np.int64)            # entity index -> position in the length-sorted batch
+        if len(have):
+            ents_h = uniq[have]
+            px, pxr = self.aggregator.forward_grouped(([hist_all[e] for e in ents_h], [hist_t_all[e] for e in ents_h]),
+                                                      ents_h, np.zeros(len(have), dtype=np.int64), self.ent_embeds,
+                                                      rel_embeds, self.graph_dict, self.global_emb, reverse, ents_h)
+            nh = len(have)
+            x = px.data                                                              # [S, 4H] packed, time-major
+            w_ih, b_ih = self.encoder.weight_ih_l0, self.encoder.bias_ih_l0
+            p_base = K.gemm(x[:, :2 * H], w_ih[:, :2 * H], tb=True, bias=b_ih)        # [h2 | ent] part + bias
+            K.gemm(x[:, 3 * H:], w_ih[:, 3 * H:], tb=True, out=p_base, beta=1.0)      # + glob part
+            q_rel = K.gemm(rel_embeds.contiguous(), w_ih[:, 2 * H:3 * H], tb=True)    # [R, 3H]
+            bs = px.batch_sizes.numpy().astype(np.int64)
+            step_off = np.concatenate(([0], np.cumsum(bs)))
+            lens_sorted = (bs[:, None] > np.arange(nh)[None, :]).sum(axis=0)          # steps of sorted position s
+            _, qq = self.encoder_r(pxr, total_rows=nh)
+            perm = np.asarray(self.aggregator.last_batch.host.perm, dtype=np.int64)   # sorted position -> sequence
+            pos_of[have[perm]] = np.arange(nh)
+            s_q[G.h2d(have[perm], dev)] = qq[0]
+        es_t = G.h2d(uniq, dev)
+        ent_rows = self.ent_embeds[es_t]                                              # [n, H]
+        logits_r = _linear_eval(self.linear_r, torch.cat((ent_rows, s_q), dim=1))    # [n, R]
+        bound = (torch.softmax(logits_r, dim=1) * prob[es_t].view(n, 1)).reshape(-1)  # [n * R]
+        bound_sorted, order = torch.sort(bound, descending=True)
+        order_np, bound_np = order.cpu().numpy(), bound_sorted.cpu().numpy()
+        block = max(1, (1 << int(os.environ.get('RENET_ADVANCE_BLOCK_LOG2', '28'))) // max(N, 1))
+        w_hh, b_hh = self.encoder.weight_hh_l0.contiguous(), self.encoder.bias_hh_l0.contiguous()
+        vals_all, rows_all, obj_all = [], [], []
+        tau, pos, total = 0.0, 0, n * R
+        self.last_prune = {'rows': total, 'scored': 0, 'blocks': 0}
+        while pos < total:
+            if tau > 0.0 and float(bound_np[pos]) * (1.0 + 1e-4) < tau:
+                break                       # (the factor: the bound and the candidates round p_r * prob differently)
+            blk = order_np[pos:pos + block]
+            pos += len(blk)
+            e_idx, r_idx = blk // R, blk % R
+            m = len(blk)
+            hh_rows = torch.zeros(m, H, device=dev)
+            sp = pos_of[e_idx]
+            sel = np.nonzero(sp >= 0)[0]
+            if len(sel):
+                # the block's sequences, ordered by (position of the entity in the sorted batch, relation): lengths descend
+                o2 = sel[np.lexsort((r_idx[sel], sp[sel]))]
+                sp_s, rr_s = sp[o2], r_idx[o2]
+                ln = lens_sorted[sp_s]
+                k_t = [int(np.count_nonzero(ln > t)) for t in range(int(ln[0]))]
+                idx_rows = np.concatenate([step_off[t] + sp_s[:k] for t, k in enumerate(k_t)])
+                idx_rel = np.concatenate([rr_s[:k] for k in k_t])
+                gi = p_base[G.h2d(idx_rows, dev)] + q_rel[G.h2d(idx_rel, dev)]
+                off = ops.host_offsets(np.concatenate(([0], np.cumsum(k_t))))
+                hh, _ = K.gru_fwd(gi, off, H, w_hh, b_hh, out_rows=len(o2))
+                hh_rows[G.h2d(o2, dev)] = hh
+            e_dev, r_dev = G.h2d(e_idx, dev), G.h2d(r_idx, dev)
+            feat = torch.cat((ent_rows[e_dev], hh_rows, rel_embeds[r_dev]), dim=1)
+            logits = _linear_eval(self.linear, feat)                                  # [m, N_ent]
+            k = min(self.num_k, m * N)
+            vals, idx = _scaled_softmax_topk(logits, bound[G.h2d(blk, dev)], k)
+            vals_all.append(vals)
+            rows_all.append(G.h2d(blk, dev)[torch.div(idx, N, rounding_mode='floor')])
+            obj_all.append(idx % N)
+            self.last_prune['scored'] += m
+            self.last_prune['blocks'] += 1
+            if pos < total:
+                seen = torch.cat(vals_all)
+                if seen.numel() >= self.num_k:
+                    tau = float(torch.topk(seen, self.num_k, sorted=False)[0].min())
+        vals_np = torch.cat(vals_all).cpu().numpy()
+        rows_np = torch.cat(rows_all).cpu().numpy().astype(np.int64)
+        obj_np = torch.cat(obj_all).cpu().numpy().astype(np.int64)
+    # the top num_k of the multiset: distinct candidates by descending value, each counted as often as its entity was sampled
+    by_val = np.argsort(-vals_np, kind='stable')
+    mult = counts[rows_np[by_val] // R]
+    last = int(np.searchsorted(np.cumsum(mult), self.num_k))          # first position where the running count reaches num_k
+    take = by_val[:last + 1]
+    mult = mult[:last + 1].copy()
+    mult[-1] -= int(mult.sum()) - self.num_k                           # the last one may enter with fewer copies
+    win_ent = np.repeat(uniq[rows_np[take] // R], mult)
+    codes = np.repeat((rows_np[take] % R) * N + obj_np[take], mult)
+    return win_ent, codes
 
 
 def _bulk_update_cache(cache_e, pairs):
@@ -876,6 +1007,8 @@ RENet.pred_r_rank2 = _moded(_pred_r_rank2)
 RENet.sample_entities = _sample
 RENet._joint_topk_many = _moded(_joint_topk_many)
 RENet._advance_side = _advance_side
+RENet._apply_winners = _apply_winners
+RENet._winners_pruned = _moded(_winners_pruned)
 RENet._roll_histories = _roll_histories
 RENet._touched_sets = _touched_sets
 RENet._cached_facts = _cached_facts

@@ -359,6 +359,8 @@ def test_inference_at_config_scale_matches_reference(dev, shadowing):
     b = set(map(tuple, gold['new_graph_quads'].tolist()))
     diff = len(a ^ b)
     print('predicted facts: mine %d, reference %d, symmetric difference %d' % (len(a), len(b), diff))
+    if getattr(net, 'last_prune', None):
+        print('pruned advance (RENET_ADVANCE_PRUNE=1), last side:', net.last_prune)
     assert diff <= 2, (len(a), len(b), diff)          # observed on MI355X (rounds 3-4, every GEMM mode): 0 of 3781
     first_of_t = np.nonzero(np.diff(case['valid'][eval_idx, 3]) != 0)[0] + 1
     keep = np.ones(len(eval_idx), dtype=bool)
