@@ -735,7 +735,8 @@ def _winners_pruned(self, picks_np, prob, subject):
     last = int(np.searchsorted(np.cumsum(mult), self.num_k))          # first position where the running count reaches num_k
     take = by_val[:last + 1]
     mult = mult[:last + 1].copy()
-    mult[-1] -= int(mult.sum()) - self.num_k                           # the last one may enter with fewer copies
+    if int(mult.sum()) > self.num_k:
+        mult[-1] -= int(mult.sum()) - self.num_k                       # the last one may enter with fewer copies
     win_ent = np.repeat(uniq[rows_np[take] // R], mult)
     codes = np.repeat((rows_np[take] % R) * N + obj_np[take], mult)
     return win_ent, codes
