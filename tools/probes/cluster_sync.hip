@@ -10,9 +10,20 @@
 #include <cstdio>
 #include <cstdlib>
 
+// same_xcd: the members of a cluster are workgroups with EQUAL index mod 8 (the dispatcher deals workgroup b to XCD b % 8), so
+// flags and state stay within one L2; otherwise consecutive workgroups = G different XCDs (coherence through the fabric).
 __global__ __launch_bounds__(256) void k(int G, int steps, int work, int words, unsigned* flags, float* state,
-                                         long long* cyc, float* sink, int sync_on) {
-    const int wg = blockIdx.x, cluster = wg / G, member = wg - cluster * G;
+                                         long long* cyc, float* sink, int sync_on, int same_xcd) {
+    const int wg = blockIdx.x;
+    int cluster, member;
+    if (same_xcd) {
+        const int x = wg & 7, local = wg >> 3;                 // position within the XCD
+        cluster = x * 64 + local / G;
+        member = local - (local / G) * G;
+    } else {
+        cluster = wg / G;
+        member = wg - cluster * G;
+    }
     unsigned* f = flags + cluster * 64;                       // one 256-byte line group per cluster
     float* st = state + (size_t)cluster * G * words;
     float acc = threadIdx.x * 1e-3f;
@@ -44,19 +55,24 @@ __global__ __launch_bounds__(256) void k(int G, int steps, int work, int words, 
 int main() {
     const int steps = 2000, work = 500;
     unsigned* flags; float *state, *sink; long long* cyc;
-    hipMalloc(&flags, 256 * 64 * sizeof(unsigned));
-    hipMalloc(&state, (size_t)256 * 8 * 4096 * sizeof(float));
+    hipMalloc(&flags, 512 * 64 * sizeof(unsigned));
+    hipMalloc(&state, (size_t)512 * 8 * 4096 * sizeof(float));
     hipMalloc(&sink, 256 * 256 * sizeof(float));
     hipMallocManaged(&cyc, 64);
-    for (int G : {1, 2, 5}) {
-        const int clusters = 255 / G, words = 80 * 40;            // 80 sequences x 40 hidden units per member and step
-        for (int sync_on = 0; sync_on <= 1; ++sync_on) {
-            hipMemset(flags, 0, 256 * 64 * sizeof(unsigned));
-            hipLaunchKernelGGL(k, dim3(clusters * G), dim3(256), 0, 0, G, steps, work, words, flags, state, cyc, sink, sync_on);
-            if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
-            printf("G = %d, %3d workgroups, rendezvous %s: %8.0f cycles per step\n", G, clusters * G, sync_on ? "on " : "off",
-                   (double)cyc[0] / steps);
+    for (int same_xcd = 0; same_xcd <= 1; ++same_xcd)
+        for (int G : {1, 2, 5}) {
+            // same_xcd: 32 workgroups per XCD -> 6 clusters of 5 (30 workgroups) per XCD: the grid is 8 * (32 / G) * G
+            const int wgs = same_xcd ? 8 * ((32 / G) * G) : (255 / G) * G;
+            const int words = 80 * 40;                            // 80 sequences x 40 hidden units per member and step
+            for (int sync_on = 0; sync_on <= 1; ++sync_on) {
+                hipMemset(flags, 0, 512 * 64 * sizeof(unsigned));
+                hipLaunchKernelGGL(k, dim3(wgs), dim3(256), 0, 0, G, steps, work, words, flags, state, cyc, sink, sync_on,
+                                   same_xcd);
+                if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
+                printf("%s, G = %d, %3d workgroups, rendezvous %s: %8.0f cycles per step\n",
+                       same_xcd ? "cluster within one XCD" : "cluster across XCDs   ", G, wgs, sync_on ? "on " : "off",
+                       (double)cyc[0] / steps);
+            }
         }
-    }
     return 0;
 }
