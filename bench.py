@@ -39,6 +39,109 @@ MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA dense peak
 MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA dense peak (never the 2:1-sparse figure)
 
 
+def _r(v, sig=4):
+    """floats to `sig` significant digits (the line is for reading and parsing, the detail file keeps full precision)"""
+    if isinstance(v, float):
+        return float('%.*g' % (sig, v))
+    return v
+
+
+def _pick(d, keys, sig=4):
+    return {k: _r(d[k], sig) for k in keys if d is not None and k in d and d[k] is not None} if d else None
+
+
+LINE_LIMIT = 4096       # the driver keeps ~8 KB of stdout tail; round 4's 37 KB line was cut and recorded as parsed: null
+
+
+def compact_line(out, detail_path=None):
+    """The ONE stdout line of a run, from the full record `out` (which goes to bench_detail.json): the contract's keys,
+    the rooflines, the CPU baseline, parity, and one-line summaries of the companion modes / other configs / scaling
+    modes.  Guaranteed < LINE_LIMIT bytes: optional blocks are dropped from the end of `optional` until it fits
+    (tests/test_host_cpu.py runs this on recorded runs, N = 1 and N > 1)."""
+    roof = out.get('roofline')
+    line = {
+        'metric': out['metric'], 'value': _r(out['value'], 6), 'unit': out['unit'], 'n_gpus': out['n_gpus'],
+        'steps': out['steps'], 'warmup': out['warmup'], 'ms_per_step': _r(out['ms_per_step'], 5),
+        'higher_is_better': True, 'scaling': out['scaling'], 'vs_baseline': out.get('vs_baseline'),
+        'dtype': out['dtype'], 'data': out['data'], 'gemm_mode': out.get('gemm_mode'),
+        'config': {'workload': out['config']['workload'], 'parallelism': out['config'].get('parallelism'),
+                   'global_batch': out.get('global_batch'),
+                   'nodes': (out['config'].get('batch_graph') or {}).get('nodes'),
+                   'edges': (out['config'].get('batch_graph') or {}).get('edges')},
+        'roofline': _pick(roof, ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic',
+                                 'operand_bytes_per_launch', 'avg_us', 'calls_per_step')),
+        'cpu_baseline': _pick(out.get('cpu_baseline'), ('value', 'unit', 'cores', 'kind', 'ms_per_step', 'sample')),
+        'parity': _pick(out.get('parity'), ('rel_err', 'tolerance', 'grad_rel_err', 'grad_tolerance', 'batches')),
+    }
+    if roof is not None and 'traffic' not in line['roofline']:
+        line['roofline']['traffic'] = None
+    optional = []
+    g = out.get('roofline_rgcn_gather') or {}
+    if g:
+        optional.append(('roofline_rgcn_gather',
+                         {k.replace('rgcn_gather_', ''): _pick(v, ('frac_strict', 'frac', 'avg_us', 'traffic'), 3)
+                          for k, v in g.items()}))
+    if out.get('roofline_gru'):
+        optional.append(('roofline_gru', _pick(out['roofline_gru'], ('bound', 'achieved', 'peak', 'unit', 'frac', 'avg_us',
+                                                                     'calls_per_step'))))
+    if out.get('kernel_only'):
+        optional.append(('kernel_only', _pick(out['kernel_only'], ('ms_per_step', 'glue_ms_per_step',
+                                                                   'timed_pass_ms_per_step'))))
+    for k in ('e2e_device_builder', 'host_enqueue_ms_per_step', 'launches_per_step', 'host_build_ms', 'last_loss',
+              'rccl_ranks_seen', 'scaling_mode'):
+        if out.get(k) is not None:
+            optional.append((k, _r(out[k])))
+    if out.get('encoder_only'):
+        optional.append(('encoder_only', _pick(out['encoder_only'], ('value', 'ms_per_step'))))
+    for sc in ('scaling_weak', 'scaling_strong', 'scaling_exact'):
+        if out.get(sc):
+            optional.append((sc, _pick(out[sc], ('value', 'ms_per_step', 'global_batch', 'batch_per_gpu', 'last_loss'))))
+
+    def summary(rec):
+        if not rec:
+            return None
+        if 'error' in rec:
+            return {'error': str(rec['error'])[-80:]}
+        s_ = _pick(rec, ('value', 'ms_per_step', 'dtype', 'gemm_mode'))
+        if rec.get('roofline'):
+            s_['roofline_frac'] = _r(rec['roofline'].get('frac'), 3)
+        if rec.get('parity'):
+            s_['rel_err'] = _r(rec['parity'].get('rel_err'), 2)
+            s_['grad_rel_err'] = _r(rec['parity'].get('grad_rel_err'), 2)
+        return s_
+    modes = {k: summary(out.get(k)) for k in ('value_bf16x6', 'value_f16x3', 'value_exact_f32') if out.get(k)}
+    if modes:
+        optional.append(('modes', modes))
+    if out.get('other_configs'):
+        optional.append(('other_configs', {k: summary(v) for k, v in out['other_configs'].items()}))
+    if detail_path:
+        line['detail'] = detail_path
+    for k, v in optional:
+        line[k] = v
+    text = json.dumps(line, separators=(',', ':'))
+    while len(text) >= LINE_LIMIT and optional:
+        k, _ = optional.pop()
+        line.pop(k, None)
+        line['dropped'] = line.get('dropped', 0) + 1
+        text = json.dumps(line, separators=(',', ':'))
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def write_detail(out):
+    """The full record (kernel tables, gemm_shapes, complete companion / other-config records) -> bench_detail.json next
+    to this script and, on a gpurun box, under gpurun_out/ (which travels back).  Returns the path named in the line."""
+    name = 'bench_detail.json' if out.get('n_gpus', 1) == 1 else 'bench_detail_n%d.json' % out['n_gpus']
+    for d_ in (ROOT, os.path.join(ROOT, 'gpurun_out')):
+        try:
+            if os.path.isdir(d_):
+                with open(os.path.join(d_, name), 'w') as f:
+                    json.dump(out, f)
+        except OSError:
+            pass
+    return name
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -82,6 +185,10 @@ def parse():
     ap.add_argument('--other-steps', type=int, default=20,
                     help='steps of the other BASELINE.json configs (WIKI-shaped, GDELT-shaped, YAGO-shaped n_hidden 400 '
                          'seq_len 15 bf16 storage), each a child process reported under `other_configs` (0 = skip)')
+    ap.add_argument('--plain', action='store_true',
+                    help='only the W + K steps of `value` (no event-timed second pass, no companions, no CPU baseline): '
+                         'the command to put under rocprofv3 --kernel-trace --stats, so that the trace holds the product '
+                         'configuration alone')
     ap.add_argument('--child', default='', help='(internal) this run is a companion of another: print the reduced record')
     return ap.parse_args()
 
@@ -103,6 +210,8 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.plain:
+        args.cpu_steps = args.enc_steps = args.e2e_steps = args.f32_steps = args.other_steps = args.companions = 0
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -262,7 +371,9 @@ def main():
     # ... then the SAME K steps once more with HIP events around every C-ABI launch: the per-class kernel table, the
     # roofline's average launch durations and `kernel_only` come from this second pass (its wall time is reported too)
     timer = K.KernelTimer()
-    elapsed_timed, _, _, _ = mode.run(timer, prepared)
+    elapsed_timed = None
+    if not args.plain:
+        elapsed_timed, _, _, _ = mode.run(timer, prepared)
 
     # ---- N > 1: the other scaling modes of the same step, so that the line is explicit about global batch size ----
     companions = {}
@@ -606,7 +717,7 @@ def main():
         'roofline': roofline, 'roofline_rgcn_gather': gather, 'roofline_gru': gru, 'parity': parity,
         'encoder_only': encoder_only,
         'kernel_only': {'ms_per_step': ko, 'value': rank_batch / max(ko * 1e-3, 1e-12), 'glue_ms_per_step': glue_ms,
-                        'timed_pass_ms_per_step': elapsed_timed * 1e3 / args.steps,
+                        'timed_pass_ms_per_step': elapsed_timed * 1e3 / args.steps if elapsed_timed else None,
                         'what': 'sum of the HIP-event durations of EVERY C-ABI launch of a step (named classes + the '
                                 "small kernels as 'glue:*'), from a second pass over the same steps with events on "
                                 '(serial launches, no side stream); torch-native launches (a dot, a few fills / adds) are '
@@ -615,6 +726,7 @@ def main():
         'other_configs': other_configs,
         'pmc_source': pmc_file,
         'traffic_source': ('%s: rocprofv3 --pmc passes of this command (tools/pmc_traffic.py), NOT measured in this run' % pmc_file) if pmc_file else None, 'kernels': kernels, 'gemm_shapes': gemm_shapes, 'cpu_baseline': cpu,
+        'launches_per_step': sum(e_['calls_per_step'] for e_ in kernels.values()) or None,     # C-ABI launches
         'host_enqueue_ms_per_step': host_enqueue_ms,       # host time to enqueue a step of the `value` run; close to
                                                            # ms_per_step = the host, not the GPU, paces the step
         'host_build_ms': host_build_ms, 'e2e_value': e2e, 'e2e_workers': e2e_workers, 'e2e_inline': e2e_inline, 'e2e_threads8': e2e_threads,
@@ -624,7 +736,10 @@ def main():
     out.update(companions)
     if world > 1 and not companions:
         out['multi_gpu_note'] = 'companion scaling modes skipped (--companions 0)'
-    print(json.dumps(out))
+    if args.child:
+        print(json.dumps(out))            # a companion's full record, read by the parent process only
+    else:
+        print(compact_line(out, write_detail(out)))
     if dist_on:
         dist.destroy_process_group()
 
@@ -675,8 +790,8 @@ def cpu_baseline(args, quads, num_ent, num_rels, hist_s, hist_o, net, perm):
     rec = {'value': args.batch / t, 'unit': 'triples/s', 'cores': int(threads), 'kind': 'port',
            'host_cpus': os.cpu_count(), 'ms_per_step': t * 1e3, 'stage_ms_median': stage_ms,
            'sample': '%d training steps (fwd both directions + bwd, eval-mode dropout) of batch %d after %d warm-ups, '
-                     'oracle/renet_oracle.py on torch-CPU with %d threads; medians'
-                     % (len(times), args.batch, warm, threads)}
+                     'oracle/renet_oracle.py (restated reference; the unmodified reference + DGL does not travel to the '
+                     'GPU box) on torch-CPU with %d threads; medians' % (len(times), args.batch, warm, threads)}
     return rec, losses, steps_idx, first_grad
 
 
