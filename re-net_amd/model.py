@@ -120,10 +120,10 @@ class RENet(nn.Module):
         # _joint_topk_many); False builds the R-fold batches of rounds 1-3 (A/B runs, tests)
         self.broadcast_relations = os.environ.get('RENET_ADVANCE_BROADCAST', '1') != '0'
         # inference advance: score the (entity, relation) rows in blocks of descending upper bound p_r * prob and stop at the
-        # first row that cannot reach the top num_k any more (_winners_pruned: exact, same winners).  Opt-in this round
-        # (RENET_ADVANCE_PRUNE=1): the arithmetic is covered on CPU (tests/test_host_cpu.py), the config-scale GPU test and
-        # the timing are next round's first session.
-        self.prune_relations = os.environ.get('RENET_ADVANCE_PRUNE', '0') == '1'
+        # first row that cannot reach the top num_k any more (_winners_pruned: exact, same winners).  Default since round 5
+        # (0.179 -> 0.059 s per advance on a trained ICEWS18-shaped model at num_k 1000, identical predicted facts:
+        # profiles/r05_a_advance_pruned.txt); RENET_ADVANCE_PRUNE=0 restores the exhaustive scoring (A/B runs, tests).
+        self.prune_relations = os.environ.get('RENET_ADVANCE_PRUNE', '1') == '1'
         self.last_prune = None
         self.shadow_pick = None
         self._shadow = {}
@@ -585,7 +585,8 @@ def _advance_side(self, picks, prob, subject):
     picks_np = picks.detach().cpu().numpy().astype(np.int64)
     if self.prune_relations and not self.reference_shadowing and \
             getattr(self.update_cache, '__func__', None) is _update_cache:
-        win_ent, codes_np = self._winners_pruned(picks_np, prob, subject)
+        with torch.no_grad():               # callers outside torch.no_grad() exist (the reference's predict is not wrapped)
+            win_ent, codes_np = self._winners_pruned(picks_np, prob.detach(), subject)
         self._shadow['s' if subject else 'o'] = int(win_ent[-1])          # (read under reference_shadowing only)
         return self._apply_winners(win_ent, codes_np, subject)
     uniq = np.unique(picks_np)                           # identical entities give identical results: compute once
@@ -759,9 +760,8 @@ def _bulk_update_cache(cache_e, pairs):
 
 def _touched_sets(self):
     """(subjects, objects) whose prediction cache is non-empty, kept by _advance_side so that rolling the histories and
-    collecting the predicted facts walk ~2 * num_k entities instead of all 2 * N_ent.  The sets belong to the CURRENT
-    cache lists: when a caller replaced them (test.py restores s_his_cache / o_his_cache from a checkpoint,
-    test.py:70-81; init_history resets them) they are rebuilt by one full scan."""
+    collecting the predicted facts walk ~2 * num_k entities instead of all 2 * N_ent.  Rebuilt by one full scan at the start
+    of every advance (_advance_time drops the key) and whenever the cache lists were replaced."""
     key = (id(self.s_his_cache), id(self.o_his_cache))
     if getattr(self, '_touched_key', None) != key:
         self._touched = tuple({e for e in range(self.in_dim) if len(c[e]) != 0}
@@ -808,6 +808,9 @@ def _cached_facts(self):
 
 def _advance_time(self, t, global_model):
     """model.py:222-328: executed once when the evaluated stream moves to a new timestamp."""
+    # the touched sets are trusted only WITHIN one advance: callers own the cache lists between advances (test.py:70-81 restores
+    # them from checkpoints, element writes are legal), so every advance starts with one full scan (~3 ms at N_ent 23 033)
+    self._touched_key = None
     _, _, prob_sub = global_model.predict(self.latest_time, self.graph_dict, subject=True)
     self._advance_side(self.sample_entities(prob_sub), prob_sub, subject=True)
     _, ob, _ = global_model.predict(t, self.graph_dict, subject=False)

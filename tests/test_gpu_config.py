@@ -11,6 +11,9 @@ seq_len = 15, compared with
 Tolerances (fp32 results, different summation order): losses 1e-4 relative; activations 5e-4 of the tensor's
 max |value|; gradients 2e-3 of the tensor's max |value| (the bound the small-scale tests use).
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -19,6 +22,7 @@ from helpers import load_golden
 from oracle import config_cases as C, fixtures
 
 pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 CASE_NAMES = ['icews18_d200', 'wiki_d200', 'gdelt_d200', 'yago_d400_l15']
 
@@ -376,3 +380,34 @@ def test_inference_at_config_scale_matches_reference(dev, shadowing):
     from oracle import renet_oracle as O
     m1, m2 = O.mrr_hits(ranks[keep].reshape(-1)), O.mrr_hits(gold['ranks'][keep].reshape(-1))
     assert abs(m1['mrr'] - m2['mrr']) < 2e-3
+
+
+def test_pruned_advance_on_a_trained_model_predicts_the_same_facts(dev):
+    """RENet.prune_relations (the default since round 5) against the exhaustive scoring of every (entity, relation) row, which
+    the test above ties to the reference's recorded facts -- on a model TRAINED for 200 steps on the ICEWS18-shaped stream
+    (N_ent 23 033, R 256, num_k 1000), so that p(r | s) is peaked and rows really are skipped (a random model prunes nothing).
+    model.py:229-297: the winners are the top num_k of the candidate multiset; identical facts are required, not a tolerance."""
+    import copy
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), 'tools'))
+    import advance_pruned_bench as APB
+    net, gnet, te = APB.build('ICEWS18', 200, 40, 1000, 200, dev)
+    ts = np.unique(te[:, 3])
+    facts, stats = {}, {}
+    for prune in (False, True):
+        m = copy.deepcopy(net)
+        m.prune_relations = prune
+        g = torch.Generator(device='cpu').manual_seed(7)
+        m.sample_entities = lambda prob, g=g, m=m: torch.multinomial(prob.detach().cpu(), m.num_k, replacement=True,
+                                                                      generator=g).to(prob.device)
+        with torch.no_grad():
+            for t in ts[1:]:
+                m._advance_time(torch.tensor(int(t)), gnet)
+        new_t = [t for t in m.graph_dict.keys() if t not in net.graph_dict]
+        facts[prune] = {int(t): set(map(tuple, np.stack(m.graph_dict[t].global_triples(), 1).tolist())) for t in new_t}
+        stats[prune] = m.last_prune
+    assert stats[False] is None and stats[True] is not None
+    print('pruned advance:', stats[True])
+    assert stats[True]['scored'] < stats[True]['rows'] // 4, stats[True]          # observed: 11 654 of 249 856
+    assert facts[False].keys() == facts[True].keys() and len(facts[True]) == len(ts) - 1
+    for t in facts[False]:
+        assert facts[False][t] == facts[True][t], (t, len(facts[False][t] ^ facts[True][t]))
