@@ -30,7 +30,16 @@ def mrr_hits(ranks):
     return float(np.mean(1.0 / ranks)), [float(np.mean(ranks <= k)) for k in (1, 3, 10)]
 
 
-def run_seed(seed, data, gold):
+FULL_CFG = dict(h=200, seq_len=10, batch=1024, num_k=1000, lr=1e-3, wd=1e-5, grad_norm=1.0, maxpool=1, pre_batch=1024,
+                pre_lr=1e-2)       # tools/make_e2e_full_golden.py (train.py:211-236, pretrain.py:113-135)
+
+
+def run_seed(seed, data, gold, stream=False, keep_ranks=False, log=None, samples=None):
+    """gold: mapping with h / seq_len / batch / num_k / dropout / lr / wd / grad_norm / maxpool / pre_* / epochs.
+    stream: validate with evaluate_filter_stream (one batch per timestamp; same ranks as the per-quadruple calls,
+    tests/test_gpu_parity.py::test_evaluate_filter_stream_equals_sequential_calls) instead of train.py's loop.
+    samples: [n_draws, num_k] entity samples recorded from the reference run of this seed (replayed in order by the
+    validation advance: the CPU and GPU generators differ); None = draw on the device."""
     from sklearn.utils import shuffle
     import global_model as GM
     import model as M
@@ -91,20 +100,30 @@ def run_seed(seed, data, gold):
             opt.step()
             tot += float(loss.item())
         epoch_losses.append(tot / (len(tr) / batch))
+        if log:
+            log('  seed %d epoch %d loss %.5f' % (seed, ep + 1, epoch_losses[-1]))
     # ---- train.py:151-185
     net.eval()
     total = torch.from_numpy(allq).to(dev)
     valid = torch.from_numpy(va)
     vs, vo, ts, to = hs.to_lists(rng_va), ho.to_lists(rng_va), hs.to_lists(rng_te), ho.to_lists(rng_te)
     ranks = []
+    if samples is not None:
+        pending = [torch.from_numpy(np.asarray(x, dtype=np.int64)).to(dev) for x in samples]
+        net.sample_entities = lambda prob: pending.pop(0)
     with torch.no_grad():
         net.init_history(tr, (sh, sht), (oh, oht), valid, vs, vo, te, ts, to)
         net.latest_time = valid[0][3]
-        for i in range(len(va)):
-            rk, _ = net.evaluate_filter(valid[i], (vs[0][i], vs[1][i]), (vo[0][i], vo[1][i]), gnet, total)
-            ranks.append(rk)
+        if stream:
+            ranks, _ = net.evaluate_filter_stream(valid, vs, vo, gnet, total)
+        else:
+            for i in range(len(va)):
+                rk, _ = net.evaluate_filter(valid[i], (vs[0][i], vs[1][i]), (vo[0][i], vo[1][i]), gnet, total)
+                ranks.append(rk)
     opt.close()
     mrr, hits = mrr_hits(ranks)
+    if keep_ranks:
+        return mrr, hits, epoch_losses, np.asarray(ranks).reshape(len(va), -1)
     return mrr, hits, epoch_losses
 
 

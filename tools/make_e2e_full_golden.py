@@ -61,10 +61,23 @@ def main():
     (tsh, tsht), (toh, toht), st = O.build_histories(te, num_ent, state=st)
     hist = ((sh, sht), (oh, oht), (vsh, vsht), (voh, voht), (tsh, tsht), (toh, toht))
     res = []
+    # the entity samples of the validation advance (model.py:225-227, 263-265: Categorical(prob).sample([num_k])) are recorded
+    # per seed, so that the HIP run can replay the reference's random trajectory (the two devices' generators differ)
+    Cat = torch.distributions.categorical.Categorical
+    orig = Cat.sample
+    drawn = []
+
+    def rec(self, shape=torch.Size()):
+        out = orig(self, shape)
+        drawn.append(out.clone().numpy())
+        return out
+    Cat.sample = rec
     with ref_loader.cpu_mode():
         for seed in seeds:
             t0 = time.time()
+            del drawn[:]
             res.append(G.run_seed(ref, seed, epochs, tr, va, te, num_ent, num_rels, hist))
+            res[-1]['samples'] = np.stack(drawn).astype(np.int32) if drawn else np.zeros((0, G.CFG['num_k']), np.int32)
             print('seed %d total %.0f s' % (seed, time.time() - t0), flush=True)
             np.savez_compressed(
                 os.path.join(OUT, name), seeds=np.asarray(seeds[:len(res)]), epochs=epochs,
@@ -72,6 +85,7 @@ def main():
                 epoch_loss=np.asarray([r['epoch_loss'] for r in res]),
                 pre_loss=np.asarray([r['pre_loss'] for r in res]),
                 ranks=np.stack([r['ranks'] for r in res]).astype(np.int32),
+                samples=np.stack([r['samples'] for r in res]),
                 **{k: np.asarray(v) for k, v in G.CFG.items()})
 
 

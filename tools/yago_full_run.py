@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""FULL-DATA accuracy run of the HIP path on all of public YAGO (tests/golden/yago_full.npz: 161 540 / 19 523 / 20 026
+quadruples), the counterpart of tools/make_e2e_full_golden.py (the unmodified reference on CPU):
+
+    python tools/yago_full_run.py <dropout> <epochs> <pre_epochs> <seed> [seed ...]      RENET_GEMM selects the GEMM mode
+
+per seed: pretrain.py's loop for the global model -> get_global_emb -> train.py's loop as the PRODUCT runs it (merged pass,
+HipAdam) -> train.py's filtered validation (train.py:151-185, one batch per timestamp) -> MRR / Hits@1,3,10.  When the
+matching reference fixture (tests/golden/e2e_yago_full_d0.npz | e2e_yago_full_drop.npz) holds this seed, its recorded entity
+samples are replayed in the validation advance and the comparison is printed.  Writes gpurun_out/yago_full_<tag>.npz
+(ranks per seed) and prints ONE JSON line."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 're-net_amd'), os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def main():
+    import renet_hip as K
+    K.lib()
+    import train_mode_run as T
+    dropout, epochs, pre_epochs = float(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    seeds = [int(x) for x in sys.argv[4:]]
+    d = np.load(os.path.join(GOLDEN, 'yago_full.npz'))
+    data = {k: (d[k].astype(np.int64) if d[k].ndim else d[k]) for k in d.files}
+    cfg = dict(T.FULL_CFG, dropout=dropout, epochs=epochs, pre_epochs=pre_epochs)
+    tag = 'd0' if dropout == 0.0 else 'drop'
+    fpath = os.path.join(GOLDEN, 'e2e_yago_full_%s.npz' % tag)
+    gold = np.load(fpath) if os.path.isfile(fpath) else None
+    if gold is not None and (int(gold['epochs']) != epochs or int(gold['pre_epochs']) != pre_epochs):
+        gold = None                                   # a different schedule (e.g. the 20-epoch run): nothing to replay
+    res, t0 = [], time.time()
+    for seed in seeds:
+        samples = None
+        if gold is not None and seed in gold['seeds'].tolist() and 'samples' in gold.files:
+            samples = gold['samples'][gold['seeds'].tolist().index(seed)]
+        t1 = time.time()
+        mrr, hits, el, ranks = T.run_seed(seed, data, cfg, stream=True, keep_ranks=True, samples=samples,
+                                          log=lambda m: print(m, file=sys.stderr, flush=True))
+        rec = {'seed': seed, 'mrr': mrr, 'hits': hits, 'epoch_loss': el, 'seconds': time.time() - t1,
+               'replayed_reference_samples': samples is not None}
+        if gold is not None and seed in gold['seeds'].tolist():
+            i = gold['seeds'].tolist().index(seed)
+            rec['reference_mrr'] = float(gold['mrr'][i])
+            rec['reference_hits'] = [float(x) for x in gold['hits'][i]]
+            rec['reference_epoch_loss'] = [float(x) for x in gold['epoch_loss'][i]]
+            rr = np.asarray(gold['ranks'][i]).reshape(ranks.shape)
+            rec['ranks_equal_frac'] = float(np.mean(rr == ranks))
+        print('  seed %d: %s' % (seed, json.dumps(rec)), file=sys.stderr, flush=True)
+        res.append((rec, ranks))
+    out_dir = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out_dir, exist_ok=True)
+    np.savez_compressed(os.path.join(out_dir, 'yago_full_%s_%s_e%d.npz' % (tag, K.GEMM_MODE, epochs)),
+                        seeds=np.asarray(seeds), ranks=np.stack([r[1] for r in res]).astype(np.int32),
+                        mrr=np.asarray([r[0]['mrr'] for r in res]))
+    print(json.dumps({'gemm_mode': K.GEMM_MODE, 'dropout': dropout, 'epochs': epochs, 'pre_epochs': pre_epochs,
+                      'num_k': cfg['num_k'], 'train_quadruples': int(len(data['train'])),
+                      'valid_quadruples': int(len(data['valid'])), 'runs': [r[0] for r in res],
+                      'seconds': time.time() - t0}))
+
+
+if __name__ == '__main__':
+    main()
