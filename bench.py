@@ -291,23 +291,18 @@ def main():
 
     import ops as ops_mod_
 
-    class Mode(object):
-        """One scaling mode of the data-parallel step: which quadruples a rank takes and how gradients combine."""
+    class Mode(parallel.ScalingMode):
+        """One scaling mode of the data-parallel step (parallel.ScalingMode: which quadruples a rank takes, how gradients
+        combine) bound to this run's network, data and optimizer."""
 
         def __init__(self, scaling):
-            self.scaling = scaling
-            self.exact = scaling == 'exact'
-            self.rank_batch = args.batch if scaling in ('weak', 'exact') else max(1, args.batch // world)
-            self.global_batch = args.batch if scaling in ('strong', 'exact') else args.batch * world
-            self.passes = 'merged' if self.exact else args.passes
+            super().__init__(scaling, args.batch, world, passes=args.passes)
 
         def prepare(self, step):
-            idx = parallel.shard_indices(perm, step, 0, 1, self.rank_batch) if self.exact else \
-                parallel.shard_indices(perm, step, rank, world, self.rank_batch)
+            idx = self.indices(perm, step, rank)
             b = quads[idx]
             if self.passes == 'merged':
-                both = net.prepare_both(b, hist_s.take(idx), hist_o.take(idx), graph_dict,
-                                        shard=(rank, world) if self.exact and world > 1 else None)
+                both = net.prepare_both(b, hist_s.take(idx), hist_o.take(idx), graph_dict, shard=self.shard(rank))
                 if both is not None:
                     return (both,)
                 assert not self.exact, 'exact scaling needs histories on both sides of the batch'
@@ -322,7 +317,7 @@ def main():
             return net.loss_prepared_pair(*preps)       # the four GRU recurrences of the two passes share one launch
 
         def train_step(self, *preps):
-            with opt.step_scope(head_passes=1 if len(preps) == 1 else 2, average=not self.exact):
+            with opt.step_scope(head_passes=1 if len(preps) == 1 else 2, average=self.average):
                 loss = self.step_loss(*preps)
                 loss.backward()
                 opt.step()                   # gradient all-reduce (N>1) -> clip -> Adam -> zero_grad
@@ -702,7 +697,7 @@ def main():
         'metric': 'RGCN+GRU encoder triples/s at bs=%d n_hidden=%d (full training step, both directions)'
                   % (args.batch, args.hidden),
         'value': value, 'unit': 'triples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'strong' if exact_split else args.scaling,
+        'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': mode.reported_scaling,
         'scaling_mode': args.scaling, 'global_batch': mode.global_batch, 'rccl_ranks_seen': ranks_seen,
         'vs_baseline': None,
         # the arithmetic type the path computes in: fp32 tensors everywhere ('f32'); --dtype bf16 = bf16 operand storage

@@ -245,26 +245,18 @@ int renet_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const floa
                     const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                     int split_k, float* workspace, size_t workspace_bytes, void* stream);
 
-/* The bf16x6 GEMM on PRE-SPLIT operands: no fp32 -> bf16 split in the k-loop (it costs as much as the MFMAs it
- * feeds); tiles are staged by LDS-DMA (global_load_lds) through a 3-deep LDS ring.  Same arithmetic and results as
- * renet_gemm_f32_split.
- *   renet_pack_planes : fp32 X[R, C] (row stride ldx) -> three bf16 planes, each a row-major [Rp][Cp] matrix with
- *                       Rp, Cp = R, C rounded up to multiples of 128 and the padding zero-filled; plane p starts at
- *                       p * Rp * Cp elements.  renet_planes_bytes(R, C) bytes.
- *   renet_gemm_planes : C[M,N] = alpha * op(A) op(B) (+ bias) (+ beta * C), contraction length K.
- *       a_tr == 0: the A planes hold A as [M rows][K cols]   (K contiguous);   lda = Cp of that plane set
- *       a_tr == 1: the A planes hold A^T, i.e. [K rows][M cols] (the tensor as stored when the contraction runs over
- *                  its rows): fragments come from the transposing LDS read ds_read_b64_tr_b16
- *       b_tr == 0: the B planes hold B^T as [N rows][K cols] (nn.Linear's weight layout);  b_tr == 1: B as [K][N]
- *     One plane set serves both roles: linear.weight [N_ent, 3D] is op(B) of the logits GEMM (b_tr = 0) and of
- *     dfeat = dlogits W (b_tr = 1); dlogits [B, N_ent] is op(A) of dfeat (a_tr = 0) and of dW = dlogits^T feat
- *     (a_tr = 1).  split_k / workspace as renet_gemm_f32. */
 /* bf16 STORAGE (BASELINE config 5, "n_hidden=400 bf16"): operands live in HBM as bf16 matrices, [Rp][Cp] row-major
  * with Rp, Cp = R, C rounded up to multiples of 256 and zero padding.
  *   renet_pack_bf16  : fp32 X[R, C] (row stride ldx) -> bf16 (RNE), padding written; renet_bf16_bytes(R, C) bytes.
- *   renet_gemm_bf16s : the GEMM contract of renet_gemm_planes on such matrices: ONE bf16 product per element pair
- *                      (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 C; operands staged by LDS-DMA, consumed
- *                      K-contiguous (tr = 0) or K-strided (tr = 1) as there.  Replaces torch.mm / nn.Linear /
+ *   renet_gemm_bf16s : C[M,N] = alpha * op(A) op(B) (+ bias) (+ beta * C) on such matrices, contraction length K: ONE bf16
+ *                      product per element pair (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 C; operands staged by
+ *                      LDS-DMA (global_load_lds) through a 3-deep LDS ring.
+ *       a_tr == 0: A is stored as [M rows][K cols] (K contiguous);  a_tr == 1: A^T, i.e. [K rows][M cols] (the tensor as
+ *                  stored when the contraction runs over its rows): fragments come from ds_read_b64_tr_b16
+ *       b_tr == 0: B^T as [N rows][K cols] (nn.Linear's weight layout);  b_tr == 1: B as [K][N]
+ *     One stored matrix serves both roles: linear.weight [N_ent, 3D] is op(B) of the logits GEMM (b_tr = 0) and of
+ *     dfeat = dlogits W (b_tr = 1); dlogits [B, N_ent] is op(A) of dfeat (a_tr = 0) and of dW = dlogits^T feat (a_tr = 1).
+ *     split_k / workspace as renet_gemm_f32.  Replaces torch.mm / nn.Linear /
  *                      nn.GRU's input projection at config 5 (RGCN.py:35, model.py:86-99) -- the reference itself
  *                      has no bf16 path; tolerances in tests/test_gpu_bf16.py. */
 size_t renet_bf16_bytes(int R, int C);
@@ -297,11 +289,6 @@ int renet_gru_bwd_layouts_bf16out(int n, const float* const* dh_last, const int3
 int renet_colsum_bf16(const void* X, int M, int N, int ldx, float* out, float beta, float* workspace,
                       size_t workspace_bytes, void* stream);
 int renet_scale_bf16_by_device_scalar(void* x, size_t n, const float* scale, void* stream);
-size_t renet_planes_bytes(int R, int C);
-int renet_pack_planes(const float* X, int R, int C, int ldx, void* planes, void* stream);
-int renet_gemm_planes(int a_tr, int b_tr, int M, int N, int K, float alpha, const void* Ap, int lda, const void* Bp,
-                      int ldb, float beta, float* C, int ldc, const float* bias, int split_k, float* workspace,
-                      size_t workspace_bytes, void* stream);
 
 /* column sums: out[n] = beta * out[n] + sum_m X[m,n]  (bias gradients; beta = 1 accumulates straight into
  * an existing .grad); two deterministic passes over row groups, `workspace` = renet_colsum_workspace(M, N)

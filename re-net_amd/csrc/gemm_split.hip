@@ -907,18 +907,11 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(SplitArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// PLANES GEMM (renet_gemm_planes): both operands arrive as three bf16 planes in HBM (renet_pack_planes, or a
-// producer kernel that writes planes directly), so the k-loop holds no fp32 -> bf16 split at all -- the split above
-// costs as much as the 48 MFMAs it feeds (its VALU work cannot hide behind the same SIMD's matrix pipe and its LDS
-// stores saturate the 85 B/clk store path; profiles/r01_g_gemm_probes.md).  Here a k-tile is
-//     12 global_load_lds_dwordx4 per wave (LDS-DMA: no VGPRs, no VALU, no ds_write)
-//     24 fragment reads + 48 v_mfma_f32_32x32x16_bf16 per wave            (same bf16x6 arithmetic, same results)
-// with a 3-deep LDS ring (3 x 48 KB, one workgroup per CU) and ONE raw s_barrier per k-tile: the DMA of tile
-// kt + 2 is issued right behind barrier(kt) into the buffer that every wave finished reading before that barrier,
-// and `s_waitcnt vmcnt(12)` -- the 12 newest DMAs may stay in flight -- is the only wait on global memory.
-//
-// A plane tensor is a row-major bf16 matrix [rows][cols] x 3 planes, both dims padded with zeros to multiples of
-// 128 (so no edge handling exists in the loop).  An operand is consumed in one of two roles:
+// LDS-DMA ring shared by the bf16-storage GEMM below (the three-plane "planes" GEMM that introduced it in round 2 was
+// measured against the in-loop split, not adopted -- DESIGN 4b -- and removed in round 5): operands are bf16 matrices
+// [rows][cols] in HBM, both dims padded with zeros to multiples of 128 (no edge handling in the loop); a k-tile is
+// global_load_lds_dwordx4 pieces (no VGPRs, no VALU, no ds_write) into a 3-deep LDS ring with ONE raw s_barrier per
+// k-tile.  An operand is consumed in one of two roles:
 //   K-CONTIGUOUS (tr = 0): rows = the operand's M (N) index, cols = K.  Tile image in LDS: [128 rows][32 k], 64-byte
 //       rows, the four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3 -- applied on the SOURCE address of
 //       the DMA (the LDS side of global_load_lds is lane-linear) -- which makes every ds_read_b128 fragment read
@@ -928,23 +921,11 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(SplitArgs g) {
 //       sixteen 16-byte chunks XOR-swizzled by 4 * (k & 3); fragments come from two ds_read_b64_tr_b16 each (gfx950's
 //       transposing LDS read: in a 16-lane group, lane i receives element i & 3 of the 8-byte chunks addressed by
 //       lanes (i >> 2) + 4 j, j = 0..3 -- measured with tools/probes/tr_probe.hip).
-// One plane set therefore serves BOTH roles: the weight of the score head feeds logits (K-contiguous) and dfeat
-// (K-strided), dlogits feeds dfeat (K-contiguous) and dW (K-strided).
 // ------------------------------------------------------------------------------------------------------
-struct PlanesArgs {
-    const __bf16* A;            // plane 0 of A; planes are a_plane elements apart
-    const __bf16* B;
-    size_t a_plane, b_plane;
-    int lda, ldb;               // row stride of a plane (elements)
-    SplitArgs out;              // M, N, K, C, ldc, alpha, beta, bias, split-K fields (A/B/lda/ldb unused)
-};
 
-constexpr int P3_STAGE = 6 * 8192;                       // bytes per ring slot: 3 A planes + 3 B planes, 8 KB each
 constexpr int P3_SLOTS = 3;
 constexpr int P3_LOADERS = 4;                           // loader waves per workgroup (48 DMA pieces per k-tile)
-constexpr int P3_PER = 48 / P3_LOADERS;
 constexpr int P3_THREADS = 64 * (4 + P3_LOADERS);
-constexpr size_t P3_LDS = (size_t)P3_STAGE * P3_SLOTS;
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -984,174 +965,11 @@ __device__ __forceinline__ bf16x8 p3_fragment(const char* tile, int lane, int w0
 //                       barrier k
 //     MFMA wave, round k : fragments of tile k (slot k % 3), 48 MFMAs with the slab-1 reads behind the first 12,
 //                          s_waitcnt lgkmcnt(0), barrier k
-template <bool A_TR, bool B_TR>
-__global__ __launch_bounds__(P3_THREADS) void gemm_planes_kernel(PlanesArgs pa) {
-    extern __shared__ __attribute__((aligned(16))) char ring[];          // the ONLY LDS object (see the header comment)
-    const SplitArgs& g = pa.out;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bx, by, z;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by, z);
-    const int m0 = by * BM, n0 = bx * BN;
-    const int kt0 = z * g.k_tiles_per_split;
-    const int kt_total = (g.K + BK - 1) / BK;
-    const int kt1 = min(kt_total, kt0 + g.k_tiles_per_split);
-    const int nk = max(kt1 - kt0, 0);                     // (an empty split-K slice still stores its zero tile)
-
-    if (wave >= 4) {
-        if (nk == 0) return;
-        // ---------------- loader waves ----------------
-        // the 12 DMA pieces of this wave: piece id = lw + 4 i  ->  operand (id / 24), plane ((id / 8) % 3), 1 KB
-        // piece (id % 8) of the plane's 8 KB tile.  Source pointers advance by a uniform stride per k-tile.
-        const int lw = wave - 4;
-        const __bf16* src[P3_PER];
-        int dst[P3_PER];
-#pragma unroll
-        for (int i = 0; i < P3_PER; ++i) {
-            const int id = lw + P3_LOADERS * i;
-            const int opnd = id / 24, plane = (id / 8) % 3, piece = id % 8;
-            const bool tr = opnd ? B_TR : A_TR;
-            const __bf16* base = (opnd ? pa.B + plane * pa.b_plane : pa.A + plane * pa.a_plane);
-            const int ld = opnd ? pa.ldb : pa.lda;
-            const int r0 = opnd ? n0 : m0;
-            size_t off;
-            if (!tr) {                                   // rows r0 + 16 piece + (lane >> 2), 64 B of k per row
-                const int row = 16 * piece + (lane >> 2);
-                const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-                off = (size_t)(r0 + row) * ld + (size_t)kt0 * BK + chunk * 8;
-            } else {                                     // k rows 4 piece + (lane >> 4), 256 B of columns per row
-                const int kk = 4 * piece + (lane >> 4);
-                const int log16 = (lane & 15) ^ (4 * (kk & 3));
-                off = (size_t)(kt0 * BK + kk) * ld + r0 + log16 * 8;
-            }
-            src[i] = base + off;
-            dst[i] = (opnd * 3 + plane) * 8192 + piece * 1024;
-        }
-        const size_t a_step = A_TR ? (size_t)BK * pa.lda : (size_t)BK;
-        const size_t b_step = B_TR ? (size_t)BK * pa.ldb : (size_t)BK;
-        auto issue_all = [&](int slot) {
-            char* base = ring + slot * P3_STAGE;
-#pragma unroll
-            for (int i = 0; i < P3_PER; ++i) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
-                                                 (__attribute__((address_space(3))) void*)(base + dst[i]), 16, 0, 0);
-                src[i] += ((lw + P3_LOADERS * i) / 24) ? b_step : a_step;
-            }
-        };
-        issue_all(0);
-        if (nk > 1) {
-            issue_all(1);
-            if constexpr (P3_PER == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();                                     // barrier -1: tile 0 visible
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 2 < nk) {
-                issue_all((kt + 2) % P3_SLOTS);
-                if constexpr (P3_PER == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();                                 // barrier kt: tile kt + 1 visible
-        }
-        return;
-    }
-
-    // ---------------- MFMA waves ----------------
-    const int wm = wave >> 1, wn = wave & 1;
-    // byte offsets of this lane's fragment reads inside a plane's 8 KB image: K-contiguous [t][slab], K-strided [t][q]
-    // (slab 1 of a K-strided image is 16 k rows = 4096 bytes further)
-    int offA[2][2], offB[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if constexpr (!A_TR) {
-                const int row = wm * 64 + 32 * t + (lane & 31);
-                offA[t][u] = row * 64 + (((2 * u + (lane >> 5)) ^ ((row >> 2) & 3)) * 16);
-            } else {
-                const int sl = lane & 15;
-                const int col = wm * 64 + 32 * t + 16 * ((lane >> 4) & 1) + 4 * (sl & 3);
-                const int kk = 8 * (lane >> 5) + 4 * u + (sl >> 2);
-                offA[t][u] = kk * 256 + (((col >> 3) ^ (4 * (kk & 3))) * 16) + ((col >> 2) & 1) * 8;
-            }
-            if constexpr (!B_TR) {
-                const int row = wn * 64 + 32 * t + (lane & 31);
-                offB[t][u] = row * 64 + (((2 * u + (lane >> 5)) ^ ((row >> 2) & 3)) * 16);
-            } else {
-                const int sl = lane & 15;
-                const int col = wn * 64 + 32 * t + 16 * ((lane >> 4) & 1) + 4 * (sl & 3);
-                const int kk = 8 * (lane >> 5) + 4 * u + (sl >> 2);
-                offB[t][u] = kk * 256 + (((col >> 3) ^ (4 * (kk & 3))) * 16) + ((col >> 2) & 1) * 8;
-            }
-        }
-    auto frag_tr = [&](const char* img, const int (&off)[2], int slab) {
-        bf16x8 r;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4*)(img + off[q] + slab * 4096));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r[4 * q + j] = __builtin_bit_cast(__bf16, (short)v[j]);
-        }
-        return r;
-    };
-    // fragment index = operand + 2 * t + 4 * plane (as in mfma_tile_ld)
-    auto read_frag = [&](auto frc, bf16x8 (&F)[12], const char* st, auto slabc) {
-        constexpr int fr = frc.value, op = fr & 1, t = (fr >> 1) & 1, p = fr >> 2, slab = slabc.value;
-        if constexpr (op == 0) {
-            if constexpr (!A_TR) F[fr] = *reinterpret_cast<const bf16x8*>(st + p * 8192 + offA[t][slab]);
-            else F[fr] = frag_tr(st + p * 8192, offA[t], slab);
-        } else {
-            if constexpr (!B_TR) F[fr] = *reinterpret_cast<const bf16x8*>(st + (3 + p) * 8192 + offB[t][slab]);
-            else F[fr] = frag_tr(st + (3 + p) * 8192, offB[t], slab);
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    constexpr int ORDER[12] = {8, 1, 3, 10, 4, 5, 7, 6, 0, 9, 11, 2};     // order in which the term pairs consume them
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    bf16x8 F0[12], F1[12];
-    if (nk > 0) __builtin_amdgcn_s_barrier();                             // barrier -1: tile 0 visible
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* st = ring + (kt % P3_SLOTS) * P3_STAGE;
-        static_for<0, 12>([&](auto n) { read_frag(std::integral_constant<int, ORDER[n.value]>{}, F0, st, I0{}); });
-        static_for<0, 48>([&](auto gc) {
-            constexpr int gI = gc.value, w = gI % 24, q = w >> 2, i = (w >> 1) & 1, j = w & 1;
-            if constexpr (gI < 24)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F0[2 * i + 4 * PA[q]], F0[1 + 2 * j + 4 * PB[q]], acc[i][j], 0, 0, 0);
-            else
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F1[2 * i + 4 * PA[q]], F1[1 + 2 * j + 4 * PB[q]], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (gI < 12) read_frag(std::integral_constant<int, ORDER[gI]>{}, F1, st, I1{});
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        // every LDS read of tile kt has returned (they were issued >= 36 MFMAs ago): the DMA that the loaders aim
-        // at this slot after the barrier cannot overtake them
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                     // barrier kt
-    }
-    store_tile(g, m0, n0, z, wm, wn, lane, acc);
-}
-
 // ------------------------------------------------------------------------------------------------------
 // bf16-STORAGE GEMM (renet_gemm_bf16s, BASELINE config 5 "n_hidden=400 bf16"): both operands are bf16 matrices in
-// HBM ([Rp][Cp], padded with zeros to multiples of 128 like a plane of the planes GEMM), ONE product per fragment
-// pair, fp32 accumulation.  Same LDS-DMA ring, wave specialisation, images and swizzles as gemm_planes_kernel; a
-// ring slot holds TWO 32-wide k sub-tiles per operand (4 x 8 KB = 32 KB per slot, 3 slots) where the planes kernel
-// holds three planes, so a stage is 128 x 128 x 64: 16 MFMAs per MFMA wave and barrier.  With one product per
+// HBM ([Rp][Cp], padded with zeros to multiples of 128), ONE product per fragment
+// pair, fp32 accumulation.  The LDS-DMA ring, wave specialisation, images and swizzles described above; a
+// ring slot holds TWO 32-wide k sub-tiles per operand (4 x 8 KB = 32 KB per slot, 3 slots), so a stage is 128 x 128 x 64: 16 MFMAs per MFMA wave and barrier.  With one product per
 // element pair the k-loop moves 16 KB of operands per 1 MFLOP: the kernel is bound by the L2 -> LDS stream, not by
 // the matrix pipe.  Either operand may be consumed K-contiguous or K-strided (ds_read_b64_tr_b16).
 // ------------------------------------------------------------------------------------------------------
@@ -1369,39 +1187,6 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
     }
 }
 
-// fp32 [R, C] (row stride ldx) -> three bf16 planes [Rp][Cp] each (Rp, Cp = R, C rounded up to 128; the padding is
-// written as zeros here, so the destination needs no initialisation).  x = p0 + p1 + p2 as in store_items.
-__global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restrict__ X, int R, int C, int ldx, int Rp,
-                                                          int Cp, __bf16* __restrict__ P) {
-    const size_t plane = (size_t)Rp * Cp;
-    const size_t total = plane / 4;                       // items of 4 consecutive columns
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int row = (int)(i / (Cp / 4)), c = (int)(i % (Cp / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < R) {
-            const float* x = X + (size_t)row * ldx + c;
-            if (c + 3 < C && ((ldx & 3) == 0)) v = *reinterpret_cast<const float4*>(x);
-            else {
-                if (c < C) v.x = x[0];
-                if (c + 1 < C) v.y = x[1];
-                if (c + 2 < C) v.z = x[2];
-                if (c + 3 < C) v.w = x[3];
-            }
-        }
-        f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const bf16x2 blo = __builtin_convertvector(lo, bf16x2);
-            const bf16x2 bhi = __builtin_convertvector(hi, bf16x2);
-            *reinterpret_cast<uint2*>(P + p * plane + (size_t)row * Cp + c) = pack4(blo, bhi);
-            if (p < 2) {
-                lo -= __builtin_convertvector(blo, f32x2);
-                hi -= __builtin_convertvector(bhi, f32x2);
-            }
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void split_reduce_kernel(const float* __restrict__ partial, int split_k,
                                                            int M, int N, float alpha, float beta,
                                                            const float* __restrict__ bias,
@@ -1452,13 +1237,20 @@ __global__ __launch_bounds__(256) void split_reduce4_kernel(const float* __restr
     }
 }
 
-// RENET_GEMM_TILE_ORDER=0: plain order; =w: panel width of the XCD-aware order (default 8)
+// RENET_GEMM_TILE_ORDER = 0 | 1: plain order | XCD-aware order (default; the SAME boolean gemm.hip reads).  The panel width
+// of the XCD-aware order is a separate knob, RENET_GEMM_PANEL_W = 1..64 (default 8; setting it also pins the width, i.e.
+// panel_width() below leaves it alone).
+bool panel_w_pinned() { return getenv("RENET_GEMM_PANEL_W") != nullptr; }
 int tile_order() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("RENET_GEMM_TILE_ORDER");
-        v = e ? atoi(e) : 8;
-        if (v < 0) v = 0;
+        if (e && e[0] == '0') v = 0;
+        else {
+            const char* w = getenv("RENET_GEMM_PANEL_W");
+            v = w ? atoi(w) : 8;
+            if (v < 1 || v > 64) v = 8;
+        }
     }
     return v;
 }
@@ -1468,9 +1260,9 @@ int tile_order() {
 // misses (PMC, tools/pmc_by_shape.py: the 256-row logits GEMM fetched 313 MB for 60 MB of operands, 258 MB of it the
 // 4.9 MB `feat`).  Narrower panels keep one panel of the short operand resident (<= 2.5 MB) and re-read the long operand
 // once per extra panel: taken when that costs less than the sweep does (so NOT for dW = dlogits^T feat, whose long
-// operand is 189 MB).  An explicit RENET_GEMM_TILE_ORDER, or a split k range, leaves the width alone.
+// operand is 189 MB).  An explicit RENET_GEMM_PANEL_W, the plain order, or a split k range leaves the width alone.
 int panel_width(int base, int nbx, int nby, int tile_m, int K, int split_k, int slots_per_xcd) {
-    if (base != 8 || split_k != 1 || getenv("RENET_GEMM_TILE_ORDER")) return base;
+    if (base != 8 || split_k != 1 || panel_w_pinned()) return base;
     const bool short_is_m = nby <= nbx;
     const int ns = short_is_m ? nby : nbx, nl = short_is_m ? nbx : nby;
     const double slab = (double)(short_is_m ? tile_m : BN) * K * 4.0;           // short-operand bytes of one tile row / column
@@ -1571,20 +1363,6 @@ int kernel_choice(int ntiles) {
 }  // namespace
 
 namespace {
-template <bool A_TR, bool B_TR>
-int launch_planes(const PlanesArgs& pa, dim3 grid, hipStream_t st) {
-    static bool attr_set = false;      // benign race: the attribute is idempotent
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_planes_kernel<A_TR, B_TR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P3_LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    RENET_LAUNCH((gemm_planes_kernel<A_TR, B_TR>), grid, dim3(P3_THREADS), P3_LDS, st, pa);
-    RENET_LAUNCH_CHECK();
-    return RENET_OK;
-}
-
 template <bool A_TR, bool B_TR, bool TALL>
 int launch_bf16s(const Bf16sArgs& pa, dim3 grid, hipStream_t st) {
     constexpr size_t lds = TALL ? B1_LDS_TALL : B1_LDS;
@@ -1678,7 +1456,7 @@ static SplitPlan plan_split(bool bf16_mode, int ta, int tb, int M, int N, int K,
     return p;
 }
 
-static int gemm_planes_launch(bool bf16_mode, int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
+static int gemm_split_launch(bool bf16_mode, int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
                               const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                               int split_k, float* workspace, size_t workspace_bytes, void* stream) {
     if (M < 0 || N < 0 || K < 1 || lda <= 0 || ldb <= 0 || ldc < N) return RENET_ERR_BADARG;
@@ -1753,7 +1531,7 @@ static int gemm_planes_launch(bool bf16_mode, int ta, int tb, int M, int N, int 
 int renet_gemm_f32_split(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
                          const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                          int split_k, float* workspace, size_t workspace_bytes, void* stream) {
-    return gemm_planes_launch(false, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, split_k, workspace,
+    return gemm_split_launch(false, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, split_k, workspace,
                               workspace_bytes, stream);
 }
 
@@ -1770,7 +1548,7 @@ int renet_gemm_split_plan(int ta, int tb, int M, int N, int K, const float* A, i
 int renet_gemm_bf16(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
                     const float* B, int ldb, float beta, float* C, int ldc, const float* bias,
                     int split_k, float* workspace, size_t workspace_bytes, void* stream) {
-    return gemm_planes_launch(true, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, split_k, workspace,
+    return gemm_split_launch(true, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, split_k, workspace,
                               workspace_bytes, stream);
 }
 
@@ -1815,7 +1593,7 @@ int renet_gemm_f32_h3(int ta, int tb, int M, int N, int K, float alpha, const fl
     // the bf16x6 kernels (same accuracy class, no bounds needed)
     const bool small_ok = (size_t)(ta ? K : M) * lda < ((size_t)1 << 30) && (size_t)(tb ? N : K) * ldb < ((size_t)1 << 30);
     if (!small_ok || ((split_k <= 1) && skinny_enabled() && renet_gemm_skinny_eligible(ta, M, N, K, A, lda, B, ldb, tb)))
-        return gemm_planes_launch(false, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, split_k, workspace,
+        return gemm_split_launch(false, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, split_k, workspace,
                                   workspace_bytes, stream);
     if (split_k < 1) split_k = 1;
     const int kt_total = (K + BK - 1) / BK;
@@ -1943,71 +1721,6 @@ int renet_gemm_bf16s(int a_tr, int b_tr, int M, int N, int K, float alpha, const
         else if (a_tr && !b_tr) e = launch_bf16s<true, false, false>(pa, grid, st);
         else e = launch_bf16s<true, true, false>(pa, grid, st);
     }
-    if (e != RENET_OK) return e;
-    if (split_k > 1) {
-        const size_t total = (size_t)M * N;
-        if (total <= (size_t)256 * 1024 && split_k >= 8) {
-            RENET_LAUNCH(split_reduce4_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, workspace,
-                               split_k, M, N, alpha, beta, bias, C, ldc);
-        } else {
-            int blocks = (int)min((size_t)2048, (total + 255) / 256);
-            RENET_LAUNCH(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, split_k, M, N, alpha,
-                               beta, bias, C, ldc);
-        }
-        RENET_LAUNCH_CHECK();
-    }
-    return RENET_OK;
-}
-
-size_t renet_planes_bytes(int R, int C) {
-    const size_t rp = ((size_t)R + 127) & ~(size_t)127, cp = ((size_t)C + 127) & ~(size_t)127;
-    return 3 * rp * cp * sizeof(__bf16);
-}
-
-int renet_pack_planes(const float* X, int R, int C, int ldx, void* planes, void* stream) {
-    if (R < 0 || C < 0 || ldx < C || !planes) return RENET_ERR_BADARG;
-    const int Rp = (R + 127) & ~127, Cp = (C + 127) & ~127;
-    if (Rp == 0 || Cp == 0) return RENET_OK;
-    const size_t total = (size_t)Rp * Cp / 4;
-    const int blocks = (int)min((size_t)4096, (total + 255) / 256);
-    RENET_LAUNCH(pack_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, R, C, ldx, Rp, Cp,
-                 (__bf16*)planes);
-    RENET_LAUNCH_CHECK();
-    return RENET_OK;
-}
-
-int renet_gemm_planes(int a_tr, int b_tr, int M, int N, int K, float alpha, const void* Ap, int lda, const void* Bp,
-                      int ldb, float beta, float* C, int ldc, const float* bias, int split_k, float* workspace,
-                      size_t workspace_bytes, void* stream) {
-    if (M < 0 || N < 0 || K < 1 || ldc < N || !Ap || !Bp) return RENET_ERR_BADARG;
-    if (M == 0 || N == 0) return RENET_OK;
-    const int Mp = (M + 127) & ~127, Np = (N + 127) & ~127, Kp = (K + 127) & ~127;
-    // plane shapes: K-contiguous [Mp][Kp] (ld >= Kp), K-strided [Kp][Mp] (ld >= Mp)
-    if (lda < (a_tr ? Mp : Kp) || ldb < (b_tr ? Np : Kp) || (lda & 7) || (ldb & 7)) return RENET_ERR_BADARG;
-    if (split_k < 1) split_k = 1;
-    const int kt_total = (K + BK - 1) / BK;
-    if (split_k > kt_total) split_k = max(kt_total, 1);
-    if (split_k > 1 && workspace_bytes < renet_gemm_workspace(M, N, split_k)) return RENET_ERR_WORKSPACE;
-    PlanesArgs pa;
-    pa.A = (const __bf16*)Ap; pa.B = (const __bf16*)Bp;
-    pa.lda = lda; pa.ldb = ldb;
-    pa.a_plane = (size_t)(a_tr ? Kp : Mp) * lda;
-    pa.b_plane = (size_t)(b_tr ? Kp : Np) * ldb;
-    SplitArgs& g = pa.out;
-    g.A = nullptr; g.B = nullptr; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
-    g.lda = 0; g.ldb = 0; g.ldc = ldc; g.alpha = alpha; g.beta = beta;
-    g.split_k = split_k;
-    g.k_tiles_per_split = max(1, (kt_total + split_k - 1) / split_k);
-    g.partial = workspace;
-    g.xcd_order = tile_order();
-    hipStream_t st = (hipStream_t)stream;
-    const int nbx = (N + BN - 1) / BN, nby = (M + BM - 1) / BM;
-    dim3 grid(nbx, nby, split_k);
-    int e;
-    if (!a_tr && !b_tr) e = launch_planes<false, false>(pa, grid, st);
-    else if (!a_tr && b_tr) e = launch_planes<false, true>(pa, grid, st);
-    else if (a_tr && !b_tr) e = launch_planes<true, false>(pa, grid, st);
-    else e = launch_planes<true, true>(pa, grid, st);
     if (e != RENET_OK) return e;
     if (split_k > 1) {
         const size_t total = (size_t)M * N;

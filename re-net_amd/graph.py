@@ -834,7 +834,7 @@ class _HostView(object):
         self.__dict__.update(pb.host_small)
 
 
-_async_h2d = [False]
+_async_h2d = threading.local()          # .on: per THREAD (builder / prefetch threads keep the blocking copy)
 
 
 @contextlib.contextmanager
@@ -843,12 +843,12 @@ def async_uploads(on=True):
     RENet._joint_topk_many).  Off by default: pinned staging buffers come from torch's caching host allocator, and a
     loop that uploads hundreds of batches without ever synchronising (bench.py preparing its steps, the prefetch
     pipeline) finds no free cached block and pays a hipHostMalloc per upload (measured: host_build_ms 13 -> 43)."""
-    old = _async_h2d[0]
-    _async_h2d[0] = bool(on) and _os.environ.get('RENET_ASYNC_H2D', '1') != '0'
+    old = getattr(_async_h2d, 'on', False)
+    _async_h2d.on = bool(on) and _os.environ.get('RENET_ASYNC_H2D', '1') != '0'
     try:
         yield
     finally:
-        _async_h2d[0] = old
+        _async_h2d.on = old
 
 
 def h2d(a, device):
@@ -857,7 +857,7 @@ def h2d(a, device):
     waits for everything queued on the stream -- in the inference advance that serialised host batch building and
     device work chunk by chunk); larger arrays, and everything outside such a scope, use the plain blocking copy."""
     t = torch.from_numpy(np.ascontiguousarray(a))
-    if not _async_h2d[0] or torch.device(device).type != 'cuda' or t.numel() == 0 or \
+    if not getattr(_async_h2d, 'on', False) or torch.device(device).type != 'cuda' or t.numel() == 0 or \
             t.numel() * t.element_size() > (1 << 20):
         return t.to(device)
     pinned = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)

@@ -2,6 +2,7 @@
 run hand-written HIP kernels; torch only owns the tensors and wires the graph.  No CPU / eager
 fallback exists: on a non-HIP tensor these raise."""
 import contextlib
+import threading
 import functools
 import ctypes
 import os
@@ -53,14 +54,18 @@ class _Side(object):
 # HipAdam.step() calls join_deferred() before it reads a gradient.  Outside such a scope (train.py's own loop with
 # clip_grad_norm_ + torch Adam) every Function joins before it returns, as before.  Tensors the deferred kernels read
 # are handed to the allocator with record_stream, so that freeing them on the main stream cannot recycle their memory
-# under the side stream.
+# under the side stream -- and EVERYTHING the deferred kernels read (those tensors, the batch graph with its index arrays and
+# item plans, operand shells with their bound partials) is also kept alive by a strong reference in `_deferred` until
+# join_deferred() has made the main stream wait: a caller that drops `loss` or the prepared batch between backward() and
+# step() cannot let the allocator recycle memory the side stream is still reading.
 DEFER_WEIGHT_GRADS = False
-_deferred = []             # (main stream, side stream) pairs with un-joined side work
+_deferred = []             # (main stream, side stream, keep-alive objects) of un-joined side work
 
 
-def _deferred_scope(device, tensors):
+def _deferred_scope(device, tensors, keep=()):
     """-> a _Side whose stream takes gradient-only work that stays UN-JOINED until join_deferred() (None when deferral
-    is off or no side stream exists).  `tensors`: what that work reads and the caller frees afterwards."""
+    is off or no side stream exists).  `tensors`: what that work reads and the caller frees afterwards; `keep`: further
+    objects (the DeviceGraph, operand shells) whose device memory the work reads."""
     if not DEFER_WEIGHT_GRADS:
         return None
     sd = _Side(device)
@@ -69,15 +74,17 @@ def _deferred_scope(device, tensors):
     for t in tensors:
         if isinstance(t, torch.Tensor) and t.is_cuda:
             t.record_stream(sd.side)
-    _deferred.append((sd.main, sd.side))
+    _deferred.append((sd.main, sd.side, (list(tensors), list(keep))))
     return sd
 
 
 def join_deferred():
-    """Make every stream that forked deferred work wait for it (no-op if nothing is pending)."""
+    """Make every stream that forked deferred work wait for it (no-op if nothing is pending); the kept objects are
+    released after the wait has been enqueued (their memory returns to the allocator on the main stream, behind it)."""
     while _deferred:
-        main, side = _deferred.pop()
+        main, side, keep = _deferred.pop()
         main.wait_stream(side)
+        del keep
 
 
 def _rank():
@@ -90,7 +97,7 @@ def _rank():
 # every rank for the N-rank step to equal the 1-rank step; the per-sequence sites (sequence assembly, score heads) act
 # on rows only this rank owns and keep rank-dependent seeds.  Set by the caller that shards a batch that way.
 SHARED_GRAPH_SEEDS = False       # process default; a sharded batch sets it for ITS forward pass only (shared_graph_seeds)
-_shared_tls = None
+_shared_tls = threading.local()  # .flag: the scope's value on THIS thread (seeds are drawn in forward, on the caller's thread)
 
 
 @contextlib.contextmanager
@@ -99,13 +106,12 @@ def shared_graph_seeds(flag):
     with shard=(rank, world)): the graph-side dropout sites draw rank-independent seeds inside this scope.  Seeds are
     only drawn in forward (the backward pass replays them from ctx), so a scope around the forward call suffices; the
     flag travels with the prepared batch instead of a module global that a caller has to set per step (review r3)."""
-    global _shared_tls
-    old = _shared_tls
-    _shared_tls = bool(flag)
+    old = getattr(_shared_tls, 'flag', None)
+    _shared_tls.flag = bool(flag)
     try:
         yield
     finally:
-        _shared_tls = old
+        _shared_tls.flag = old
 
 
 def next_seed(graph_site=False):
@@ -114,7 +120,8 @@ def next_seed(graph_site=False):
     correlate the ranks' dropout noise) and a per-process site counter.  graph_site: a site on the batch GRAPH --
     rank-independent when the ranks replicate one graph (SHARED_GRAPH_SEEDS)."""
     _seed_state['counter'] += 1
-    shared = SHARED_GRAPH_SEEDS if _shared_tls is None else _shared_tls
+    scoped = getattr(_shared_tls, 'flag', None)
+    shared = SHARED_GRAPH_SEEDS if scoped is None else scoped
     rank = 0 if (graph_site and shared) else _rank()
     x = torch.initial_seed() * 0x9E3779B1 + (rank + 1) * 0xC2B2AE3D27D4EB4F + _seed_state['counter'] * 0x85EBCA77
     return x & 0x7FFFFFFFFFFFFFFF
@@ -298,7 +305,8 @@ class RGCNLayerFn(Function):
         # the relation-block and self-loop weight gradients feed only the optimizer, and nothing else writes their
         # buffers: inside a declared step they run on the side stream, un-joined, under the rest of the backward pass
         sd = _deferred_scope(h.device, (h, gn, g_loop, getattr(gl_op, 'p', None), getattr(gl_op, 'part', None),
-                                        getattr(h_op, 'p', None))) \
+                                        getattr(h_op, 'p', None), getattr(h_op, 'part', None), getattr(h_op, 't', None),
+                                        getattr(gl_op, 't', None)), keep=(g, h_op, gl_op, weight_grads)) \
             if (acc and tgt_loop is not None and K.current_mode() != 'bf16s') else None
         if sd is not None:
             if isinstance(gl_op, K.F32Op):
@@ -368,7 +376,7 @@ class RGCNTableLayerFn(Function):
         acc = tgt_w is not None
         d_w = tgt_w if acc else torch.empty_like(weight)
         e_src_t = g.table_items()[3]
-        sd = _deferred_scope(dev, (gn,)) if acc else None               # (see RGCNLayerFn.backward)
+        sd = _deferred_scope(dev, (gn, e_src_t), keep=(g, table)) if acc else None      # (see RGCNLayerFn.backward)
         with (sd() if sd is not None else contextlib.nullcontext()):
             K.rgcn_bwd_w(table, gn, e_src_t, g.e_dst, g.chunk_ptr, g.chunk_type, g.n_chunks, g.type_chunk_ptr,
                          g.num_types, ctx.shift, d_w, beta=1.0 if acc else 0.0)
@@ -581,7 +589,7 @@ class MultiGRUFn(Function):
                     t.record_stream(sd.side)
             for k in range(n):
                 res[k] = [input_grad(k, ops_[k]), None, None, None, None]
-            _deferred.append((sd.main, sd.side))
+            _deferred.append((sd.main, sd.side, (list(d_gis), list(d_ghs), list(xs), list(svs), live_ops)))
             out = [None, None, None]
             for k in range(n):
                 out += res[k]

@@ -196,6 +196,43 @@ def shard_indices(perm, step, rank, world, batch_size):
     return perm[start:start + batch_size]
 
 
+class ScalingMode(object):
+    """How ONE data-parallel step divides its quadruples over the ranks and combines their gradients -- the bookkeeping
+    bench.py's three modes (and a training loop) share, kept here so that it is tested without a GPU
+    (tests/test_parallel_cpu.py):
+
+      weak   : every rank takes its own `batch` quadruples (global batch = batch * world), each rank builds its own batch
+               graph, gradients are AVERAGED (SURVEY 8e option (ii): the reference's semantics at batch size `batch`)
+      strong : `batch` quadruples per step in total, batch // world per rank (each rank its own, smaller, reference batch;
+               global batch = (batch // world) * world), gradients averaged
+      exact  : ONE reference batch of `batch` quadruples per step; every rank builds ITS graph (same on every rank) and keeps
+               1 / world of the sequences (graph.shard_sequences), gradients and losses are SUMMED -- the N-rank step
+               equals the 1-rank step on that batch (SURVEY 8e option (i)); reported as scaling "strong"."""
+
+    MODES = ('weak', 'strong', 'exact')
+
+    def __init__(self, scaling, batch, world, passes='merged'):
+        if scaling not in self.MODES:
+            raise ValueError('scaling must be one of %s' % (self.MODES,))
+        self.scaling, self.world = scaling, int(world)
+        self.exact = scaling == 'exact'
+        self.rank_batch = int(batch) if scaling in ('weak', 'exact') else max(1, int(batch) // self.world)
+        self.global_batch = int(batch) if self.exact else self.rank_batch * self.world
+        self.average = not self.exact                 # exact: per-rank losses are partial sums of the batch mean
+        self.passes = 'merged' if self.exact else passes
+        self.reported_scaling = 'strong' if scaling in ('strong', 'exact') else 'weak'
+
+    def indices(self, perm, step, rank):
+        """The quadruple indices rank `rank` builds its batch from at global step `step`."""
+        if self.exact:
+            return shard_indices(perm, step, 0, 1, self.rank_batch)          # the same reference batch on every rank
+        return shard_indices(perm, step, rank, self.world, self.rank_batch)
+
+    def shard(self, rank):
+        """`shard=` argument of RENet.prepare_both: which sequences of the shared batch this rank keeps (exact mode)."""
+        return (rank, self.world) if (self.exact and self.world > 1) else None
+
+
 class FlatParams(object):
     """Moves every parameter of `module` into ONE contiguous buffer (param.data become views), in the same
     order as FlatGrads, so that the optimizer is a single fused kernel over flat buffers."""

@@ -7,6 +7,7 @@ There is NO fallback: if the library is missing or a call fails, this raises.
 import contextlib
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -64,16 +65,12 @@ _SIGNATURES = {
     'renet_gemm_bf16': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                 c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'renet_gemm_split_plan': (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
-    'renet_planes_bytes': (c_size_t, [c_int, c_int]),
     'renet_maxabs_blocks': (c_int, [c_int, c_int, c_int]),
     'renet_maxabs_partials_multi': (c_int, [c_void_p, c_int, c_void_p]),
     'renet_maxabs_partials': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'renet_gemm_f32_h3': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
                                   c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_int,
                                   c_void_p, c_int, c_void_p]),
-    'renet_pack_planes': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    'renet_gemm_planes': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
-                                  c_float, c_void_p, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'renet_bf16_bytes': (c_size_t, [c_int, c_int]),
     'renet_pack_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'renet_gemm_bf16s': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_int,
@@ -554,12 +551,13 @@ GEMM_MODE = os.environ.get('RENET_GEMM', 'bf16x6')
 # through current_mode().  GEMM_MODE stays the PROCESS default, and the two modes that change more than the GEMM entry
 # point -- 'f32' (the GRU recurrences pick their exact kernels inside the library from RENET_GEMM) and 'bf16s' (operand
 # storage) -- remain process-wide: gemm_mode() accepts them only when they equal the process default.
-_mode_override = [None]
+_mode_override = threading.local()       # .mode: per THREAD (a prefetch / evaluation thread must not inherit another thread's
+                                         # scope; ops._fwd_mode / _bwd_mode re-enter the scope on the autograd thread explicitly)
 _PER_MODEL_MODES = ('bf16x6', 'f16x3')
 
 
 def current_mode():
-    return _mode_override[0] or GEMM_MODE
+    return getattr(_mode_override, 'mode', None) or GEMM_MODE
 
 
 @contextlib.contextmanager
@@ -571,12 +569,12 @@ def gemm_mode(mode):
     if mode not in _PER_MODEL_MODES or GEMM_MODE not in _PER_MODEL_MODES:
         raise RenetHipError('gemm_mode(%r): only %s can be chosen per model, and only in a process whose default is one '
                             'of them (RENET_GEMM=%s)' % (mode, ' / '.join(_PER_MODEL_MODES), GEMM_MODE))
-    old = _mode_override[0]
-    _mode_override[0] = mode
+    old = getattr(_mode_override, 'mode', None)
+    _mode_override.mode = mode
     try:
         yield
     finally:
-        _mode_override[0] = old
+        _mode_override.mode = old
 
 
 class BF16Mat(object):
@@ -961,57 +959,6 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, beta=0.0, spl
                   ws_bytes, _stream()), 'gemm_f32')
     if t0 is not None:
         _timer.end('gemm_f32', t0, flops=2.0 * m * n * k, tag=(int(ta), int(tb), m, n, k, split_k))
-    return out
-
-
-class Planes(object):
-    """Three bf16 planes of an fp32 matrix [R, C] (x = p0 + p1 + p2), each [Rp, Cp] with Rp, Cp multiples of 128 and
-    zero padding: the operand format of gemm_planes (renet_pack_planes)."""
-    __slots__ = ('p', 'R', 'C')
-
-    def __init__(self, p, R, C):
-        self.p, self.R, self.C = p, R, C
-
-
-def pack_planes(x, out=None):
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
-        raise RenetHipError('pack_planes needs a 2-D float32 device tensor with unit inner stride')
-    r, c = x.shape
-    rp, cp = (r + 127) & ~127, (c + 127) & ~127
-    p = out.p if out is not None else torch.empty(3, rp, cp, device=x.device, dtype=torch.bfloat16)
-    if tuple(p.shape) != (3, rp, cp):
-        raise RenetHipError('pack_planes: destination has the wrong shape')
-    t0 = _timer.begin() if _timer is not None else None
-    _check(lib().renet_pack_planes(x.data_ptr(), r, c, x.stride(0), p.data_ptr(), _stream()), 'pack_planes')
-    if t0 is not None:
-        _timer.end('pack_planes', t0, nbytes=float(r * c * 4 + 3 * rp * cp * 2))
-    return Planes(p, r, c)
-
-
-def gemm_planes(pa, a_tr, pb, b_tr, out=None, bias=None, alpha=1.0, beta=0.0, split_k=None):
-    """out = alpha * op(A) @ op(B) + bias + beta * out on pre-split operands (include/renet_hip.h):
-    a_tr False: pa holds A [M, K];  True: pa holds A^T [K, M].   b_tr False: pb holds B^T [N, K];  True: B [K, N]."""
-    m, k = (pa.C, pa.R) if a_tr else (pa.R, pa.C)
-    n, k2 = (pb.C, pb.R) if b_tr else (pb.R, pb.C)
-    if k != k2:
-        raise RenetHipError('gemm_planes inner dimensions differ: %d vs %d' % (k, k2))
-    if out is None:
-        if beta != 0.0:
-            raise RenetHipError('beta != 0 needs an output tensor')
-        out = torch.empty(m, n, device=pa.p.device, dtype=torch.float32)
-    if split_k is None:
-        split_k = auto_split_k(m, n, k)
-    ws_ptr, ws_bytes = None, 0
-    if split_k > 1:
-        ws_bytes = lib().renet_gemm_workspace(m, n, split_k)
-        ws = torch.empty(ws_bytes // 4, device=out.device, dtype=torch.float32)
-        ws_ptr = ws.data_ptr()
-    t0 = _timer.begin() if _timer is not None else None
-    _check(lib().renet_gemm_planes(int(a_tr), int(b_tr), m, n, k, float(alpha), pa.p.data_ptr(), pa.p.shape[2],
-                                   pb.p.data_ptr(), pb.p.shape[2], float(beta), out.data_ptr(), _ld(out), _f32(bias),
-                                   split_k, ws_ptr, ws_bytes, _stream()), 'gemm_planes')
-    if t0 is not None:
-        _timer.end('gemm_f32', t0, flops=2.0 * m * n * k)
     return out
 
 

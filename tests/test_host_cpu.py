@@ -457,7 +457,7 @@ def test_gemm_dispatch_plan_of_the_bench_shapes():
     """renet_gemm_split_plan: the launcher's own decision function (csrc/gemm_split.hip plan_split), queried without a GPU.
     Pins what DESIGN / profiles say the step's GEMMs run on: kernel family, loader, tile order, grid."""
     import renet_hip as K
-    if os.environ.get('RENET_GEMM_TILE_ORDER') or os.environ.get('RENET_GEMM_TALL') or os.environ.get('RENET_GEMM_KERNEL'):
+    if os.environ.get('RENET_GEMM_TILE_ORDER') or os.environ.get('RENET_GEMM_PANEL_W') or os.environ.get('RENET_GEMM_TALL') or os.environ.get('RENET_GEMM_KERNEL'):
         pytest.skip('dispatch knobs set in the environment')
     S = 15439
     logits = K.gemm_split_plan(0, 1, 2048, 23033, 600)

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -348,3 +349,105 @@ def test_bench_starts_its_own_ranks_when_no_launcher_is_around():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     assert line['n_gpus'] == 1 and line['gpus_arg'] == 2
+
+
+# ---------------------------------------------------------------------------------------------
+# parallel.ScalingMode -- the bookkeeping bench.py's three scaling modes share (which quadruples a rank takes, the global
+# batch a line reports, whether gradients are averaged or summed) -- and the three modes END TO END on two gloo ranks over
+# the emulated wrappers: weak / strong == one process accumulating the ranks' batches and averaging; exact == the 1-rank step.
+# ---------------------------------------------------------------------------------------------
+def test_scaling_mode_bookkeeping():
+    perm = np.random.RandomState(0).permutation(100000)
+    for world in (1, 2, 4, 8):
+        weak, strong, exact = (parallel.ScalingMode(s, 1024, world) for s in ('weak', 'strong', 'exact'))
+        assert (weak.rank_batch, weak.global_batch, weak.average, weak.reported_scaling) == (1024, 1024 * world, True, 'weak')
+        assert (strong.rank_batch, strong.global_batch, strong.average) == (1024 // world, 1024, True)
+        assert (exact.rank_batch, exact.global_batch, exact.average) == (1024, 1024, False)
+        assert strong.reported_scaling == exact.reported_scaling == 'strong'
+        assert exact.passes == 'merged' and parallel.ScalingMode('weak', 1024, world, passes='pair').passes == 'pair'
+        for step in (0, 3):
+            got = {m.scaling: [m.indices(perm, step, r) for r in range(world)] for m in (weak, strong, exact)}
+            for name, m in (('weak', weak), ('strong', strong)):
+                allq = np.concatenate(got[name])
+                assert len(allq) == m.global_batch == len(np.unique(allq))          # disjoint shards, global batch covered
+            for r in range(world):
+                assert np.array_equal(got['exact'][r], got['exact'][0]) and len(got['exact'][r]) == 1024
+                assert exact.shard(r) == ((r, world) if world > 1 else None)
+            assert weak.shard(0) is None and strong.shard(0) is None
+        # consecutive steps of the weak mode never hand two ranks the same slice
+        a = np.concatenate([weak.indices(perm, 0, r) for r in range(world)] + [weak.indices(perm, 1, r) for r in range(world)])
+        assert len(np.unique(a)) == len(a)
+    with pytest.raises(ValueError):
+        parallel.ScalingMode('linear', 1024, 2)
+
+
+def _mode_step(net, flat, quads, gd, hs, ho, idx, shard):
+    prep = net.prepare_both(quads[idx], hs.take(idx), ho.take(idx), gd, shard=shard)
+    loss = net.loss_prepared_both(prep)
+    loss.backward()
+    return float(loss)
+
+
+def _scaling_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cpu_abi_emulation
+    cpu_abi_emulation.install()
+    import ops
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    net, quads, gd, hs, ho, perm = _renet_setup()
+    flat = parallel.FlatGrads(net)
+    early = [p for n, p in net.named_parameters() if n in ('linear.weight', 'linear.bias')]
+    red = parallel.OverlapReducer(flat, flat.span(('linear.weight', 'linear.bias'), net), early)
+    ops.register_grad_done_hook(early, red.on_grad_done)
+    res = {}
+    for scaling in parallel.ScalingMode.MODES:
+        mode = parallel.ScalingMode(scaling, 96, world)
+        flat.zero()
+        red.begin_step(head_passes=1, average=mode.average)
+        loss = _mode_step(net, flat, quads, gd, hs, ho, mode.indices(perm, 1, rank), mode.shard(rank))
+        red.finish()
+        lsum = torch.tensor([loss])
+        dist.all_reduce(lsum)
+        res[scaling] = {'flat': flat.flat.clone(), 'loss_sum': float(lsum), 'global_batch': mode.global_batch,
+                        'rank_batch': mode.rank_batch}
+    torch.save(res, out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_scaling_modes_on_two_ranks_equal_their_single_process_definitions(tmp_path):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    world, port, out = 2, _free_port(), str(tmp_path / 'm%d.pt')
+    mp.spawn(_scaling_worker, args=(world, port, out), nprocs=world, join=True)
+    got = [torch.load(out % r) for r in range(world)]
+    import cpu_abi_emulation
+    undo = cpu_abi_emulation.install()
+    try:
+        net, quads, gd, hs, ho, perm = _renet_setup()
+        flat = parallel.FlatGrads(net)
+        for scaling in parallel.ScalingMode.MODES:
+            assert torch.equal(got[0][scaling]['flat'], got[1][scaling]['flat']), scaling     # every rank ends with the same gradient
+            mode = parallel.ScalingMode(scaling, 96, world)
+            assert got[0][scaling]['global_batch'] == {'weak': 192, 'strong': 96, 'exact': 96}[scaling]
+            assert got[0][scaling]['rank_batch'] == {'weak': 96, 'strong': 48, 'exact': 96}[scaling]
+            if mode.exact:                     # == the ONE-rank step on the same reference batch: loss and gradient
+                flat.zero()
+                loss = _mode_step(net, flat, quads, gd, hs, ho, parallel.ScalingMode('exact', 96, 1).indices(perm, 1, 0), None)
+                ref, ref_loss = flat.flat.clone(), loss
+                assert abs(got[0][scaling]['loss_sum'] - ref_loss) <= 2e-6 * abs(ref_loss)
+            else:                              # == the mean of the ranks' own batches
+                acc, ref_loss = torch.zeros_like(flat.flat), 0.0
+                for rank in range(world):
+                    flat.zero()
+                    ref_loss += _mode_step(net, flat, quads, gd, hs, ho, mode.indices(perm, 1, rank), None)
+                    acc += flat.flat
+                ref = acc / world
+                assert abs(got[0][scaling]['loss_sum'] - ref_loss) <= 2e-6 * abs(ref_loss)
+            scale = float(ref.abs().max())
+            assert float((got[0][scaling]['flat'] - ref).abs().max()) <= 1e-5 * scale, scaling
+    finally:
+        undo()
