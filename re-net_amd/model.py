@@ -124,6 +124,9 @@ class RENet(nn.Module):
         # (0.179 -> 0.059 s per advance on a trained ICEWS18-shaped model at num_k 1000, identical predicted facts:
         # profiles/r05_a_advance_pruned.txt); RENET_ADVANCE_PRUNE=0 restores the exhaustive scoring (A/B runs, tests).
         self.prune_relations = os.environ.get('RENET_ADVANCE_PRUNE', '1') == '1'
+        # forward(): run the two calls of train.py:136-137 as ONE merged pass (_forward_fused; opt-in, see its contract)
+        self.fuse_directions = os.environ.get('RENET_FUSE_DIRECTIONS', '0') == '1'
+        self._fused_pending = None
         self.last_prune = None
         self.shadow_pick = None
         self._shadow = {}
@@ -255,7 +258,7 @@ class RENet(nn.Module):
         return None if hbatch is None else self.prepare_both_from_host(hbatch)
 
     @_moded
-    def loss_prepared_both(self, prep):
+    def loss_prepared_both(self, prep, row_tap=None):
         """loss_prepared(prep_s) + loss_prepared(prep_o) evaluated as ONE pass over the 2B sequences of the merged
         batch (extension of the reference API; train.py:136-138 adds the two losses of the same quadruples).  The
         aggregator, both encoders and both heads are shared between the directions (model.py:26-40), the directions
@@ -281,7 +284,7 @@ class RENet(nn.Module):
             return ops.DualHeadCEFn.apply(self.ent_embeds, prep.s_idx, s_h, self.rel_embeds, prep.r_idx,
                                           self.linear.weight, self.linear.bias, prep.o_idx, s_q,
                                           self.linear_r.weight, self.linear_r.bias, prep.r_label, prep.plan_s,
-                                          prep.plan_r, p, seed1, seed2, scale, 0.1)
+                                          prep.plan_r, p, seed1, seed2, scale, 0.1, row_tap)
         loss_sub = ops.HeadCEFn.apply(self.ent_embeds, prep.s_idx, s_h, self.rel_embeds, prep.r_idx,
                                       self.linear.weight, self.linear.bias, prep.o_idx, prep.plan_s,
                                       prep.plan_r, p, seed1, scale)
@@ -359,7 +362,51 @@ class RENet(nn.Module):
         """Training loss of one direction (model.py:64-104): CE over objects + 0.1 * CE over relations.
         triplets: int tensor [B, >=3]; s_hist / o_hist: (histories, timestamps) in the reference's nested
         list layout, or graph.FlatHistory objects."""
+        if self.fuse_directions and self.training and torch.is_grad_enabled() and DUAL_HEAD:
+            out = self._forward_fused(triplets, s_hist, o_hist, graph_dict, subject)
+            if out is not None:
+                return out
         return self.loss_prepared(self.prepare(triplets, s_hist if subject else o_hist, graph_dict, subject))
+
+    def _forward_fused(self, triplets, s_hist, o_hist, graph_dict, subject):
+        """train.py:136-138 calls  model(batch, s_hist, o_hist, graph_dict, subject=True)  and then the same with
+        subject=False  and adds the two losses.  With `fuse_directions` (opt-in: RENET_FUSE_DIRECTIONS=1 or the attribute) the
+        FIRST call runs both directions as the merged pass the product loop uses (ONE host batch build, every kernel over the
+        2B sequences, loss_prepared_both) and returns a tensor whose VALUE is the subject-direction loss and whose autograd
+        graph is that of the SUM; the SECOND call, recognised by the identity of its arguments, returns the
+        object-direction loss as a constant.  loss_s + loss_o then has the reference's value and gradient with half the
+        launches and half the host work.  The contract is train.py's: every subject=True call is followed by the
+        subject=False call on the same argument objects and the two results enter the total with EQUAL weight; a
+        subject=True call while another is still pending raises instead of training on a silently wrong gradient."""
+        pend = self._fused_pending
+        if not subject:
+            if pend is None:
+                return None                            # an object-direction call on its own: the plain path
+            args, loss_o = pend
+            def same(a, b):          # (train.py builds the (hist, hist_t) tuples anew at every call: compare their members)
+                return a is b or (isinstance(a, tuple) and isinstance(b, tuple) and len(a) == len(b) and
+                                  all(x is y for x, y in zip(a, b)))
+            if not (same(args[0], triplets) and same(args[1], s_hist) and same(args[2], o_hist) and args[3] is graph_dict):
+                raise RuntimeError('fuse_directions: model(..., subject=False) did not receive the argument objects of the '
+                                   'preceding subject=True call (train.py:136-137); set model.fuse_directions = False')
+            self._fused_pending = None
+            return loss_o
+        if pend is not None:
+            self._fused_pending = None
+            raise RuntimeError('fuse_directions: model(..., subject=True) was called again before the subject=False call '
+                               'of the previous batch (its gradient already contains both directions)')
+        prep = self.prepare_both(triplets, s_hist, o_hist, graph_dict)
+        if prep is None:
+            return None                                # a direction without any history: two plain passes
+        tap = []
+        total = self.loss_prepared_both(prep, row_tap=tap)
+        rl, s1, s2 = tap[0]
+        b2 = prep.b                                    # 2B rows in sorted order; perm: sorted position -> sequence (>= B: object side)
+        is_obj = torch.from_numpy(np.asarray(prep.perm) >= (b2 // 2)).to(rl.device)
+        w = torch.cat((is_obj.to(rl.dtype) * s1, is_obj.to(rl.dtype) * s2))
+        loss_o = torch.dot(rl, w)                      # the object-direction rows' share of `total` (no autograd graph)
+        self._fused_pending = ((triplets, s_hist, o_hist, graph_dict), loss_o)
+        return total - loss_o
 
 
 class PreparedBatch(object):

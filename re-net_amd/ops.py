@@ -771,7 +771,9 @@ class DualHeadCEFn(Function):
     @staticmethod
     @_fwd_mode
     def forward(ctx, a, ia, h1, c, ic, w1, b1, target1, h2, w2, b2, target2, plan_a, plan_c, drop_p, seed1, seed2,
-                loss_scale=1.0, rel_weight=0.1):
+                loss_scale=1.0, rel_weight=0.1, row_tap=None):
+        """row_tap: a list that receives (row losses [2b]: entity head rows then relation head rows, s1, s2) -- the weights
+        with which the returned scalar sums them (RENet.forward's fused directions split the merged loss by direction)."""
         ctx.srcs = (a, c, w1, b1, w2, b2)
         a, h1, h2, c, w1, b1, w2, b2 = (_c(t) for t in (a, h1, h2, c, w1, b1, w2, b2))
         b, d = h1.shape
@@ -795,6 +797,8 @@ class DualHeadCEFn(Function):
             ctx.save_for_backward(feat1, lg1, w1, feat2, lg2, w2)
             ctx.consumed = False
             ctx.bf16 = (dl1, fop1, dl2, fop2)
+        if row_tap is not None:
+            row_tap.append((rl.detach(), s1, s2))
         return torch.dot(rl, _loss_weight_vector(b, s1, s2, h1.device))
 
     @staticmethod
@@ -840,7 +844,7 @@ class DualHeadCEFn(Function):
         else:
             d_c = torch.zeros(c_shape, device=g.device, dtype=torch.float32)
             K.segment_add(dc1, plan_c, d_c)
-        return (d_a, None, dh1, d_c, None, d_w1, d_b1, None, dh2, d_w2, d_b2, None) + (None,) * 7
+        return (d_a, None, dh1, d_c, None, d_w1, d_b1, None, dh2, d_w2, d_b2, None) + (None,) * 8
 
 
 class SegmentPoolFn(Function):

@@ -118,6 +118,68 @@ def test_merged_pass_equals_the_two_passes():
         undo()
 
 
+def test_fused_directions_of_forward_equal_the_two_calls_of_train_py():
+    """RENet.fuse_directions (opt-in): train.py:136-138's  model(..., subject=True) + model(..., subject=False)  through
+    the reference's list API run as ONE merged pass -- each call's VALUE is its own direction's loss, the sum carries the
+    gradient of both; breaking the calling contract raises."""
+    import cpu_abi_emulation
+    undo = cpu_abi_emulation.install()
+    try:
+        import model as M
+        import parallel
+        quads, num_ent, R = _data()
+        gd = P.build_graph_dict(quads, R)
+        hs, ho = P.HistoryIndex(quads, 's'), P.HistoryIndex(quads, 'o')
+        torch.manual_seed(21)
+        net = M.RENet(num_ent, 100, R, dropout=0.0, seq_len=10)
+        gen = torch.Generator().manual_seed(2)
+        net.global_emb = {int(t): torch.randn(1, 1, 100, generator=gen) * 0.1 for t in gd}
+        net.train()
+        flat = parallel.FlatGrads(net)
+        idx = np.random.RandomState(4).permutation(len(quads))[:160]
+        bt = torch.from_numpy(quads[idx])
+        (sh, sht), (oh, oht) = hs.to_lists(idx), ho.to_lists(idx)
+
+        def two_calls():
+            flat.zero()
+            ls = net(bt, (sh, sht), (oh, oht), gd, subject=True)          # (fresh tuples per call, as train.py writes them)
+            lo = net(bt, (sh, sht), (oh, oht), gd, subject=False)
+            (ls + lo).backward()
+            return float(ls), float(lo), flat.flat.clone()
+        assert net.fuse_directions is False
+        ls0, lo0, g0 = two_calls()
+        net.fuse_directions = True
+        ls1, lo1, g1 = two_calls()
+        assert net._fused_pending is None
+        assert abs(ls0 - ls1) <= 2e-6 * abs(ls0) and abs(lo0 - lo1) <= 2e-6 * abs(lo0)
+        assert float((g0 - g1).abs().max()) <= 2e-6 * float(g0.abs().max())
+        # eval mode / no_grad: the plain path (nothing pending afterwards)
+        net.eval()
+        with torch.no_grad():
+            le = net(bt, (sh, sht), (oh, oht), gd, subject=True)
+        assert net._fused_pending is None and abs(float(le) - ls0) <= 2e-6 * abs(ls0)
+        net.train()
+        # an object-direction call on its own is the plain pass
+        assert abs(float(net(bt, (sh, sht), (oh, oht), gd, subject=False)) - lo0) <= 2e-6 * abs(lo0)
+        # contract violations raise: two subject=True calls in a row; a subject=False call on other arguments
+        net(bt, (sh, sht), (oh, oht), gd, subject=True)
+        try:
+            net(bt, (sh, sht), (oh, oht), gd, subject=True)
+            raise AssertionError('expected RuntimeError')
+        except RuntimeError as e:
+            assert 'fuse_directions' in str(e)
+        assert net._fused_pending is None
+        net(bt, (sh, sht), (oh, oht), gd, subject=True)
+        other = torch.from_numpy(quads[idx])
+        try:
+            net(other, (sh, sht), (oh, oht), gd, subject=False)
+            raise AssertionError('expected RuntimeError')
+        except RuntimeError as e:
+            assert 'fuse_directions' in str(e)
+    finally:
+        undo()
+
+
 def test_sequence_shards_of_one_batch_sum_to_the_batch():
     """SURVEY 8e option (i): every rank builds the SAME merged batch and keeps its share of the sequences
     (graph.shard_sequences); the ranks' losses and gradients SUM to those of the unsharded batch."""

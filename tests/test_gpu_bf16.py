@@ -93,6 +93,12 @@ def test_bf16_storage_gemm_on_prepacked_operands_and_sliced_weights(dev):
         K.unregister_weights([w])
 
 
+# per-tensor relative L2 bound of the bf16-mode gradients against the fp32 reference: 2 x the largest value observed on MI355X
+# (profiles/r05_*_gpu_tests.txt prints every tensor's value); REL_L2_BOUND overrides it per tensor where needed
+REL_L2_DEFAULT = 5e-2
+REL_L2_BOUND = {}
+
+
 @pytest.mark.parametrize('mode', ['bf16', 'bf16s'])
 def test_config5_training_step_in_bf16_mode(dev, mode):
     """ONE eval-mode training step at config 5's sizes (YAGO-shaped, n_hidden 400, seq_len 15, B 1024) with the
@@ -128,6 +134,7 @@ def test_config5_training_step_in_bf16_mode(dev, mode):
             report['%s_%s' % (tag, key)] = err / scale
             assert ok, (tag, key, err, scale)
     worst = 0.0
+    rel_l2 = {}
     for k, p in net.named_parameters():
         g = p.grad.cpu().numpy()
         ref_s = np.asarray(gold['grad.' + k + '__samp']) if ('grad.' + k + '__samp') in gold else np.asarray(gold['grad.' + k]).reshape(-1)
@@ -137,10 +144,14 @@ def test_config5_training_step_in_bf16_mode(dev, mode):
         err = float(np.abs(got_s - ref_s).max())
         worst = max(worst, err / scale)
         assert err <= 0.15 * scale, (k, err, scale)                 # observed worst entry 7.3 % of its tensor's max: 2x
+        # the sharper statement (review r4): per-tensor RELATIVE L2 error over the compared positions
+        rel_l2[k] = float(np.linalg.norm((got_s - ref_s).astype(np.float64)) / max(np.linalg.norm(ref_s.astype(np.float64)), 1e-30))
+        assert rel_l2[k] <= REL_L2_BOUND.get(k, REL_L2_DEFAULT), (k, rel_l2[k])
         if ('grad.' + k + '__norm') in gold:
             nr = float(gold['grad.' + k + '__norm'])
             assert abs(float(np.linalg.norm(g.astype(np.float64))) - nr) <= 5e-2 * nr, k
     report['worst_grad'] = worst
+    print('bf16 config-5 per-tensor relative L2 gradient error [%s]:' % mode, {k: float('%.3g' % v) for k, v in rel_l2.items()})
     print('bf16 config-5 deviations from the fp32 reference:', {k: float('%.3g' % v) for k, v in report.items()})
 
 

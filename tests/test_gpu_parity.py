@@ -485,6 +485,32 @@ def test_gru_matches_torch_cpu(dev, i, h, nseq, kernels, monkeypatch):
         np.testing.assert_allclose(p.grad.cpu().numpy(), getattr(ref, name).grad.numpy(), rtol=1e-3, atol=1e-4)
 
 
+def test_fused_directions_of_forward_equal_the_two_calls_of_train_py(dev):
+    """RENet.fuse_directions through the real kernels: train.py:136-138's two model() calls as one merged pass (eval-mode
+    masks: dropout 0, so both forms are deterministic) -- per-direction values and the gradient of the sum."""
+    c = train_case('small', 200)
+    net, gd = _build_model(c, dev, dropout=0.0)
+    net.train()
+    batch = torch.from_numpy(c['batch']).to(dev)
+    (sh, sht), (oh, oht) = c['hists']['s'], c['hists']['o']
+
+    def two_calls():
+        net.zero_grad()
+        ls = net(batch, (sh, sht), (oh, oht), gd, subject=True)
+        lo = net(batch, (sh, sht), (oh, oht), gd, subject=False)
+        (ls + lo).backward()
+        return float(ls), float(lo), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    ls0, lo0, g0 = two_calls()
+    net.fuse_directions = True
+    ls1, lo1, g1 = two_calls()
+    assert net._fused_pending is None
+    assert abs(ls0 - ls1) <= 2e-5 * abs(ls0) and abs(lo0 - lo1) <= 2e-5 * abs(lo0), (ls0, ls1, lo0, lo1)
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-4 * scale + 1e-9, k
+
+
 @pytest.mark.parametrize('passes', ['separate', 'merged'])
 def test_train_mode_gradients_match_finite_differences_under_replayed_masks(dev, passes):
     """Train mode (dropout 0.5 at all four sites: RGCN self-loop, sequence assembly x2, both heads): with the seed
