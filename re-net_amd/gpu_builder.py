@@ -101,6 +101,102 @@ class DeviceStore(object):
             self._pinned_free.append(buf)
 
 
+class GraphDeviceStore(DeviceStore):
+    """The part of a DeviceStore that a batch does NOT bring itself: the per-timestamp fact lists of the graph store and the
+    timestamps of the global-embedding table.  Used by the reference's LIST API (RENet.forward with nested history lists,
+    train.py:136-137): there the quadruples and their histories arrive with every call (ListBatchStore uploads them, ~160 KB),
+    so no dataset has to be registered with the model.  Cached per (graph store, global_emb size) in graph_store_for()."""
+
+    def __init__(self, graph_dict, global_emb, num_ent, num_rels, device):      # (no DeviceStore.__init__: no dataset here)
+        store = G.store_for(graph_dict)
+        times = np.asarray(store.times, dtype=np.int64)
+        if len(times) > 1 and np.any(np.diff(times) <= 0):
+            raise ValueError('graph_dict must be in ascending time order')
+        for arr in (store.trip_s, store.trip_o, times):
+            if len(arr) and (arr.max() >= 2 ** 31 or arr.min() < 0):
+                raise ValueError('ids / timestamps must fit int32')
+        self.device = device
+        self.num_ent, self.num_rels = int(num_ent), int(num_rels)
+        self.n_quads = 0
+        self.t = dict(times=_i32(times, device), trip_ptr=_i32(store.trip_ptr, device), trip_s=_i32(store.trip_s, device),
+                      trip_r=_i32(store.trip_r, device), trip_o=_i32(store.trip_o, device),
+                      glob_times=_i32(sorted(int(t) for t in global_emb.keys()), device))
+        self.n_facts = int(len(store.trip_s))
+        self.T, self.n_glob = len(times), int(self.t['glob_times'].numel())
+        self.cap_nodes, self.cap_edges = 1 << 17, 1 << 19
+        self._pinned_free = []
+        self.c = None                         # (a ListBatchStore fills a struct per batch)
+
+
+_graph_stores = {}
+
+
+def graph_store_for(graph_dict, global_emb, num_ent, num_rels, device):
+    """The resident GraphDeviceStore of (graph_dict, global_emb) on `device`; rebuilt when the graph store object changed
+    (graph.store_for re-creates it when the dict gained timestamps) or the global-embedding table grew."""
+    store = G.store_for(graph_dict)
+    key = (id(graph_dict), str(device))
+    ent = _graph_stores.get(key)
+    if ent is None or ent[0] is not store or ent[1] != len(global_emb):
+        if len(_graph_stores) > 8:
+            _graph_stores.clear()
+        ent = (store, len(global_emb), GraphDeviceStore(graph_dict, global_emb, num_ent, num_rels, device))
+        _graph_stores[key] = ent
+    return ent[2]
+
+
+class ListBatchStore(object):
+    """What DeviceBatch needs of a store, for ONE batch that arrives through the reference's list API: the batch's own
+    quadruples (s, r, o) and its two FlatHistory objects (graph.FlatHistory.from_lists of the nested lists) uploaded in ONE
+    int32 copy, laid out like a DeviceStore's history index (first / count per sequence, snapshot timestamps, snapshot
+    pointers, neighbours) on top of the resident GraphDeviceStore.  The batch's quadruple indices are 0..B-1."""
+
+    def __init__(self, base, trip, fs, fo, stream=None):
+        self.base = base
+        self.device, self.num_ent, self.num_rels = base.device, base.num_ent, base.num_rels
+        trip = np.asarray(trip, dtype=np.int64)
+        B = len(trip)
+        if len(fs) != B or len(fo) != B:
+            raise ValueError('histories and quadruples differ in length')
+        parts = [trip[:, 0], trip[:, 1], trip[:, 2]]
+        for fh in (fs, fo):
+            parts += [fh.seq_ptr[:-1], np.diff(fh.seq_ptr), fh.step_t, fh.nbr_ptr, fh.nbr_o]
+        for a in parts:
+            if len(a) and (int(a.max()) >= 2 ** 31 or int(a.min()) < 0):
+                raise ValueError('ids / timestamps must fit int32')
+        offs, tot = [], 0
+        for a in parts:
+            offs.append(tot)
+            tot += (len(a) + 15) & ~15                       # 64-byte aligned slices
+        flat = np.zeros(tot + 16, dtype=np.int32)
+        for a, o in zip(parts, offs):
+            flat[o:o + len(a)] = a
+        st = stream if stream is not None else torch.cuda.current_stream()
+        with torch.cuda.stream(st):
+            self._buf = torch.from_numpy(flat).to(self.device, non_blocking=True)
+        ptr = [self._buf.data_ptr() + 4 * o for o in offs]
+        sd = _StoreDev()
+        sd.q_s, sd.q_r, sd.q_o = ptr[0], ptr[1], ptr[2]
+        for k, n in enumerate(('h_first', 'h_count', 'snap_t', 'snap_ptr', 'nbr_o')):
+            setattr(sd, n, (_P * 2)(ptr[3 + k], ptr[8 + k]))
+        for n in ('times', 'trip_ptr', 'trip_s', 'trip_r', 'trip_o', 'glob_times'):
+            setattr(sd, n, base.t[n].data_ptr())
+        sd.T, sd.n_glob, sd.n_facts = base.T, base.n_glob, base.n_facts
+        sd.num_ent, sd.num_rels = self.num_ent, self.num_rels
+        self.c = sd
+        self.n_quads = B
+
+    # capacities and the pinned count buffers live in the resident store (they outlast the batch)
+    cap_nodes = property(lambda self: self.base.cap_nodes, lambda self, v: setattr(self.base, 'cap_nodes', v))
+    cap_edges = property(lambda self: self.base.cap_edges, lambda self, v: setattr(self.base, 'cap_edges', v))
+
+    def _take_pinned(self):
+        return self.base._take_pinned()
+
+    def _give_pinned(self, buf):
+        self.base._give_pinned(buf)
+
+
 class _Host(object):
     """Host-side view of a DeviceBatch (what graph._HostView offers for a host-built batch)."""
 

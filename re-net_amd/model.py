@@ -127,6 +127,9 @@ class RENet(nn.Module):
         # forward(): run the two calls of train.py:136-137 as ONE merged pass (_forward_fused; opt-in, see its contract)
         self.fuse_directions = os.environ.get('RENET_FUSE_DIRECTIONS', '0') == '1'
         self._fused_pending = None
+        # ... and build that merged batch with the DEVICE builder (_prepare_both_lists_device; RENET_DEVICE_BUILDER_LISTS=0:
+        # the host builder)
+        self.device_builder_lists = os.environ.get('RENET_DEVICE_BUILDER_LISTS', '1') != '0'
         self.last_prune = None
         self.shadow_pick = None
         self._shadow = {}
@@ -368,6 +371,29 @@ class RENet(nn.Module):
                 return out
         return self.loss_prepared(self.prepare(triplets, s_hist if subject else o_hist, graph_dict, subject))
 
+    def _prepare_both_lists_device(self, triplets, s_hist, o_hist, graph_dict):
+        """prepare_both() for a batch that arrives through the reference's LIST API, with the batch graph built by the DEVICE
+        builder (csrc/builder.hip): the nested lists are flattened on the host (graph.FlatHistory.from_lists), uploaded with
+        the batch's (s, r, o) in one copy (gpu_builder.ListBatchStore) and everything else -- node sets, induced edges,
+        norm, plans: utils.py:209-244 + 115-131 + dgl.batch -- is kernels; the arrays are those of the host builder
+        (tests/test_gpu_builder.py).  None when a direction has no history at all (the caller takes the host path)."""
+        import gpu_builder
+        trip = triplets.detach().cpu().numpy() if isinstance(triplets, torch.Tensor) else np.asarray(triplets)
+        fs = s_hist if isinstance(s_hist, G.FlatHistory) else G.FlatHistory.from_lists(s_hist[0], s_hist[1])
+        fo = o_hist if isinstance(o_hist, G.FlatHistory) else G.FlatHistory.from_lists(o_hist[0], o_hist[1])
+        if fs.seq_ptr[-1] == 0 or fo.seq_ptr[-1] == 0:
+            return None
+        longest = max(int(np.diff(fs.seq_ptr).max()), int(np.diff(fo.seq_ptr).max()))
+        if longest > self.seq_len:
+            raise ValueError('history longer than seq_len (%d > %d)' % (longest, self.seq_len))
+        base = gpu_builder.graph_store_for(graph_dict, self.global_emb, self.in_dim, self.num_rels, self.ent_embeds.device)
+        for _ in range(8):                                  # (a capacity grew: rebuild; first batches only)
+            st = gpu_builder.ListBatchStore(base, trip, fs, fo)
+            prep = self.finish_prepare_device(gpu_builder.DeviceBatch(st, np.arange(len(trip)), self.seq_len))
+            if prep is not None:
+                return prep
+        raise RuntimeError('device batch builder did not converge on its capacities')
+
     def _forward_fused(self, triplets, s_hist, o_hist, graph_dict, subject):
         """train.py:136-138 calls  model(batch, s_hist, o_hist, graph_dict, subject=True)  and then the same with
         subject=False  and adds the two losses.  With `fuse_directions` (opt-in: RENET_FUSE_DIRECTIONS=1 or the attribute) the
@@ -395,14 +421,21 @@ class RENet(nn.Module):
             self._fused_pending = None
             raise RuntimeError('fuse_directions: model(..., subject=True) was called again before the subject=False call '
                                'of the previous batch (its gradient already contains both directions)')
-        prep = self.prepare_both(triplets, s_hist, o_hist, graph_dict)
+        prep = None
+        if self.device_builder_lists and self.ent_embeds.is_cuda:
+            prep = self._prepare_both_lists_device(triplets, s_hist, o_hist, graph_dict)
+        if prep is None:
+            prep = self.prepare_both(triplets, s_hist, o_hist, graph_dict)
         if prep is None:
             return None                                # a direction without any history: two plain passes
         tap = []
         total = self.loss_prepared_both(prep, row_tap=tap)
         rl, s1, s2 = tap[0]
         b2 = prep.b                                    # 2B rows in sorted order; perm: sorted position -> sequence (>= B: object side)
-        is_obj = torch.from_numpy(np.asarray(prep.perm) >= (b2 // 2)).to(rl.device)
+        if prep.perm is None:                          # device-built: the permutation stays on the device
+            is_obj = prep.g._v['perm'][:b2] >= (b2 // 2)
+        else:
+            is_obj = torch.from_numpy(np.asarray(prep.perm) >= (b2 // 2)).to(rl.device)
         w = torch.cat((is_obj.to(rl.dtype) * s1, is_obj.to(rl.dtype) * s2))
         loss_o = torch.dot(rl, w)                      # the object-direction rows' share of `total` (no autograd graph)
         self._fused_pending = ((triplets, s_hist, o_hist, graph_dict), loss_o)

@@ -20,11 +20,13 @@ SHAPES = ['2048,23033,600,0,1', '2048,600,23033,0,0,6', '23033,600,2048,1,0', '1
           '16000,600,600,0,0', '4096,4096,4096,0,1']
 
 
-def build():
+def build(only=None):
     os.makedirs(OUT, exist_ok=True)
     src = [os.path.join(ROOT, 're-net_amd', 'csrc', f) for f in ('gemm_split.hip', 'gemm.hip', 'gemm_skinny.hip')]
     procs = []
     for name, flags in VARIANTS.items():
+        if only and name not in only:
+            continue
         lib = os.path.join(OUT, 'libsplit_%s.so' % name)
         procs.append(subprocess.Popen(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
                                        '-I' + os.path.join(ROOT, 'include')] + flags + src + ['-o', lib]))
@@ -102,7 +104,7 @@ def compare(names):
 
 if __name__ == '__main__':
     if sys.argv[1] == 'build':
-        build()
+        build(sys.argv[2:])
     elif sys.argv[1] == 'cmp':
         compare(list(VARIANTS))
     elif sys.argv[1] == 'one':

@@ -22,6 +22,10 @@ def main():
     # hold numpy arrays (the per-entity history lists, train.py:189-195).  torch >= 2.6 defaults to
     # weights_only=True and refuses those; restore the old default for this run instead of editing the drivers.
     os.environ.setdefault('TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD', '1')
+    # train.py:136-138 calls model(..., subject=True) and model(..., subject=False) on the same batch and adds the losses:
+    # exactly the contract of RENet.fuse_directions (one merged pass, batch graph built on the device); set
+    # RENET_FUSE_DIRECTIONS=0 to run the two calls as two passes
+    os.environ.setdefault('RENET_FUSE_DIRECTIONS', '1')
     sys.path.insert(0, os.path.join(ROOT, 're-net_amd'))
     sys.argv = [script] + sys.argv[2:]
     runpy.run_path(script, run_name='__main__')
