@@ -130,6 +130,10 @@ class RENet(nn.Module):
         # ... and build that merged batch with the DEVICE builder (_prepare_both_lists_device; RENET_DEVICE_BUILDER_LISTS=0:
         # the host builder)
         self.device_builder_lists = os.environ.get('RENET_DEVICE_BUILDER_LISTS', '1') != '0'
+        # evaluate_filter(): answer the per-quadruple calls of test.py / train.py's validation from ONE batched evaluation
+        # per timestamp (_lookahead_filter; opt-in, see its docstring)
+        self.lookahead_eval = os.environ.get('RENET_LOOKAHEAD_EVAL', '0') == '1'
+        self._la = self._la_at = None
         self.last_prune = None
         self.shadow_pick = None
         self._shadow = {}
@@ -478,6 +482,7 @@ def _init_history(self, triples, s_history, o_history, valid_triples, s_history_
     """model.py:107-165: per-entity rolling windows as of the end of training (+ valid/test entries whose
     last step is not later than the last training time)."""
     n = self.in_dim
+    self._la = None                                   # (look-ahead table of evaluate_filter: a new evaluation pass starts)
     self.s_hist_test = [[] for _ in range(n)]
     self.o_hist_test = [[] for _ in range(n)]
     self.s_hist_test_t = [[] for _ in range(n)]
@@ -960,8 +965,57 @@ def _evaluate(self, triplet, s_hist, o_hist, global_model):
     return np.array([_rank(sub_pred, s), _rank(ob_pred, o)]), loss
 
 
+def _param_version(*modules):
+    return tuple(p._version for m in modules for p in m.parameters())
+
+
+def _lookahead_filter(self, triplet, s_hist, o_hist, global_model, all_triplets):
+    """test.py:104-139 and train.py:160-172 call evaluate_filter once per quadruple (~2 ms of launch-bound work each: 40 s
+    per validation pass over YAGO) -- but every call also hands over `all_triplets`, which holds the whole evaluated
+    stream.  With `lookahead_eval` (opt-in: RENET_LOOKAHEAD_EVAL=1; tools/run_reference_driver.py turns it on) the FIRST call
+    at a timestamp evaluates ALL quadruples of all_triplets that carry this timestamp in one evaluate_filter_batch (the
+    per-timestamp state update of predict() runs inside it, exactly where the sequential loop runs it) and later calls are
+    answered from that table.  Same ranks as the per-quadruple path up to fp32 summation order of a batched vs a one-row
+    GEMM (tests/test_gpu_parity.py::test_evaluate_filter_stream_equals_sequential_calls: losses to 1e-5, >= 99 % of the ranks
+    identical, the rest off by one).  The table assumes the call's GIVEN histories are non-empty (model.py:332,342 only test
+    their emptiness); a call whose given history is empty while the entity's rolling window is not takes the plain path.
+    Returns None whenever the table does not apply."""
+    q = triplet.tolist() if isinstance(triplet, torch.Tensor) else [int(x) for x in triplet]
+    s, r, o, t = int(q[0]), int(q[1]), int(q[2]), int(q[3])
+    la = self._la
+    ver = _param_version(self, global_model)
+    if la is None or la['t'] != t or la['at'] is not all_triplets or la['ver'] != ver or _as_int(self.latest_time) != t:
+        at = self._la_at
+        if at is None or at[0] is not all_triplets:
+            arr = all_triplets.detach().cpu().numpy() if isinstance(all_triplets, torch.Tensor) else np.asarray(all_triplets)
+            at = self._la_at = (all_triplets, arr.astype(np.int64)[:, :4])
+        rows = at[1][at[1][:, 3] == t]
+        rows = np.unique(rows, axis=0)
+        if len(rows) == 0 or not np.any((rows[:, 0] == s) & (rows[:, 1] == r) & (rows[:, 2] == o)):
+            return None
+        res = {}
+        for c in range(0, len(rows), 4096):
+            blk = rows[c:c + 4096]
+            given = ([[0]] * len(blk), None)                  # "non-empty": only len(given[i]) is read (predict_batch)
+            rk, ls = self.evaluate_filter_batch(blk, given, given, global_model, all_triplets)
+            ls = ls.detach().float().cpu()
+            for i, row in enumerate(blk.tolist()):
+                res[(row[0], row[1], row[2])] = (rk[i], ls[i])
+        la = self._la = {'t': t, 'at': all_triplets, 'ver': _param_version(self, global_model), 'res': res}
+    hit = la['res'].get((s, r, o))
+    if hit is None:
+        return None
+    if (len(s_hist[0]) == 0 and len(self.s_hist_test[s]) != 0) or (len(o_hist[0]) == 0 and len(self.o_hist_test[o]) != 0):
+        return None                                           # zero state on that side (model.py:332,342): the plain path
+    return np.array(hit[0]), hit[1]
+
+
 def _evaluate_filter(self, triplet, s_hist, o_hist, global_model, all_triplets):
     """model.py:384-419: time-agnostic filtered ranks of the gold subject and object."""
+    if self.lookahead_eval and not self.reference_shadowing and not torch.is_grad_enabled():
+        hit = self._lookahead_filter(triplet, s_hist, o_hist, global_model, all_triplets)
+        if hit is not None:
+            return hit
     s, r, o = _as_int(triplet[0]), _as_int(triplet[1]), _as_int(triplet[2])
     loss, sub_pred, ob_pred = self.predict(triplet, s_hist, o_hist, global_model)
     at = all_triplets
@@ -1100,6 +1154,7 @@ RENet._advance_time = _moded(_advance_time)
 RENet.predict = _moded(_predict)
 RENet.evaluate = _moded(_evaluate)
 RENet.evaluate_filter = _moded(_evaluate_filter)
+RENet._lookahead_filter = _lookahead_filter
 RENet.predict_batch = _moded(_predict_batch)
 RENet.evaluate_filter_batch = _moded(_evaluate_filter_batch)
 RENet.evaluate_filter_stream = _moded(_evaluate_filter_stream)

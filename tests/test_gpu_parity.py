@@ -868,6 +868,29 @@ def test_evaluate_filter_stream_equals_sequential_calls(dev):
         net2.predict_batch(va[:n_eval], (vs[:n_eval], vst[:n_eval]), (vo[:n_eval], vot[:n_eval]), gnet2)
 
 
+def test_lookahead_evaluation_equals_the_per_quadruple_calls(dev):
+    """RENet.lookahead_eval through the real kernels: test.py's loop (one evaluate_filter call per quadruple, the whole stream
+    as all_triplets) answered from one batched evaluation per timestamp vs the plain per-call path on an identical model."""
+    gold = load_golden('eval_small_100.npz')
+    n_eval = int(gold['n_eval'])
+    out = []
+    for look in (False, True):
+        net, gnet, H, gd, samples, total, valid, va = _eval_setup(dev, gold)
+        net.lookahead_eval = look
+        (vs, vst), (vo, vot) = H['valid']
+        with torch.no_grad():
+            res = [net.evaluate_filter(valid[i].to(dev), (vs[i], vst[i]), (vo[i], vot[i]), gnet, total) for i in range(n_eval)]
+        assert len(samples) == 0
+        graphs = {t: gd[t].global_triples() for t in gd.keys()}
+        out.append((np.asarray([r for r, _ in res]), np.asarray([float(l) for _, l in res]), graphs, net))
+    (r0, l0, g0, _), (r1, l1, g1, net1) = out
+    assert net1._la is not None and list(g0.keys()) == list(g1.keys())
+    for t in g0:
+        assert all(np.array_equal(x, y) for x, y in zip(g0[t], g1[t]))
+    np.testing.assert_allclose(l1, l0, rtol=1e-5, atol=1e-5)
+    assert float(np.mean(r0 == r1)) >= 0.99 and np.abs(r0 - r1).max() <= 1
+
+
 def test_evaluate_filter_matches_reference_golden(dev):
     gold = load_golden('eval_small_100.npz')
     cfg, tr, va, te = fixtures.split_dataset('small')

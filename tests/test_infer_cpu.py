@@ -129,3 +129,64 @@ def test_pruned_advance_through_the_evaluation_loop(monkeypatch):
         assert np.array_equal(out[0][0], out[1][0])
     finally:
         undo()
+
+
+def test_lookahead_evaluation_answers_the_per_quadruple_calls_from_one_batch_per_timestamp():
+    """RENet.lookahead_eval: the loop of test.py:104-139 / train.py:160-172 (one evaluate_filter call per quadruple, the whole
+    stream passed as all_triplets) over two timestamps, with and without the look-ahead table: same ranks and losses, the
+    same predicted graph, ONE batched evaluation per timestamp; the table is dropped when parameters change."""
+    undo = EMU.install()
+    try:
+        import global_model as GM
+        num_k = 16
+        net, cfg = _setup(num_k, 20.0)
+        gnet = GM.RENet_global(cfg['num_ent'], 100, cfg['num_rels'], dropout=0.0, seq_len=5, num_k=num_k, maxpool=1)
+        gnet.load_state_dict({k: torch.from_numpy(v) for k, v in
+                              fixtures.make_params(12, global_shapes(cfg['num_ent'], cfg['num_rels'], 100)).items()})
+        gnet.eval()
+        _, tr, va, te = fixtures.split_dataset('small')
+        import preprocess as P
+        allq = np.concatenate((tr, va, te))
+        hs, ho = P.HistoryIndex(allq, 's', 5), P.HistoryIndex(allq, 'o', 5)
+        idx = np.arange(len(tr), len(tr) + len(va))
+        (vs, vst), (vo, vot) = hs.to_lists(idx), ho.to_lists(idx)
+        total = torch.from_numpy(allq)
+        valid = torch.from_numpy(va)
+        t_first = int(va[0, 3])
+        n_eval = int(np.count_nonzero(va[:, 3] == t_first)) + 5          # into the second timestamp: one advance
+        out = []
+        for look in (False, True):
+            m = copy.deepcopy(net)
+            m.lookahead_eval = look
+            calls = []
+            real = m.evaluate_filter_batch
+            m.evaluate_filter_batch = lambda *a, real=real, calls=calls, **k: (calls.append(len(a[0])), real(*a, **k))[1]
+            torch.manual_seed(5)
+            with torch.no_grad():
+                res = [m.evaluate_filter(valid[i], (vs[i], vst[i]), (vo[i], vot[i]), gnet, total) for i in range(n_eval)]
+            new_t = [t for t in m.graph_dict.keys() if t not in net.graph_dict]
+            facts = {t: set(map(tuple, np.stack(m.graph_dict[t].global_triples(), 1).tolist())) for t in new_t}
+            out.append((np.asarray([r for r, _ in res]), np.asarray([float(l) for _, l in res]), facts, calls, m))
+        (r0, l0, f0, c0, _), (r1, l1, f1, c1, m1) = out
+        assert c0 == [] and len(c1) == 2, (c0, c1)                          # one batched evaluation per timestamp
+        assert c1[0] == len(np.unique(va[va[:, 3] == t_first], axis=0))
+        assert f0.keys() == f1.keys() and all(f0[t] == f1[t] for t in f0) and len(f0) == 1
+        np.testing.assert_allclose(l1, l0, rtol=1e-5, atol=1e-5)
+        assert float(np.mean(r0 == r1)) >= 0.99 and np.abs(r0 - r1).max() <= 1, (r0, r1)
+        # a parameter update drops the table (validation passes of different epochs start at the same timestamp)
+        t_now = int(va[n_eval - 1, 3])
+        with torch.no_grad():
+            m1.linear.bias.add_(0.25)
+            m1.evaluate_filter(valid[n_eval - 1], (vs[n_eval - 1], vst[n_eval - 1]), (vo[n_eval - 1], vot[n_eval - 1]), gnet, total)
+        assert len(c1) == 3 and m1._la['t'] == t_now
+        # an empty GIVEN history with a non-empty rolling window: the plain path (zero state on that side), not the table
+        k = n_eval - 1
+        s_k = int(va[k, 0])
+        if len(m1.s_hist_test[s_k]) != 0:
+            with torch.no_grad():
+                a = m1.evaluate_filter(valid[k], ([], []), (vo[k], vot[k]), gnet, total)
+                m1.lookahead_eval = False
+                b = m1.evaluate_filter(valid[k], ([], []), (vo[k], vot[k]), gnet, total)
+            assert np.array_equal(a[0], b[0]) and float(a[1]) == float(b[1])
+    finally:
+        undo()

@@ -26,6 +26,9 @@ def main():
     # exactly the contract of RENet.fuse_directions (one merged pass, batch graph built on the device); set
     # RENET_FUSE_DIRECTIONS=0 to run the two calls as two passes
     os.environ.setdefault('RENET_FUSE_DIRECTIONS', '1')
+    # test.py:104-139 / train.py:160-172 evaluate one quadruple per call and pass the whole stream as `all_triplets`:
+    # RENet.lookahead_eval answers them from one batched evaluation per timestamp (RENET_LOOKAHEAD_EVAL=0: per call)
+    os.environ.setdefault('RENET_LOOKAHEAD_EVAL', '1')
     sys.path.insert(0, os.path.join(ROOT, 're-net_amd'))
     sys.argv = [script] + sys.argv[2:]
     runpy.run_path(script, run_name='__main__')
