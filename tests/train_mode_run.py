@@ -34,12 +34,14 @@ FULL_CFG = dict(h=200, seq_len=10, batch=1024, num_k=1000, lr=1e-3, wd=1e-5, gra
                 pre_lr=1e-2)       # tools/make_e2e_full_golden.py (train.py:211-236, pretrain.py:113-135)
 
 
-def run_seed(seed, data, gold, stream=False, keep_ranks=False, log=None, samples=None):
+def run_seed(seed, data, gold, stream=False, keep_ranks=False, log=None, samples=None, test_too=False):
     """gold: mapping with h / seq_len / batch / num_k / dropout / lr / wd / grad_norm / maxpool / pre_* / epochs.
     stream: validate with evaluate_filter_stream (one batch per timestamp; same ranks as the per-quadruple calls,
     tests/test_gpu_parity.py::test_evaluate_filter_stream_equals_sequential_calls) instead of train.py's loop.
     samples: [n_draws, num_k] entity samples recorded from the reference run of this seed (replayed in order by the
-    validation advance: the CPU and GPU generators differ); None = draw on the device."""
+    validation advance: the CPU and GPU generators differ); None = draw on the device.
+    test_too: after the validation pass continue as test.py does from train.py's checkpoint (the state AFTER validation,
+    train.py:187-195; histories cut to seq_len, test.py:96-103) over the test split; the result gains (test_mrr, test_hits)."""
     from sklearn.utils import shuffle
     import global_model as GM
     import model as M
@@ -120,11 +122,23 @@ def run_seed(seed, data, gold, stream=False, keep_ranks=False, log=None, samples
             for i in range(len(va)):
                 rk, _ = net.evaluate_filter(valid[i], (vs[0][i], vs[1][i]), (vo[0][i], vo[1][i]), gnet, total)
                 ranks.append(rk)
+        test_res = None
+        if test_too:
+            for ee in range(num_ent):                                   # test.py:96-103
+                while len(net.s_hist_test[ee]) > seq_len:
+                    net.s_hist_test[ee].pop(0)
+                    net.s_hist_test_t[ee].pop(0)
+                while len(net.o_hist_test[ee]) > seq_len:
+                    net.o_hist_test[ee].pop(0)
+                    net.o_hist_test_t[ee].pop(0)
+            tranks, _ = net.evaluate_filter_stream(torch.from_numpy(te), ts, to, gnet, total)
+            test_res = mrr_hits(tranks)
     opt.close()
     mrr, hits = mrr_hits(ranks)
     if keep_ranks:
-        return mrr, hits, epoch_losses, np.asarray(ranks).reshape(len(va), -1)
-    return mrr, hits, epoch_losses
+        out = (mrr, hits, epoch_losses, np.asarray(ranks).reshape(len(va), -1))
+        return out + (test_res,) if test_too else out
+    return (mrr, hits, epoch_losses, test_res) if test_too else (mrr, hits, epoch_losses)
 
 
 def main():

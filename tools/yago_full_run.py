@@ -3,6 +3,8 @@
 quadruples), the counterpart of tools/make_e2e_full_golden.py (the unmodified reference on CPU):
 
     python tools/yago_full_run.py <dropout> <epochs> <pre_epochs> <seed> [seed ...]      RENET_GEMM selects the GEMM mode
+    RENET_FULL_TEST=1: continue over the TEST split as test.py does (filtered test MRR / Hits, README.md:169's metric);
+    RENET_FULL_PRE_LR=<lr>: learning rate of the global model's pretraining (default 1e-2 = pretrain.py's; README: 1e-3)
 
 per seed: pretrain.py's loop for the global model -> get_global_emb -> train.py's loop as the PRODUCT runs it (merged pass,
 HipAdam) -> train.py's filtered validation (train.py:151-185, one batch per timestamp) -> MRR / Hits@1,3,10.  When the
@@ -32,10 +34,14 @@ def main():
     d = np.load(os.path.join(GOLDEN, 'yago_full.npz'))
     data = {k: (d[k].astype(np.int64) if d[k].ndim else d[k]) for k in d.files}
     cfg = dict(T.FULL_CFG, dropout=dropout, epochs=epochs, pre_epochs=pre_epochs)
+    if os.environ.get('RENET_FULL_PRE_LR'):
+        cfg['pre_lr'] = float(os.environ['RENET_FULL_PRE_LR'])
+    test_too = os.environ.get('RENET_FULL_TEST') == '1'
     tag = 'd0' if dropout == 0.0 else 'drop'
     fpath = os.path.join(GOLDEN, 'e2e_yago_full_%s.npz' % tag)
     gold = np.load(fpath) if os.path.isfile(fpath) else None
-    if gold is not None and (int(gold['epochs']) != epochs or int(gold['pre_epochs']) != pre_epochs):
+    if gold is not None and (int(gold['epochs']) != epochs or int(gold['pre_epochs']) != pre_epochs or
+                             abs(float(gold['pre_lr']) - cfg['pre_lr']) > 1e-12):
         gold = None                                   # a different schedule (e.g. the 20-epoch run): nothing to replay
     res, t0 = [], time.time()
     for seed in seeds:
@@ -43,10 +49,13 @@ def main():
         if gold is not None and seed in gold['seeds'].tolist() and 'samples' in gold.files:
             samples = gold['samples'][gold['seeds'].tolist().index(seed)]
         t1 = time.time()
-        mrr, hits, el, ranks = T.run_seed(seed, data, cfg, stream=True, keep_ranks=True, samples=samples,
-                                          log=lambda m: print(m, file=sys.stderr, flush=True))
+        res_ = T.run_seed(seed, data, cfg, stream=True, keep_ranks=True, samples=samples, test_too=test_too,
+                          log=lambda m: print(m, file=sys.stderr, flush=True))
+        mrr, hits, el, ranks = res_[:4]
         rec = {'seed': seed, 'mrr': mrr, 'hits': hits, 'epoch_loss': el, 'seconds': time.time() - t1,
                'replayed_reference_samples': samples is not None}
+        if test_too:
+            rec['test_mrr'], rec['test_hits'] = res_[4]
         if gold is not None and seed in gold['seeds'].tolist():
             i = gold['seeds'].tolist().index(seed)
             rec['reference_mrr'] = float(gold['mrr'][i])
