@@ -391,6 +391,15 @@ int renet_gru_bwd_layouts_bounds(int n, const float* const* dh_last, const int32
                                  const float* const* Whh, const float* const* saved, float* const* dGi,
                                  float* const* dGh, float* const* bounds, float* workspace, size_t workspace_bytes,
                                  void* stream);
+/* The same recurrences with EXACT fp32 products (v_mfma_f32_16x16x4_f32) whatever RENET_GEMM says: the per-model form of the
+ * exact mode (round 5; `net.gemm_mode = 'f32'`).  RENET_GEMM=f32 makes the plain entries above behave like these. */
+int renet_gru_fwd_layouts_f32(int n, const float* const* Gi, const int32_t* const* step_off, const int* L, int H,
+                              const float* const* Whh, const float* const* bhh, float* const* h_last,
+                              const int* out_rows, float* const* saved, float* workspace, size_t workspace_bytes,
+                              void* stream);
+int renet_gru_bwd_layouts_f32(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
+                              const float* const* Whh, const float* const* saved, float* const* dGi,
+                              float* const* dGh, float* workspace, size_t workspace_bytes, void* stream);
 /* The same recurrences in bf16 mode (BASELINE config 5): W_hh and the hidden state / gate gradients are rounded to
  * bf16 (RNE) as MFMA operands -- ONE v_mfma_f32_16x16x32_bf16 product per fragment pair instead of the six of the
  * fp32-class split, a third of the W_hh stream -- with fp32 accumulation, fp32 gate math, fp32 state and outputs. */

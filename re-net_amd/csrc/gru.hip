@@ -1307,6 +1307,13 @@ int renet_gru_fwd_layouts(int n, const float* const* Gi, const int32_t* const* s
     return gru_fwd_impl(3, n, Gi, step_off, L, H, Whh, bhh, h_last, out_rows, saved, workspace, workspace_bytes, stream);
 }
 
+int renet_gru_fwd_layouts_f32(int n, const float* const* Gi, const int32_t* const* step_off, const int* L, int H,
+                              const float* const* Whh, const float* const* bhh, float* const* h_last,
+                              const int* out_rows, float* const* saved, float* workspace, size_t workspace_bytes,
+                              void* stream) {
+    return gru_fwd_impl(0, n, Gi, step_off, L, H, Whh, bhh, h_last, out_rows, saved, workspace, workspace_bytes, stream);
+}
+
 int renet_gru_fwd_layouts_bf16(int n, const float* const* Gi, const int32_t* const* step_off, const int* L, int H,
                                const float* const* Whh, const float* const* bhh, float* const* h_last,
                                const int* out_rows, float* const* saved, float* workspace, size_t workspace_bytes,
@@ -1326,7 +1333,7 @@ static int gru_fwd_impl(int npl, int n, const float* const* Gi, const int32_t* c
     if (max_rows(ly) == 0) return RENET_OK;
     if (H != 100 && H != 200 && H != 400) return RENET_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (use_f32() && npl == 3) {
+    if (npl == 0 || (use_f32() && npl == 3)) {              // npl 0: the exact-fp32 kernels asked for by the caller (per model)
         FwdProbs ps;
         for (int i = 0; i < MAXP; ++i) {
             const int k = i < n ? i : 0;
@@ -1405,6 +1412,12 @@ int renet_gru_bwd_layouts(int n, const float* const* dh_last, const int32_t* con
     return gru_bwd_impl(3, n, dh_last, step_off, L, H, Whh, saved, dGi, dGh, workspace, workspace_bytes, stream);
 }
 
+int renet_gru_bwd_layouts_f32(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
+                              const float* const* Whh, const float* const* saved, float* const* dGi,
+                              float* const* dGh, float* workspace, size_t workspace_bytes, void* stream) {
+    return gru_bwd_impl(0, n, dh_last, step_off, L, H, Whh, saved, dGi, dGh, workspace, workspace_bytes, stream);
+}
+
 int renet_gru_bound_parts(int max_rows) { return max(1, (max_rows + MT - 1) / MT); }
 
 int renet_gru_bwd_layouts_bounds(int n, const float* const* dh_last, const int32_t* const* step_off, const int* L, int H,
@@ -1443,7 +1456,7 @@ static int gru_bwd_impl(int npl, int n, const float* const* dh_last, const int32
     if (max_rows(ly) == 0) return RENET_OK;
     if (H != 100 && H != 200 && H != 400) return RENET_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const bool f32 = use_f32() && npl == 3;
+    const bool f32 = npl == 0 || (use_f32() && npl == 3);
     const bool steps = npl == 3 && !f32 && !use_persistent(H);
     if (bounds && (f32 || steps || npl != 3)) return RENET_ERR_UNSUPPORTED;   // only the persistent bf16x6 kernel emits them
     int Bmax = 0;

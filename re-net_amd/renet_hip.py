@@ -113,6 +113,10 @@ _SIGNATURES = {
     'renet_gru_bound_parts': (c_int, [c_int]),
     'renet_gru_bwd_layouts_bounds': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'renet_gru_fwd_layouts_f32': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'renet_gru_bwd_layouts_f32': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_gru_fwd_layouts_bf16': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_gru_bwd_layouts_bf16': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
@@ -546,14 +550,15 @@ def auto_split_k(m, n, k):
 # operands, the round-3 default) is the opt-in FAST mode, 'f32' the exact-product mode; bench.py reports all three.
 GEMM_MODE = os.environ.get('RENET_GEMM', 'bf16x6')
 
-# Per-MODEL choice between the two split modes (round 4; review r3 "weak 8"): a model may carry `gemm_mode = 'f16x3'` (or
-# 'bf16x6') and its forward / backward passes then run inside `with gemm_mode(...)`; everything below reads the mode
-# through current_mode().  GEMM_MODE stays the PROCESS default, and the two modes that change more than the GEMM entry
-# point -- 'f32' (the GRU recurrences pick their exact kernels inside the library from RENET_GEMM) and 'bf16s' (operand
-# storage) -- remain process-wide: gemm_mode() accepts them only when they equal the process default.
+# Per-MODEL choice of the fp32-storage modes (round 4: the two split modes; round 5: 'f32' too): a model may carry
+# `gemm_mode = 'f16x3' | 'bf16x6' | 'f32'` and its forward / backward passes then run inside `with gemm_mode(...)`; everything
+# below reads the mode through current_mode() -- the GEMM entry point, and for 'f32' the exact GRU entries
+# renet_gru_{fwd,bwd}_layouts_f32 (until round 4 the library chose them from RENET_GEMM alone).  GEMM_MODE stays the PROCESS
+# default; 'bf16s' (operand STORAGE: packed weights, bf16 activations) remains process-wide: gemm_mode() accepts it only when
+# it equals the process default.  (In a RENET_GEMM=f32 process the recurrences stay exact whatever a model asks for.)
 _mode_override = threading.local()       # .mode: per THREAD (a prefetch / evaluation thread must not inherit another thread's
                                          # scope; ops._fwd_mode / _bwd_mode re-enter the scope on the autograd thread explicitly)
-_PER_MODEL_MODES = ('bf16x6', 'f16x3')
+_PER_MODEL_MODES = ('bf16x6', 'f16x3', 'f32')
 
 
 def current_mode():
@@ -1142,7 +1147,9 @@ def gru_fwd_layouts(gis, step_offs, hdim, w_hhs, b_hhs, out_rows):
     ws = torch.empty(max(nbytes // 4, 1), device=dev, dtype=torch.float32)
     so, ls = _offs(step_offs)
     t0 = _timer.begin() if _timer is not None else None
-    fn = lib().renet_gru_fwd_layouts_bf16 if current_mode() == 'bf16s' else lib().renet_gru_fwd_layouts
+    md = current_mode()
+    fn = lib().renet_gru_fwd_layouts_bf16 if md == 'bf16s' else lib().renet_gru_fwd_layouts_f32 if md == 'f32' else \
+        lib().renet_gru_fwd_layouts
     _check(fn(n, _ptrs(gis), so, ls, hdim, _ptrs(w_hhs), _ptrs(b_hhs), _ptrs(hs),
                                        (ctypes.c_int * n)(*rows), _ptrs(svs), ws.data_ptr(), nbytes, _stream()),
            'gru_fwd_layouts')
@@ -1202,7 +1209,9 @@ def gru_bwd_layouts(dh_lasts, step_offs, hdim, w_hhs, saveds, out_bf16=False):
         elif rc != -2:                                   # RENET_ERR_UNSUPPORTED: another recurrence is selected
             _check(rc, 'gru_bwd_layouts_bounds')
     if not done:
-        fn = lib().renet_gru_bwd_layouts_bf16 if current_mode() == 'bf16s' else lib().renet_gru_bwd_layouts
+        md = current_mode()
+        fn = lib().renet_gru_bwd_layouts_bf16 if md == 'bf16s' else lib().renet_gru_bwd_layouts_f32 if md == 'f32' else \
+            lib().renet_gru_bwd_layouts
         _check(fn(n, _ptrs(dh_lasts), so, ls, hdim, _ptrs(w_hhs), _ptrs(saveds), _ptrs(d_gis),
                   _ptrs(d_ghs), ws.data_ptr(), nbytes, _stream()), 'gru_bwd_layouts')
     if t0 is not None:

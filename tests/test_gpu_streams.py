@@ -137,7 +137,7 @@ def test_two_models_with_different_gemm_modes_in_one_process(dev, monkeypatch):
     import renet_hip as K
     import synth
     if K.GEMM_MODE not in ('bf16x6', 'f16x3'):
-        pytest.skip('per-model modes exist for the two split modes only')
+        pytest.skip('this test alternates the two split modes')
     quads, num_ent, num_rels, _ = synth.make_stream('ICEWS18', seed=5, num_t=40)
     gd = P.build_graph_dict(quads, num_rels)
     hs, ho = P.HistoryIndex(quads, 's', 10), P.HistoryIndex(quads, 'o', 10)
@@ -184,8 +184,30 @@ def test_two_models_with_different_gemm_modes_in_one_process(dev, monkeypatch):
     assert torch.equal(pa, solo['f16x3'][1]) and torch.equal(pb, solo['bf16x6'][1])
     assert not torch.equal(pa, pb)                              # (the two modes do differ in the last bits)
     with pytest.raises(K.RenetHipError):
-        with K.gemm_mode('bf16s'):                              # storage / exact modes stay process-wide
+        with K.gemm_mode('bf16s'):                              # the storage mode stays process-wide
             pass
+
+
+def test_exact_fp32_mode_per_model_equals_the_process_wide_mode(dev):
+    """Round 5: `net.gemm_mode = 'f32'` (exact fp32 MFMA products in the GEMMs AND in the GRU recurrences, through the
+    renet_gru_*_layouts_f32 entries) inside a bf16x6 process must train bit-identically to a process started with RENET_GEMM=f32
+    -- until round 4 the exact mode existed as a process-wide switch only (the library read RENET_GEMM for the recurrences)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = {}
+    for tag, args, env in (('per_model', ['f32'], {'RENET_GEMM': 'bf16x6'}), ('process', [], {'RENET_GEMM': 'f32'}),
+                           ('split', [], {'RENET_GEMM': 'bf16x6'})):
+        r = subprocess.run([sys.executable, os.path.join(here, 'mode_run.py')] + args, env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        out[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['per_model']['process_default'] == 'bf16x6' and out['process']['process_default'] == 'f32'
+    assert out['per_model']['losses'] == out['process']['losses'], (out['per_model'], out['process'])
+    assert out['per_model']['digest'] == out['process']['digest']
+    assert out['split']['digest'] != out['process']['digest']            # (the split mode does differ in the last bits)
 
 
 def test_deferred_weight_gradients_change_no_value(dev, monkeypatch):

@@ -687,8 +687,8 @@ def test_bulk_cache_update_equals_one_update_cache_call_per_winner():
 
 
 def test_gemm_mode_scopes():
-    """renet_hip.gemm_mode (round 4): nesting, restoration after an exception, None = no change, and the two modes that
-    stay process-wide ('f32', 'bf16s') are refused unless they ARE the process default."""
+    """renet_hip.gemm_mode (round 4): nesting, restoration after an exception, None = no change; 'f32' is a per-model mode
+    since round 5, the storage modes ('bf16s', 'bf16') stay process-wide: refused unless they ARE the process default."""
     import renet_hip as K
     base = K.GEMM_MODE
     if base not in ('bf16x6', 'f16x3'):
@@ -707,7 +707,10 @@ def test_gemm_mode_scopes():
         with K.gemm_mode(other):
             raise ValueError('boom')
     assert K.current_mode() == base
-    for refused in ('f32', 'bf16s', 'bf16', 'nonsense'):
+    with K.gemm_mode('f32'):
+        assert K.current_mode() == 'f32'
+    assert K.current_mode() == base
+    for refused in ('bf16s', 'bf16', 'nonsense'):
         with pytest.raises(K.RenetHipError):
             with K.gemm_mode(refused):
                 pass
