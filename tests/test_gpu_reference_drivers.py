@@ -58,7 +58,5 @@ def test_unmodified_reference_drivers_train_and_test_on_the_hip_path(tmp_path):
     print('unmodified drivers on the HIP path, 2 + 2 epochs: epoch losses %s, valid MRR %s, TEST MRR %.4f hits %s'
           % (losses, vmrr, mrr, hits))
     assert 0.3 < mrr < 0.9 and len(hits) == 3 and hits[0] <= hits[1] <= hits[2]
-    # the same test.py with the per-call evaluation (look-ahead off): same metrics to print precision
-    out_e2 = _run(work, 'test.py', ['-d', 'YAGO', '--gpu', '0', '--n-hidden', '200'], 1200, env={'RENET_LOOKAHEAD_EVAL': '0'})
-    mrr2 = float(re.search(r'MRR \(filtered\): ([0-9.]+)', out_e2).group(1))
-    assert abs(mrr - mrr2) <= 2e-5, (mrr, mrr2)
+    # (the same test.py with the look-ahead off prints the identical metrics in 44 s instead of 4.6 s:
+    #  profiles/r05_e_unmodified_drivers_readme_commands.md)
