@@ -95,8 +95,10 @@ def test_bf16_storage_gemm_on_prepacked_operands_and_sliced_weights(dev):
 
 # per-tensor relative L2 bound of the bf16-mode gradients against the fp32 reference: 2 x the largest value observed on MI355X
 # (profiles/r05_*_gpu_tests.txt prints every tensor's value); REL_L2_BOUND overrides it per tensor where needed
-REL_L2_DEFAULT = 5e-2
-REL_L2_BOUND = {}
+REL_L2_DEFAULT = 6.6e-3            # observed (profiles/r05_g_gpu_tests.txt, both bf16 modes): <= 3.3e-3 for 17 of the 20 tensors
+REL_L2_BOUND = {'ent_embeds': 4e-2,                       # 1.95e-2: the entity rows are READ as bf16 by layer 1 (bf16 storage)
+                'aggregator.rgcn1.weight': 5.6e-2,        # 2.78e-2  } layer 1 multiplies bf16 entity rows by bf16 relation
+                'aggregator.rgcn1.loop_weight': 6.4e-2}   # 3.19e-2  } blocks: its weight gradients carry both roundings
 
 
 @pytest.mark.parametrize('mode', ['bf16', 'bf16s'])
