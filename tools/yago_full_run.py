@@ -5,6 +5,7 @@ quadruples), the counterpart of tools/make_e2e_full_golden.py (the unmodified re
     python tools/yago_full_run.py <dropout> <epochs> <pre_epochs> <seed> [seed ...]      RENET_GEMM selects the GEMM mode
     RENET_FULL_TEST=1: continue over the TEST split as test.py does (filtered test MRR / Hits, README.md:169's metric);
     RENET_FULL_PRE_LR=<lr>: learning rate of the global model's pretraining (default 1e-2 = pretrain.py's; README: 1e-3)
+    RENET_FULL_H / RENET_FULL_SEQ_LEN: n_hidden / seq_len (BASELINE configs[4]: 400 / 15 with RENET_GEMM=bf16s)
 
 per seed: pretrain.py's loop for the global model -> get_global_emb -> train.py's loop as the PRODUCT runs it (merged pass,
 HipAdam) -> train.py's filtered validation (train.py:151-185, one batch per timestamp) -> MRR / Hits@1,3,10.  When the
@@ -36,12 +37,17 @@ def main():
     cfg = dict(T.FULL_CFG, dropout=dropout, epochs=epochs, pre_epochs=pre_epochs)
     if os.environ.get('RENET_FULL_PRE_LR'):
         cfg['pre_lr'] = float(os.environ['RENET_FULL_PRE_LR'])
+    if os.environ.get('RENET_FULL_H'):                 # BASELINE configs[4]: n_hidden 400, seq_len 15 (RENET_GEMM=bf16s)
+        cfg['h'] = int(os.environ['RENET_FULL_H'])
+    if os.environ.get('RENET_FULL_SEQ_LEN'):
+        cfg['seq_len'] = int(os.environ['RENET_FULL_SEQ_LEN'])
     test_too = os.environ.get('RENET_FULL_TEST') == '1'
     tag = 'd0' if dropout == 0.0 else 'drop'
     fpath = os.path.join(GOLDEN, 'e2e_yago_full_%s.npz' % tag)
     gold = np.load(fpath) if os.path.isfile(fpath) else None
     if gold is not None and (int(gold['epochs']) != epochs or int(gold['pre_epochs']) != pre_epochs or
-                             abs(float(gold['pre_lr']) - cfg['pre_lr']) > 1e-12):
+                             abs(float(gold['pre_lr']) - cfg['pre_lr']) > 1e-12 or int(gold['h']) != cfg['h'] or
+                             int(gold['seq_len']) != cfg['seq_len']):
         gold = None                                   # a different schedule (e.g. the 20-epoch run): nothing to replay
     res, t0 = [], time.time()
     for seed in seeds:
@@ -67,10 +73,11 @@ def main():
         res.append((rec, ranks))
     out_dir = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(out_dir, exist_ok=True)
-    np.savez_compressed(os.path.join(out_dir, 'yago_full_%s_%s_e%d.npz' % (tag, K.GEMM_MODE, epochs)),
+    np.savez_compressed(os.path.join(out_dir, 'yago_full_%s_%s_h%d_e%d.npz' % (tag, K.GEMM_MODE, cfg['h'], epochs)),
                         seeds=np.asarray(seeds), ranks=np.stack([r[1] for r in res]).astype(np.int32),
                         mrr=np.asarray([r[0]['mrr'] for r in res]))
-    print(json.dumps({'gemm_mode': K.GEMM_MODE, 'dropout': dropout, 'epochs': epochs, 'pre_epochs': pre_epochs,
+    print(json.dumps({'gemm_mode': K.GEMM_MODE, 'dropout': dropout, 'epochs': epochs, 'pre_epochs': pre_epochs, 'n_hidden': cfg['h'],
+                      'seq_len': cfg['seq_len'],
                       'num_k': cfg['num_k'], 'train_quadruples': int(len(data['train'])),
                       'valid_quadruples': int(len(data['valid'])), 'runs': [r[0] for r in res],
                       'seconds': time.time() - t0}))
