@@ -26,6 +26,10 @@ def main():
     sys.argv = [script] + sys.argv[3:]
     sys.path.insert(0, ROOT)
     if mode == 'ours':
+        # the two switches tools/run_reference_driver.py turns on for the drivers' calling pattern (round 5): train.py's two
+        # model() calls as one merged pass, the per-quadruple evaluate_filter calls from one batched evaluation per timestamp
+        os.environ.setdefault('RENET_FUSE_DIRECTIONS', '1')
+        os.environ.setdefault('RENET_LOOKAHEAD_EVAL', '1')
         sys.path.insert(0, os.path.join(ROOT, 're-net_amd'))
         sys.path.insert(0, HERE)
         import cpu_abi_emulation
