@@ -117,7 +117,12 @@ def test_yago_prefix_training_and_filtered_mrr_match_reference(tag, loop):
         assert abs(mine[k] - ref[k]) <= 0.01, (k, mine[k], ref[k])
 
 
-@pytest.mark.parametrize('mode', ['bf16x6', 'f16x3', 'f32', 'bf16s'])
+# exact fp32 equals bf16x6 to 1e-6 per seed (profiles/r04_c_train_mode_mrr.md, r05_c section 1b): run on request only, to keep
+# the default GPU suite short (RENET_TEST_ALL_MODES=1)
+_TRAIN_MODES = ['bf16x6', 'f16x3', 'bf16s'] + (['f32'] if os.environ.get('RENET_TEST_ALL_MODES') == '1' else [])
+
+
+@pytest.mark.parametrize('mode', _TRAIN_MODES)
 def test_train_mode_filtered_mrr_matches_reference_statistically(mode):
     """The mode bench.py TIMES -- dropout 0.5 at all four sites (RGCN.py:36-37, Aggregator.py:157-158, model.py:90,99) --
     against the unmodified reference trained the same way (tools/make_e2e_drop_golden.py -> tests/golden/e2e_yago_drop.npz:
