@@ -30,11 +30,20 @@ def flat_layout(params):
     return offs, off
 
 
+def ordered_params(module, first=()):
+    """The trainable parameters of `module` in parameter order, those in `first` moved to the front (same relative order)."""
+    ps = [p for p in module.parameters() if p.requires_grad]
+    ids = {id(p) for p in first}
+    return [p for p in ps if id(p) in ids] + [p for p in ps if id(p) not in ids]
+
+
 class FlatGrads(object):
     """Makes every parameter's .grad a view into one contiguous buffer."""
 
-    def __init__(self, module):
-        self.params = [p for p in module.parameters() if p.requires_grad]
+    def __init__(self, module, first=()):
+        """first: parameters to place at the START of the buffer (HipAdam puts the score head there, so that everything
+        else is ONE contiguous tail region: two collectives per step instead of three)."""
+        self.params = ordered_params(module, first)
         self.offsets, total = flat_layout(self.params)
         dev = self.params[0].device if self.params else torch.device('cpu')
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -237,8 +246,8 @@ class FlatParams(object):
     """Moves every parameter of `module` into ONE contiguous buffer (param.data become views), in the same
     order as FlatGrads, so that the optimizer is a single fused kernel over flat buffers."""
 
-    def __init__(self, module):
-        self.params = [p for p in module.parameters() if p.requires_grad]
+    def __init__(self, module, first=()):
+        self.params = ordered_params(module, first)
         self.offsets, total = flat_layout(self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -262,8 +271,12 @@ class HipAdam(object):
         import renet_hip as K
         self.K = K
         self._module = module          # (its `gemm_mode` attribute is read at every step)
-        self.params = FlatParams(module)
-        self.grads = FlatGrads(module)            # same layout (flat_layout) as the parameters
+        # the score head's parameters FIRST in both flat buffers: the early bucket is then [0, n) and everything else one
+        # contiguous tail -- two collectives per step instead of three (round 5: every RCCL call costs the launching thread
+        # ~0.15 ms, and that thread already paces the step; profiles/r05_i_one_rank_rccl_trace.md)
+        head = [p for n, p in module.named_parameters() if n in ('linear.weight', 'linear.bias')]
+        self.params = FlatParams(module, first=head)
+        self.grads = FlatGrads(module, first=head)     # same layout (flat_layout) as the parameters
         self.m = torch.zeros_like(self.params.flat)
         self.v = torch.zeros_like(self.params.flat)
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
