@@ -272,8 +272,7 @@ class HipAdam(object):
         self.K = K
         self._module = module          # (its `gemm_mode` attribute is read at every step)
         # the score head's parameters FIRST in both flat buffers: the early bucket is then [0, n) and everything else one
-        # contiguous tail -- two collectives per step instead of three (round 5: every RCCL call costs the launching thread
-        # ~0.15 ms, and that thread already paces the step; profiles/r05_i_one_rank_rccl_trace.md)
+        # contiguous tail -- two collectives per step instead of three (round 5; profiles/r05_i_one_rank_rccl_trace.md)
         head = [p for n, p in module.named_parameters() if n in ('linear.weight', 'linear.bias')]
         self.params = FlatParams(module, first=head)
         self.grads = FlatGrads(module, first=head)     # same layout (flat_layout) as the parameters
