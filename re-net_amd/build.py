@@ -28,7 +28,37 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+WALK_SRC = os.path.join(CSRC, 'listwalk.c')
+WALK_LIB = os.path.join(HERE, '_renet_listwalk.so')
+
+
+def build_listwalk(force=False, verbose=True):
+    """The host-side list flattener (csrc/listwalk.c: CPython C API, no device code) -> re-net_amd/_renet_listwalk.so.
+    Optional: graph.FlatHistory.from_lists keeps its numpy formulation for a box without a C compiler or Python headers --
+    a failure here is reported, not raised (the HIP library below is the part without a fallback)."""
+    import sysconfig
+    if not force and os.path.isfile(WALK_LIB) and os.path.getmtime(WALK_LIB) >= os.path.getmtime(WALK_SRC):
+        return WALK_LIB
+    inc = sysconfig.get_paths().get('include')
+    extra = []
+    try:                                   # numpy's headers, when present: ndarrays read through their struct
+        import numpy
+        extra = ['-DRENET_LISTWALK_NUMPY', '-I' + numpy.get_include()]
+    except Exception:
+        pass
+    cmd = [os.environ.get('CC', 'gcc'), '-O2', '-shared', '-fPIC', '-I' + str(inc)] + extra + [WALK_SRC, '-o', WALK_LIB]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    try:
+        subprocess.check_call(cmd)
+    except (OSError, subprocess.CalledProcessError) as e:
+        print('listwalk.c not built (%s): FlatHistory.from_lists uses its numpy formulation' % e, flush=True)
+        return None
+    return WALK_LIB
+
+
 def build(force=False, verbose=True):
+    build_listwalk(force, verbose)
     if not force and not stale():
         return LIB
     objs = []

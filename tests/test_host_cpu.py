@@ -716,3 +716,41 @@ def test_gemm_mode_scopes():
                 pass
     with K.gemm_mode(base):                      # the process default itself is always accepted
         pass
+
+
+def test_c_list_flattener_equals_the_numpy_formulation():
+    """csrc/listwalk.c (graph._listwalk, optional) against FlatHistory.from_lists' numpy path: real histories, empty sequences and
+    steps, strided / Fortran-ordered / int32 step arrays, numpy and Python timestamps, tuples (declined -> numpy path)."""
+    if G._listwalk is None:
+        pytest.skip('_renet_listwalk.so not built (python re-net_amd/build.py)')
+    cfg, tr, va, te = fixtures.split_dataset('small')
+    (sh, sht), _, _ = O.build_histories(tr, cfg['num_ent'])
+    rs = np.random.RandomState(3)
+    pick = rs.permutation(len(sh))[:300].tolist()
+    hist = [list(sh[i]) for i in pick] + [[], [np.zeros((0, 2), dtype=np.int64)]]
+    hist_t = [[np.int64(t) if k % 2 else int(t) for k, t in enumerate(sht[i])] for i in pick] + [[], [7]]
+    hist[0] = [np.asfortranarray(a) for a in hist[0]]
+    hist[1] = [np.concatenate((a, a))[::2] for a in hist[1]]            # strided views
+    hist[2] = [a.astype(np.int32) for a in hist[2]]                      # declined by the C path -> numpy formulation, same values
+
+    def flat(use_c):
+        saved = G._listwalk
+        if not use_c:
+            G._listwalk = None
+        try:
+            return G.FlatHistory.from_lists(hist, hist_t)
+        finally:
+            G._listwalk = saved
+    a, b = flat(True), flat(False)
+    for f in ('seq_ptr', 'step_t', 'nbr_ptr', 'nbr_o'):
+        assert np.array_equal(getattr(a, f), getattr(b, f)) and getattr(a, f).dtype == np.int64, f
+    hist2 = [h for k, h in enumerate(hist) if k != 2]
+    hist_t2 = [h for k, h in enumerate(hist_t) if k != 2]
+    lens, cnt, nbr, st = (np.frombuffer(x, dtype=np.int64) for x in G._listwalk.flatten(hist2, hist_t2))
+    ref = G.FlatHistory.from_lists(tuple(hist2), tuple(hist_t2))        # tuples: the numpy path
+    assert np.array_equal(np.concatenate(([0], np.cumsum(lens))), ref.seq_ptr) and np.array_equal(nbr, ref.nbr_o)
+    assert np.array_equal(st, ref.step_t) and np.array_equal(np.concatenate(([0], np.cumsum(cnt))), ref.nbr_ptr)
+    with pytest.raises(TypeError):
+        G._listwalk.flatten([[np.zeros((2, 3), dtype=np.int64)]], [[1]])
+    with pytest.raises(TypeError):
+        G._listwalk.flatten([[np.zeros((2, 2), dtype=np.int64)]], [[1, 2]])
