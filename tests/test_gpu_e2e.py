@@ -117,9 +117,9 @@ def test_yago_prefix_training_and_filtered_mrr_match_reference(tag, loop):
         assert abs(mine[k] - ref[k]) <= 0.01, (k, mine[k], ref[k])
 
 
-# exact fp32 equals bf16x6 to 1e-6 per seed (profiles/r04_c_train_mode_mrr.md, r05_c section 1b): run on request only, to keep
-# the default GPU suite short (RENET_TEST_ALL_MODES=1)
-_TRAIN_MODES = ['bf16x6', 'f16x3', 'bf16s'] + (['f32'] if os.environ.get('RENET_TEST_ALL_MODES') == '1' else [])
+# exact fp32 equals bf16x6 to 1e-6 per seed and f16x3 to 3e-4 (profiles/r04_c_train_mode_mrr.md, r05_c section 1b; all four modes
+# measured in tools/sessions/r05_s8.sh): those two run on request only, to keep the default GPU suite short (RENET_TEST_ALL_MODES=1)
+_TRAIN_MODES = ['bf16x6', 'bf16s'] + (['f16x3', 'f32'] if os.environ.get('RENET_TEST_ALL_MODES') == '1' else [])
 
 
 @pytest.mark.parametrize('mode', _TRAIN_MODES)
