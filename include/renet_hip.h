@@ -290,6 +290,38 @@ int renet_colsum_bf16(const void* X, int M, int N, int ldx, float* out, float be
                       size_t workspace_bytes, void* stream);
 int renet_scale_bf16_by_device_scalar(void* x, size_t n, const float* scale, void* stream);
 
+/* PLANES (round 6): the bf16x6 arithmetic of renet_gemm_f32_split on operands that are ALREADY split -- a matrix [R, C] is
+ * stored as three bf16 matrices ("planes", x = p1 + p2 + p3, p1 = rne(x), p2 = rne(x - p1), p3 = rne(x - p1 - p2): the
+ * split the bf16x6 loaders perform per k-tile), each [Rp][Cp] row-major with Rp, Cp = R, C rounded up to multiples of 256
+ * and ZERO padding, `plane` elements apart.  The producers write the format directly (renet_softmax_ce_planes: the CE
+ * gradient; renet_adam_step_planes: the score-head weight; renet_pack_planes: anything else), so the GEMM k-loop contains
+ * no conversion: LDS-DMA staging (global_load_lds) into a 2-slot ring of 256 x 128 x 32 stages, six
+ * v_mfma_f32_32x32x16_bf16 per fragment pair, fp32 accumulation; same result as renet_gemm_f32_split up to fp32
+ * summation order.
+ *   renet_planes_elems : Rp * Cp, the element count of one plane (the plane stride the packers use)
+ *   renet_pack_planes  : fp32 X[R, C] (row stride ldx) -> planes; ones_col != 0 appends a column of ones (C + 1 columns:
+ *                        see col_out)
+ *   renet_gemm_planes  : C[M, N] = alpha * (*alpha_dev) * op(A) op(B) (+ bias) (+ beta * C)
+ *       a_tr == 0: A stored [M rows][K cols];  a_tr == 1: stored [K rows][M cols] (contraction over its rows)
+ *       b_tr == 0: B^T stored [N rows][K cols] (nn.Linear's weight layout);  b_tr == 1: B stored [K rows][N cols]
+ *       alpha_dev : optional DEVICE scalar folded into alpha (the upstream autograd gradient: no pass over the operand)
+ *       col_out   : optional; N then counts one EXTRA logical column whose values go to col_out[M] instead of C -- with
+ *                   B packed with ones_col this is the bias gradient sum_k op(A)[m, k] inside the weight-gradient GEMM
+ *       split_k / workspace as renet_gemm_f32 (renet_gemm_workspace(M, N, split_k) with this N).
+ * Replaces nn.Linear's forward and backward GEMMs of the entity score head (model.py:89-90 and autograd), like
+ * renet_gemm_f32_split. */
+size_t renet_planes_elems(int R, int C);
+int renet_pack_planes(const float* X, int R, int C, int ldx, int ones_col, void* out, void* stream);
+int renet_gemm_planes(int a_tr, int b_tr, int M, int N, int K, float alpha, const float* alpha_dev, const void* Ap,
+                      int lda, size_t a_plane, const void* Bp, int ldb, size_t b_plane, float beta, float* C, int ldc,
+                      const float* bias, float* col_out, int split_k, float* workspace, size_t workspace_bytes,
+                      void* stream);
+/* renet_softmax_ce with the gradient (softmax - onehot) * grad_scale written as planes [3][rows16][ld16] (`plane`
+ * elements apart; ld16 % 4 == 0; columns [C, ceil64(C)) and rows [B, rows16) zeroed); the fp32 logits are left untouched.
+ * Replaces F.cross_entropy's backward (model.py:91,100) as renet_softmax_ce does. */
+int renet_softmax_ce_planes(const float* logits, const int32_t* target, int B, int C, int ld, float grad_scale,
+                            float* row_loss, void* dl_planes, size_t plane, int ld16, int rows16, void* stream);
+
 /* column sums: out[n] = beta * out[n] + sum_m X[m,n]  (bias gradients; beta = 1 accumulates straight into
  * an existing .grad); two deterministic passes over row groups, `workspace` = renet_colsum_workspace(M, N)
  * bytes (0 for short matrices). */

@@ -1359,6 +1359,7 @@ int kernel_choice(int ntiles) {
 }
 
 #include "gemm_h3.h"
+#include "gemm_p6.h"
 
 }  // namespace
 
@@ -1732,6 +1733,72 @@ int renet_gemm_bf16s(int a_tr, int b_tr, int M, int N, int K, float alpha, const
             RENET_LAUNCH(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, split_k, M, N, alpha,
                                beta, bias, C, ldc);
         }
+        RENET_LAUNCH_CHECK();
+    }
+    return RENET_OK;
+}
+
+// ---- planes GEMM (gemm_p6.h) -----------------------------------------------------------------------------------
+size_t renet_planes_elems(int R, int C) {
+    const size_t rp = ((size_t)R + 255) & ~(size_t)255, cp = ((size_t)C + 255) & ~(size_t)255;
+    return rp * cp;
+}
+
+int renet_pack_planes(const float* X, int R, int C, int ldx, int ones_col, void* out, void* stream) {
+    if (R < 0 || C < 0 || ldx < C || !out) return RENET_ERR_BADARG;
+    const int cols = ones_col ? C + 1 : C;
+    const int Rp = (R + 255) & ~255, Cp = (cols + 255) & ~255;
+    if (Rp == 0 || Cp == 0) return RENET_OK;
+    const size_t total = (size_t)Rp * Cp / 4;
+    const int blocks = (int)min((size_t)4096, (total + 255) / 256);
+    RENET_LAUNCH(pack_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, R, C, ldx, Rp, Cp,
+                 ones_col ? C : -1, (__bf16*)out, (size_t)Rp * Cp);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_gemm_planes(int a_tr, int b_tr, int M, int N, int K, float alpha, const float* alpha_dev, const void* Ap,
+                      int lda, size_t a_plane, const void* Bp, int ldb, size_t b_plane, float beta, float* C, int ldc,
+                      const float* bias, float* col_out, int split_k, float* workspace, size_t workspace_bytes,
+                      void* stream) {
+    // N counts the logical columns of the product INCLUDING the col_out one
+    const int n_main = col_out ? N - 1 : N;
+    if (M < 0 || N < 0 || n_main < 0 || K < 1 || ldc < n_main || !Ap || !Bp) return RENET_ERR_BADARG;
+    if (M == 0 || N == 0) return RENET_OK;
+    const int Mp = (M + 255) & ~255, Np = (N + 127) & ~127, Kp = (K + 15) & ~15;
+    if (lda < (a_tr ? Mp : Kp) || ldb < (b_tr ? Np : Kp) || (lda & 7) || (ldb & 7)) return RENET_ERR_BADARG;
+    // the plane strides must cover the stored (padded) matrix
+    if (a_plane < (size_t)(a_tr ? Kp : Mp) * lda || b_plane < (size_t)(b_tr ? Kp : Np) * ldb) return RENET_ERR_BADARG;
+    if (split_k < 1) split_k = 1;
+    const int st_total = (K + 15) / 16;                       // half-stages of 16 k (gemm_p6.h)
+    if (split_k > st_total) split_k = max(st_total, 1);
+    if (split_k > 1 && workspace_bytes < renet_gemm_workspace(M, N, split_k)) return RENET_ERR_WORKSPACE;
+    P6Args pa;
+    pa.A = (const __bf16*)Ap; pa.B = (const __bf16*)Bp;
+    pa.a_plane = a_plane; pa.b_plane = b_plane;
+    pa.lda = lda; pa.ldb = ldb;
+    pa.alpha_dev = alpha_dev; pa.col_out = col_out;
+    SplitArgs& g = pa.out;
+    g.A = nullptr; g.B = nullptr; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
+    g.lda = 0; g.ldb = 0; g.ldc = ldc; g.alpha = alpha; g.beta = beta;
+    g.split_k = split_k;
+    g.k_tiles_per_split = max(1, (st_total + split_k - 1) / split_k);
+    g.partial = workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const int nbx = (N + BN - 1) / BN, nby = Mp / 256;
+    g.xcd_order = panel_width(tile_order(), nbx, nby, 256, K, split_k, 32);
+    dim3 grid(nbx, nby, split_k);
+    int e;
+    if (!a_tr && !b_tr) e = launch_p6<false, false>(pa, grid, st);
+    else if (!a_tr && b_tr) e = launch_p6<false, true>(pa, grid, st);
+    else if (a_tr && !b_tr) e = launch_p6<true, false>(pa, grid, st);
+    else e = launch_p6<true, true>(pa, grid, st);
+    if (e != RENET_OK) return e;
+    if (split_k > 1) {
+        const size_t total = (size_t)M * N;
+        const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+        RENET_LAUNCH(p6_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, split_k, M, N, alpha, alpha_dev, beta,
+                     bias, C, ldc, col_out);
         RENET_LAUNCH_CHECK();
     }
     return RENET_OK;

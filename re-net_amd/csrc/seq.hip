@@ -390,6 +390,144 @@ __global__ __launch_bounds__(1024) void softmax_ce_lds_kernel(const float* logit
     }
 }
 
+// ---- the CE gradient as THREE bf16 PLANES (round 6): the operand format of renet_gemm_planes (gemm_p6.h) -----------
+// dl = (softmax - onehot) * grad_scale is never stored as fp32: each value leaves this kernel as p1 = rne(dl),
+// p2 = rne(dl - p1), p3 = rne(dl - p1 - p2) -- the split the bf16x6 GEMM loaders (gemm_split.hip: store_items) do per k-tile
+// -- into planes [3][rows16][ld16]; 6 bytes per element instead of 4, and the backward GEMMs that consume it (dfeat, dW)
+// run without any conversion work in their k-loops.  Columns [C, C64) of every row are written as zeros.
+typedef uint32_t sq_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t sq_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3_f4(float4 v, sq_u32x2 (&out)[3]) {
+    sq_f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const sq_bf16x2 blo = __builtin_convertvector(lo, sq_bf16x2);
+        const sq_bf16x2 bhi = __builtin_convertvector(hi, sq_bf16x2);
+        out[p].x = __builtin_bit_cast(uint32_t, blo);
+        out[p].y = __builtin_bit_cast(uint32_t, bhi);
+        if (p < 2) {
+            lo -= __builtin_convertvector(blo, sq_f32x2);
+            hi -= __builtin_convertvector(bhi, sq_f32x2);
+        }
+    }
+}
+
+// Row in registers (the structure of softmax_ce_reg_kernel): 512 threads, thread t owns the float4 groups at columns
+// 4 t + 2048 q, q < NQ4 (<= 12: C <= 24 576); needs 16-byte aligned rows (ld % 4 == 0).
+template <int NQ4>
+__global__ __launch_bounds__(512, 4) void softmax_ce_planes_kernel(const float* __restrict__ logits,
+                                                                   const int32_t* __restrict__ target, int C, int ld,
+                                                                   float grad_scale, float* __restrict__ row_loss,
+                                                                   __bf16* __restrict__ P, size_t plane, int ld16) {
+    __shared__ float red_m[8], red_s[8];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = target[b];
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(logits + (size_t)b * ld), (short)0, C * 4, 0x00020000);
+    const int voff = (int)threadIdx.x * 16;
+    float4 v[NQ4];
+#pragma unroll
+    for (int q = 0; q < NQ4; ++q) {
+        const sq_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rin, voff, 8192 * q, 0);
+        v[q] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+    }
+    float m = -INFINITY, xt = 0.f;
+    const int tg = t >> 2;                              // column t is component t & 3 of float4 group tg
+    const bool mine = (int)threadIdx.x == (tg & 511);
+    const int tq = tg >> 9, tc = t & 3;
+    const int c0 = (int)threadIdx.x * 4;
+#pragma unroll
+    for (int q = 0; q < NQ4; ++q) {
+        const int lim = C - 2048 * q;                   // scalar bound: columns c0 + j < lim are real
+        v[q].x = c0 < lim ? v[q].x : -INFINITY;
+        v[q].y = c0 + 1 < lim ? v[q].y : -INFINITY;
+        v[q].z = c0 + 2 < lim ? v[q].z : -INFINITY;
+        v[q].w = c0 + 3 < lim ? v[q].w : -INFINITY;
+        m = fmaxf(fmaxf(m, fmaxf(v[q].x, v[q].y)), fmaxf(v[q].z, v[q].w));
+        if (mine && q == tq) xt = tc == 0 ? v[q].x : tc == 1 ? v[q].y : tc == 2 ? v[q].z : v[q].w;
+    }
+    m = wave_max(m);
+    if (lane == 0) red_m[wave] = m;
+    __syncthreads();
+    m = red_m[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fmaxf(m, red_m[w]);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ4; ++q) {
+        v[q].x = expf(v[q].x - m); v[q].y = expf(v[q].y - m); v[q].z = expf(v[q].z - m); v[q].w = expf(v[q].w - m);
+        s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+        if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);       // eight expf at a time (register budget, as above)
+    }
+    s = wave_sum(s);
+    if (lane == 0) red_s[wave] = s;
+    __syncthreads();
+    s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += red_s[w];
+    if (mine) row_loss[b] = logf(s) + m - xt;
+    // stores through one descriptor per plane: exactly the C64 (<= ld16) bf16 of the row; groups beyond are dropped
+    const int C64 = min((C + 63) & ~63, ld16);
+    __amdgpu_buffer_rsrc_t rout[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        rout[p] = __builtin_amdgcn_make_buffer_rsrc(P + (size_t)p * plane + (size_t)b * ld16, (short)0, C64 * 2, 0x00020000);
+    const float inv = 1.f / s;
+    const int vo = (int)threadIdx.x * 8;
+#pragma unroll
+    for (int q = 0; q < NQ4; ++q) {
+        float4 o = make_float4(v[q].x * inv, v[q].y * inv, v[q].z * inv, v[q].w * inv);
+        if (mine && q == tq) {
+            if (tc == 0) o.x -= 1.f; else if (tc == 1) o.y -= 1.f; else if (tc == 2) o.z -= 1.f; else o.w -= 1.f;
+        }
+        o = f4_scale(o, grad_scale);
+        sq_u32x2 pk[3];
+        split3_f4(o, pk);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) __builtin_amdgcn_raw_buffer_store_b64(pk[p], rout[p], vo, 4096 * q, 0);
+    }
+}
+
+// any width / alignment: three passes over the row (the structure of softmax_ce_kernel), planes out
+__global__ __launch_bounds__(256) void softmax_ce_planes_generic_kernel(const float* __restrict__ logits,
+                                                                        const int32_t* __restrict__ target, int C, int ld,
+                                                                        float grad_scale, float* __restrict__ row_loss,
+                                                                        __bf16* __restrict__ P, size_t plane, int ld16) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* x = logits + (size_t)b * ld;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, x[c]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += expf(x[c] - m);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    const int t = target[b];
+    if (threadIdx.x == 0) row_loss[b] = logf(s) + m - x[t];
+    const float inv = 1.f / s;
+    const int C64 = min((C + 63) & ~63, ld16);
+    __bf16* dx = P + (size_t)b * ld16;
+    for (int c = threadIdx.x; c < C64; c += 256) {
+        float r = c < C ? (expf(x[c] - m) * inv - (c == t ? 1.f : 0.f)) * grad_scale : 0.f;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const __bf16 h = (__bf16)r;
+            dx[(size_t)p * plane + c] = h;
+            r -= (float)h;
+        }
+    }
+}
+
 // ---- dgl.max_nodes / mean_nodes (Aggregator.py:58-61) ------------------------------------------
 __global__ __launch_bounds__(256) void segment_pool_fwd_kernel(const float* __restrict__ h,
                                                                const int32_t* __restrict__ seg_ptr, int D,
@@ -647,6 +785,36 @@ static int softmax_ce_impl(const float* logits, const int32_t* target, int B, in
     } else {
         RENET_LAUNCH(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, target, C, ld,
                      grad_scale, row_loss, dlogits, dl16, ld16);
+    }
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_softmax_ce_planes(const float* logits, const int32_t* target, int B, int C, int ld, float grad_scale,
+                            float* row_loss, void* dl_planes, size_t plane, int ld16, int rows16, void* stream) {
+    if (B < 0 || C <= 0 || ld < C || !dl_planes || ld16 < C || (ld16 & 3) || rows16 < B) return RENET_ERR_BADARG;
+    if (plane < (size_t)rows16 * ld16) return RENET_ERR_BADARG;
+    if (B == 0) return RENET_OK;
+    hipStream_t st = (hipStream_t)stream;
+    __bf16* P = (__bf16*)dl_planes;
+    // rows [B, rows16): the k padding of dW = dl^T feat (contraction over the rows) must be zero in every plane
+    if (rows16 > B) {
+        for (int p = 0; p < 3; ++p) {
+            hipError_t e = hipMemsetAsync(P + (size_t)p * plane + (size_t)B * ld16, 0,
+                                          (size_t)(rows16 - B) * ld16 * sizeof(__bf16), st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    const bool aligned = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(dl_planes) & 7) == 0 && (plane & 3) == 0;
+    if (aligned && C >= 2048 && C <= 12 * 2048) {
+        const dim3 grid(B), blk(512);
+        if (C <= 4 * 2048) RENET_LAUNCH((softmax_ce_planes_kernel<4>), grid, blk, 0, st, logits, target, C, ld, grad_scale, row_loss, P, plane, ld16);
+        else if (C <= 8 * 2048) RENET_LAUNCH((softmax_ce_planes_kernel<8>), grid, blk, 0, st, logits, target, C, ld, grad_scale, row_loss, P, plane, ld16);
+        else RENET_LAUNCH((softmax_ce_planes_kernel<12>), grid, blk, 0, st, logits, target, C, ld, grad_scale, row_loss, P, plane, ld16);
+    } else {
+        RENET_LAUNCH(softmax_ce_planes_generic_kernel, dim3(B), dim3(256), 0, st, logits, target, C, ld, grad_scale,
+                     row_loss, P, plane, ld16);
     }
     RENET_LAUNCH_CHECK();
     return RENET_OK;

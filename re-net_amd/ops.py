@@ -628,8 +628,20 @@ def dual_gru(x, xr, enc, enc_r, step_off, total_rows):
 
 def _head_forward(a, ia, hmid, c, ic, weight, bias, target, drop_p, seed, grad_scale, need_grad, row_loss=None):
     """One score head up to the per-row losses: [a[ia] | hmid | c[ic]] -> dropout -> Linear -> CE.
-    -> (row_loss[B], feat, logits-or-gradient buffer, bf16 gradient matrix or None, bf16 copy of feat or None)"""
+    -> (row_loss[B], feat, logits-or-gradient buffer, bf16 / planes gradient matrix or None, operand handle of feat or None)"""
     feat = K.concat3_fwd(a, ia, hmid, c, ic, drop_p, seed)
+    if need_grad and debug_tap is None and K.use_planes(weight, weight.shape[0]):
+        # PLANES path (round 6, the entity head): every operand of the head's three GEMMs is split into its bf16 terms ONCE
+        # -- the weight per optimizer step, feat here, the CE gradient by the kernel that computes it -- and the GEMMs run
+        # without conversion work (csrc/gemm_p6.h).  The fp32 logits live in a scratch buffer with 16-byte aligned rows
+        # and are dropped after the loss; no fp32 copy of the gradient exists.
+        b_, c_ = feat.shape[0], weight.shape[0]
+        w_pl = K.weight_planes(weight)
+        logits = torch.empty(b_, (c_ + 3) & ~3, device=feat.device, dtype=torch.float32)[:, :c_]
+        K.gemm_planes(K.pack_planes(feat), w_pl, tb=True, bias=bias, out=logits)
+        row_loss, dl_pl = K.softmax_ce_planes(logits, target, grad_scale, row_loss=row_loss)
+        # feat with a ones column: dW's GEMM then yields the bias gradient as one more output column (col_out)
+        return row_loss, feat, feat.new_empty(0), dl_pl, K.pack_planes(feat, ones_col=True)
     feat_op = K.operand(feat)                                        # (bf16 mode: packed once, reused by dW)
     logits = K.gemm(feat_op, weight, tb=True, bias=bias)             # [B, C]
     if debug_tap is not None:
@@ -648,16 +660,28 @@ def _scale_ce_gradient(dlogits, g, grad_scale):
     """dlogits *= g (the upstream scalar, device memory) -> the bound |g| * grad_scale on max |dlogits| as a 1-element
     device tensor in f16x3 mode (those GEMMs scale their operands by a bound on the tensor's magnitude; |softmax -
     onehot| <= 1, so this one is known without a pass over the 188 MB), else None."""
+    if isinstance(dlogits, K.PlanesMat):
+        return None                      # (the planes GEMMs take the upstream scalar as alpha_dev: no pass over the gradient)
     if K.current_mode() == 'f16x3' and not isinstance(dlogits, K.BF16Mat) and dlogits.is_cuda:
         return K.scale_by_device_scalar(dlogits, g, bound_in=float(grad_scale))
     K.scale_by_device_scalar(dlogits, g)
     return None
 
 
-def _head_backward(dlogits, feat, feat_op, weight, t_w, t_b, bias_side=None, bound=None):
+def _head_backward(dlogits, feat, feat_op, weight, t_w, t_b, bias_side=None, bound=None, g=None):
     """The three gradient products of one score head from its (already scaled) CE gradient -> (dfeat, d_w, d_b).
     bias_side: a _Side whose stream takes the bias column sum (bandwidth bound, next to the matrix-bound GEMMs that
-    read the same gradient).  bound: see _scale_ce_gradient."""
+    read the same gradient).  bound: see _scale_ce_gradient.  g: the upstream scalar (device), applied here when the
+    gradient arrives as planes (it was NOT scaled then)."""
+    if isinstance(dlogits, K.PlanesMat):
+        w_pl = K.weight_planes(weight)
+        dfeat = K.gemm_planes(dlogits, w_pl, alpha_dev=g)            # [B, parts*D]: contraction over the classes
+        # dW and db in ONE product: [C, parts*D | 1] = dl^T @ [feat | 1]
+        acc = t_w is not None and t_b is not None
+        d_w = t_w if acc else torch.empty_like(weight)
+        d_b = t_b if acc else torch.empty(weight.shape[0], device=weight.device, dtype=torch.float32)
+        K.gemm_planes(dlogits, feat_op, ta=True, out=d_w, col_out=d_b, alpha_dev=g, beta=1.0 if acc else 0.0)
+        return dfeat, (None if acc else d_w), (None if acc else d_b)
     dl_op = K.operand(dlogits, bound=bound)                          # consumed by dfeat and dW
     f_op = feat_op if feat_op is not None else feat
 
@@ -724,7 +748,7 @@ class HeadCEFn(Function):
             dlogits = ctx.dl_bf16
         bound = _scale_ce_gradient(dlogits, g, ctx.grad_scale)
         sd = _Side(feat.device)
-        dfeat, d_w, d_b = _head_backward(dlogits, feat, ctx.feat_op, weight, t_w, t_b, bias_side=sd, bound=bound)
+        dfeat, d_w, d_b = _head_backward(dlogits, feat, ctx.feat_op, weight, t_w, t_b, bias_side=sd, bound=bound, g=g)
         sd.join()
         if t_w is not None and t_b is not None:
             grad_done(ctx.srcs[2])
@@ -821,9 +845,9 @@ class DualHeadCEFn(Function):
         # with the GRU / RGCN backward kernels it would run beside)
         with sd():
             bound2 = _scale_ce_gradient(dl2, g, ctx.grad_scales[1])
-            dfeat2, d_w2, d_b2 = _head_backward(dl2, feat2, fop2, w2, t_w2, t_b2, bound=bound2)
+            dfeat2, d_w2, d_b2 = _head_backward(dl2, feat2, fop2, w2, t_w2, t_b2, bound=bound2, g=g)
             da2, dh2, _ = K.concat3_bwd(dfeat2, d, 2, drop_p, seed2)
-        dfeat1, d_w1, d_b1 = _head_backward(dl1, feat1, fop1, w1, t_w1, t_b1, bias_side=sd, bound=bound1)
+        dfeat1, d_w1, d_b1 = _head_backward(dl1, feat1, fop1, w1, t_w1, t_b1, bias_side=sd, bound=bound1, g=g)
         da1, dh1, dc1 = K.concat3_bwd(dfeat1, d, 3, drop_p, seed1)
         sd.join()
         if t_w1 is not None and t_b1 is not None:

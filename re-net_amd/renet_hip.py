@@ -85,6 +85,13 @@ _SIGNATURES = {
                                               c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'renet_colsum_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     'renet_scale_bf16_by_device_scalar': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    'renet_planes_elems': (c_size_t, [c_int, c_int]),
+    'renet_pack_planes': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'renet_gemm_planes': (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_size_t,
+                                  c_void_p, c_int, c_size_t, c_float, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                  c_void_p, c_size_t, c_void_p]),
+    'renet_softmax_ce_planes': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t,
+                                        c_int, c_int, c_void_p]),
     'renet_colsum_workspace': (c_size_t, [c_int, c_int]),
     'renet_colsum': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     'renet_scale_by_device_scalar': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -280,7 +287,7 @@ _timer = None
 
 # wrappers without a timer of their own (the step's small kernels): set_timer(t, glue=True) times each of them as class
 # 'glue:<name>' so that bench.py's `kernel_only` covers EVERY C-ABI launch of a step, not only the named classes
-GLUE = ('gather_rows', 'segment_add', 'segment_add2', 'compose_table_items', 'rgcn_bwd_prep', 'colsum',
+GLUE = ('softmax_ce_planes', 'gather_rows', 'segment_add', 'segment_add2', 'compose_table_items', 'rgcn_bwd_prep', 'colsum',
         'scale_by_device_scalar', 'seq_assemble_fwd', 'seq_assemble_fwd_bf16', 'softmax_ce_bf16', 'seq_assemble_bwd',
         'concat3_fwd', 'concat3_bwd', 'dropout', 'softmax_ce', 'adam_step', 'segment_pool_fwd', 'segment_pool_bwd',
         'pack_bf16_glue')
@@ -641,6 +648,7 @@ def unregister_weights(tensors):
     for t in tensors:
         _weight_ptrs.pop(t.data_ptr(), None)
         _weight_cache.pop(t.data_ptr(), None)
+        _weight_planes.pop(t.data_ptr(), None)
         _weight_max.pop(t.data_ptr(), None)
         _weight_objs.pop(t.data_ptr(), None)
 
@@ -669,6 +677,151 @@ def _as_bf16(x):
     return m, m.R, m.C
 
 
+# ---- PLANES (round 6): operands of the bf16x6 GEMM stored ALREADY split into their three bf16 terms ----------------
+# The entity score head's three GEMMs (logits, dfeat, dW: 2/3 of the step's GEMM flops) re-split every operand element
+# once per output tile that reads it (csrc/gemm_split.hip); here a tensor is split ONCE, by the kernel that produces it
+# (softmax_ce_planes: the CE gradient; HipAdam: the head weight; pack_planes: the features), and the GEMM
+# (csrc/gemm_p6.h) stages the planes by LDS-DMA with no conversion work in its k-loop.  Same arithmetic (three RNE terms,
+# six products, fp32 accumulation) as the in-loop split.  RENET_PLANES=0 keeps the in-loop split everywhere.
+PLANES = os.environ.get('RENET_PLANES', '1') != '0'
+PLANES_MIN_CLASSES = int(os.environ.get('RENET_PLANES_MIN_CLASSES', '2048'))
+
+
+class PlanesMat(object):
+    """A matrix [R, C] as three bf16 planes in ONE tensor p [3, Rp, Cp] (Rp, Cp multiples of 256, zero padding)."""
+    __slots__ = ('p', 'R', 'C')
+
+    def __init__(self, p, R, C):
+        self.p, self.R, self.C = p, R, C
+
+    @property
+    def shape(self):
+        return (self.R, self.C)
+
+    @property
+    def plane(self):
+        return self.p.shape[1] * self.p.shape[2]
+
+
+def planes_empty(r, c, device, zero=False):
+    """PlanesMat for a producer kernel; zero=True when the producer does not write the padding itself."""
+    rp, cp = (r + 255) & ~255, (c + 255) & ~255
+    mk = torch.zeros if zero else torch.empty
+    return PlanesMat(mk(3, rp, cp, device=device, dtype=torch.bfloat16), r, c)
+
+
+def pack_planes(x, ones_col=False):
+    """fp32 [R, C] (row-strided views allowed) -> PlanesMat; ones_col: one more column, all ones (gemm_planes' col_out)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1):
+        raise RenetHipError('pack_planes needs a 2-D float32 device tensor with unit inner stride')
+    r, c = x.shape
+    m = planes_empty(r, c + (1 if ones_col else 0), x.device)
+    t0 = _timer.begin() if _timer is not None else None
+    _check(lib().renet_pack_planes(x.data_ptr(), r, c, x.stride(0), int(bool(ones_col)), m.p.data_ptr(), _stream()),
+           'pack_planes')
+    if t0 is not None:
+        _timer.end('pack_planes', t0, nbytes=float(r * c * 4 + 3 * m.plane * 2))
+    return m
+
+
+_weight_planes = {}            # data_ptr -> ((epoch, version), PlanesMat) of a registered weight
+
+
+def weight_planes(w):
+    """Planes of a weight matrix: a registered weight (parallel.HipAdam) is packed once per optimizer step -- or not at
+    all when the optimizer kernel wrote them (note_weight_planes) -- anything else on every call."""
+    ptr = w.data_ptr()
+    shp = _weight_ptrs.get(ptr)
+    if shp is not None and tuple(w.shape) == tuple(shp) and w.is_contiguous():
+        stamp = (_weight_epoch[0], w._version)
+        ent = _weight_planes.get(ptr)
+        if ent is None or ent[0] != stamp:
+            ent = (stamp, pack_planes(w), _StreamGuard(w.device))
+            _weight_planes[ptr] = ent
+        ent[2].wait(w.device)
+        return ent[1]
+    return pack_planes(w)
+
+
+def note_weight_planes(w, mat):
+    """The optimizer kernel has just written `mat` = the planes of the UPDATED weight w (call after weights_changed())."""
+    _weight_planes[w.data_ptr()] = ((_weight_epoch[0], w._version), mat, _StreamGuard(w.device))
+
+
+def use_planes(weight, n_classes):
+    """Whether a score head with this weight runs its GEMMs on planes: default fp32-class mode, a wide class dimension."""
+    return (PLANES and current_mode() == 'bf16x6' and weight.is_cuda and n_classes >= PLANES_MIN_CLASSES and
+            weight.dim() == 2 and weight.is_contiguous())
+
+
+def auto_split_k_planes(m, n, k):
+    """Split-K factor of gemm_planes (256 x 128 tiles, one workgroup per CU): auto_split_k's cost model on that grid."""
+    tiles = ((m + 255) // 256) * ((n + 127) // 128)
+    ktiles = (k + 31) // 32
+    if tiles >= 128 or ktiles < 8:
+        return 1
+    smax = int(max(1, min(64, ktiles // 4)))
+    per_slice = m * n * 2.7e-6
+    best, best_t = 1, None
+    for s_ in range(1, smax + 1):
+        rounds = (tiles * s_ + 255) // 256
+        t = rounds * (ktiles / float(s_) + 6.0) + (per_slice * s_ if s_ > 1 else 0.0)
+        if best_t is None or t < best_t - 1e-9:
+            best, best_t = s_, t
+    return best
+
+
+def gemm_planes(a, b, ta=False, tb=False, out=None, bias=None, alpha=1.0, alpha_dev=None, beta=0.0, col_out=None,
+                split_k=None):
+    """out = alpha * alpha_dev * op(a) @ op(b) + bias + beta * out on PlanesMat operands (renet_gemm_planes).
+    ta: a is stored [K, M]; tb: b is stored [N, K] (the conventions of gemm()).  col_out [M]: b's LAST column (a ones
+    column, pack_planes(ones_col=True)) is not part of `out`; its product -- sum_k op(a)[m, k] -- goes to col_out."""
+    if not (isinstance(a, PlanesMat) and isinstance(b, PlanesMat)):
+        raise RenetHipError('gemm_planes needs PlanesMat operands')
+    m, k = (a.C, a.R) if ta else (a.R, a.C)
+    n, k2 = (b.R, b.C) if tb else (b.C, b.R)
+    if k != k2:
+        raise RenetHipError('gemm_planes inner dimensions differ: %d vs %d' % (k, k2))
+    n_main = n - 1 if col_out is not None else n
+    dev = a.p.device
+    if out is None:
+        if beta != 0.0:
+            raise RenetHipError('beta != 0 needs an output tensor')
+        out = torch.empty(m, n_main, device=dev, dtype=torch.float32)
+    if tuple(out.shape) != (m, n_main):
+        raise RenetHipError('gemm_planes: output shape %r, expected %r' % (tuple(out.shape), (m, n_main)))
+    if col_out is not None and (col_out.numel() != m or not col_out.is_contiguous()):
+        raise RenetHipError('gemm_planes: col_out must be a contiguous vector of M floats')
+    if split_k is None:
+        split_k = auto_split_k_planes(m, n, k)
+    ws_ptr, ws_bytes = None, 0
+    if split_k > 1:
+        ws_bytes = lib().renet_gemm_workspace(m, n, split_k)
+        ws = torch.empty(ws_bytes // 4, device=dev, dtype=torch.float32)
+        ws_ptr = ws.data_ptr()
+    t0 = _timer.begin() if _timer is not None else None
+    _check(lib().renet_gemm_planes(int(ta), int(not tb), m, n, k, float(alpha), _f32(alpha_dev), a.p.data_ptr(),
+                                   a.p.shape[2], a.plane, b.p.data_ptr(), b.p.shape[2], b.plane, float(beta),
+                                   out.data_ptr(), _ld(out), _f32(bias), _f32(col_out), split_k, ws_ptr, ws_bytes,
+                                   _stream()), 'gemm_planes')
+    if t0 is not None:
+        _timer.end('gemm_f32', t0, flops=2.0 * m * n_main * k, tag=(int(ta), int(tb), m, n_main, k, split_k))
+    return out
+
+
+def softmax_ce_planes(logits, target, grad_scale, row_loss=None):
+    """-> (row_loss[B], PlanesMat (softmax - onehot) * grad_scale); the fp32 logits (row-strided view allowed) are not
+    modified."""
+    b, c = logits.shape
+    if row_loss is None:
+        row_loss = torch.empty(b, device=logits.device, dtype=torch.float32)
+    dl = planes_empty(b, c, logits.device)
+    _check(lib().renet_softmax_ce_planes(logits.data_ptr(), _i32(target), b, c, _ld(logits), float(grad_scale),
+                                         _f32(row_loss), dl.p.data_ptr(), dl.plane, dl.p.shape[2], dl.p.shape[1],
+                                         _stream()), 'softmax_ce_planes')
+    return row_loss, dl
+
+
 class F32Op(object):
     """An fp32 GEMM operand together with the bound on its largest magnitude that the f16x3 GEMM scales it by:
     `part` holds n <= 256 device floats whose maximum bounds max |t| (renet_maxabs_partials, or a known bound)."""
@@ -690,7 +843,7 @@ class F32Op(object):
 
 def is_handle(x):
     """x is an operand handle made by operand() (to be kept for the GEMMs of the backward pass), not a plain tensor."""
-    return isinstance(x, (BF16Mat, F32Op))
+    return isinstance(x, (BF16Mat, F32Op, PlanesMat))
 
 
 def maxabs_partials(x):
