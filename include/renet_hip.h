@@ -292,16 +292,23 @@ int renet_scale_bf16_by_device_scalar(void* x, size_t n, const float* scale, voi
 
 /* PLANES (round 6): the bf16x6 arithmetic of renet_gemm_f32_split on operands that are ALREADY split -- a matrix [R, C] is
  * stored as three bf16 matrices ("planes", x = p1 + p2 + p3, p1 = rne(x), p2 = rne(x - p1), p3 = rne(x - p1 - p2): the
- * split the bf16x6 loaders perform per k-tile), each [Rp][Cp] row-major with Rp, Cp = R, C rounded up to multiples of 256
- * and ZERO padding, `plane` elements apart.  The producers write the format directly (renet_softmax_ce_planes: the CE
- * gradient; renet_adam_step_planes: the score-head weight; renet_pack_planes: anything else), so the GEMM k-loop contains
- * no conversion: LDS-DMA staging (global_load_lds) into a 2-slot ring of 256 x 128 x 32 stages, six
+ * split the bf16x6 loaders perform per k-tile), each over the padded extent [Rp][Cp] (R, C rounded up to multiples of 256,
+ * ZERO padding), `plane` elements apart.  Inside a plane the elements are TILED, not row-major ("T16": 16 x 16 tiles of
+ * 512 bytes, tile (tr, tc) at (tr * Cp / 16 + tc) * 256 elements; element (i, j) of a tile at
+ * (i ^ 4 * (tc & 1)) * 16 + ((j >> 3) ^ ((i >> 3) & 1)) * 8 + (j & 7) -- csrc/common.h renet_t16_off): every 1 KB
+ * LDS-DMA piece of the GEMM is then two whole tiles whether the matrix is contracted over its columns or over its rows,
+ * and both kinds of fragment read are free of LDS bank conflicts (tools/p6_layout_sim.py models the data path).
+ * The producers write the format directly (renet_softmax_ce_planes: the CE gradient; renet_pack_planes: anything
+ * else -- a weight once per optimizer step), so the GEMM k-loop contains no conversion: LDS-DMA staging
+ * (global_load_lds) into a 3-slot ring of 128 x 128 x 16 half-stages (two workgroups per CU; RENET_P6_TILE=256: 4 slots of
+ * 256 x 128 x 16, one workgroup per CU), fragments double buffered in registers, six
  * v_mfma_f32_32x32x16_bf16 per fragment pair, fp32 accumulation; same result as renet_gemm_f32_split up to fp32
  * summation order.
  *   renet_planes_elems : Rp * Cp, the element count of one plane (the plane stride the packers use)
  *   renet_pack_planes  : fp32 X[R, C] (row stride ldx) -> planes; ones_col != 0 appends a column of ones (C + 1 columns:
  *                        see col_out)
- *   renet_gemm_planes  : C[M, N] = alpha * (*alpha_dev) * op(A) op(B) (+ bias) (+ beta * C)
+ *   renet_gemm_planes  : C[M, N] = alpha * (*alpha_dev) * op(A) op(B) (+ bias) (+ beta * C);  lda / ldb = Cp of the
+ *                        stored matrices
  *       a_tr == 0: A stored [M rows][K cols];  a_tr == 1: stored [K rows][M cols] (contraction over its rows)
  *       b_tr == 0: B^T stored [N rows][K cols] (nn.Linear's weight layout);  b_tr == 1: B stored [K rows][N cols]
  *       alpha_dev : optional DEVICE scalar folded into alpha (the upstream autograd gradient: no pass over the operand)
@@ -316,8 +323,9 @@ int renet_gemm_planes(int a_tr, int b_tr, int M, int N, int K, float alpha, cons
                       int lda, size_t a_plane, const void* Bp, int ldb, size_t b_plane, float beta, float* C, int ldc,
                       const float* bias, float* col_out, int split_k, float* workspace, size_t workspace_bytes,
                       void* stream);
-/* renet_softmax_ce with the gradient (softmax - onehot) * grad_scale written as planes [3][rows16][ld16] (`plane`
- * elements apart; ld16 % 4 == 0; columns [C, ceil64(C)) and rows [B, rows16) zeroed); the fp32 logits are left untouched.
+/* renet_softmax_ce with the gradient (softmax - onehot) * grad_scale written as T16 planes over [rows16][ld16] (`plane`
+ * elements apart; ld16 % 16 == 0, rows16 >= ceil16(B); columns [C, ld16) of the rows < B and the rows [B, ceil16(B))
+ * zeroed); the fp32 logits are left untouched.
  * Replaces F.cross_entropy's backward (model.py:91,100) as renet_softmax_ce does. */
 int renet_softmax_ce_planes(const float* logits, const int32_t* target, int B, int C, int ld, float grad_scale,
                             float* row_loss, void* dl_planes, size_t plane, int ld16, int rows16, void* stream);

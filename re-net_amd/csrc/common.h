@@ -75,3 +75,14 @@ __device__ __forceinline__ float4 f4_scale(float4 a, float s) {
 __device__ __forceinline__ int renet_xcd_block(int b, int nb) {
     return (nb & 7) == 0 ? (b & 7) * (nb >> 3) + (b >> 3) : b;
 }
+
+// ---- T16: the tiled storage format of bf16 operand PLANES (csrc/gemm_p6.h; tools/p6_layout_sim.py is the executable
+// specification).  Element offset of (row, col) inside one plane of a padded matrix with `tc_count` = Cp / 16 tiles per
+// tile row: 16 x 16 tiles of 512 bytes, row i of a tile at i ^ 4 when the tile column is odd, the two 16-byte halves of a
+// tile row swapped when (i >> 3) & 1.  Four consecutive columns starting at a multiple of 4 are consecutive elements.
+__host__ __device__ __forceinline__ size_t renet_t16_off(int row, int col, int tc_count) {
+    const int i = row & 15, j = col & 15, tc = col >> 4;
+    const int ip = i ^ ((tc & 1) << 2);
+    const int hh = (j >> 3) ^ ((i >> 3) & 1);
+    return ((size_t)(row >> 4) * tc_count + tc) * 256 + ip * 16 + hh * 8 + (j & 7);
+}

@@ -1,28 +1,30 @@
 // "Planes" GEMM (round 6; included by gemm_split.hip inside its anonymous namespace): the bf16x6 arithmetic of
 // gemm_split_kernel -- every fp32 operand value as three bf16 terms, the six leading term products on
 // v_mfma_f32_32x32x16_bf16, fp32 accumulation -- on operands that ARRIVE split: three bf16 planes per matrix in HBM,
-// written by the kernel that produces the tensor (softmax-CE: the CE gradient; Adam: the weights; renet_pack_planes for
-// anything else).  The k-loop then contains no conversion at all: no v_cvt / v_sub, no ds_write -- the resource the
+// written by the kernel that produces the tensor (softmax-CE: the CE gradient) or by renet_pack_planes (a weight: once per
+// optimizer step).  The k-loop then contains no conversion at all: no v_cvt / v_sub, no ds_write -- the resource the
 // in-loop split is bound by (a SIMD's conversion VALU work and its partner's MFMAs serialise, the matrix
 // pipe idles half of every k-tile).  An operand element is split ONCE per step instead of once per output tile that
 // reads it (the logits GEMM re-split `feat` 180 times and the weight 8 times).
 //
-// Structure: LDS-DMA (global_load_lds: no VGPRs, no VALU, no ds_write) into a ring of FOUR half-stage slots, wave
-// specialised like gemm_bf16s_kernel<.., TALL> above; one stored matrix serves the K-contiguous and the K-strided role
-// (ds_read_b128 / ds_read_b64_tr_b16).
-//   * tile 256 x 128, half-stage = 16 k of THREE planes per operand: 3 x (8 KB + 4 KB) = 36 KB, four slots = 144 KB;
-//   * 8 MFMA waves (4 x 2, two per SIMD, 64 x 64 each): 24 MFMAs per wave and half-stage = 1536 matrix-pipe cycles per
-//     SIMD, against 36 x 1 KB DMA pieces issued by the 4 loader waves (one per SIMD);
-//   * one raw s_barrier per half-stage: at barrier j half-stage j is visible and j - 1 is consumed; the loaders then
-//     issue half-stage j + 3 into the slot j - 1 held and wait (counted vmcnt) only for half-stage j + 1 -- two to three
-//     half-stages (72-108 KB per CU) stay in flight.  (The first version had two 72 KB k32 slots and waited vmcnt(0) per
-//     stage: ablation builds, tools/p6_probe.py, showed the DMA stream alone at 240 us and the MFMA stream alone at 294 us
-//     on the logits GEMM, the two together at 394 us -- latency-exposed, profiles/r06_a_planes_ablation.md.)
-//   * K-contiguous image of a half-stage: [rows][16 k], 32-byte rows, the two 16-byte chunks of a row swapped when
-//     (row >> 3) & 1 (on the DMA's SOURCE address): every ds_read_b128 lane group of MI355X_MICROARCH.md's LDS table
-//     ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) then covers all 64 banks exactly once.
-//     K-strided image: [16 k][128-column panels], 256-byte rows, sixteen 16-byte chunks XOR-swizzled by 4 * (k & 3) -- the
-//     image of the bf16-storage kernel, read with two ds_read_b64_tr_b16 per fragment.
+// PLANE FORMAT "T16" (renet_t16_off in common.h; tools/p6_layout_sim.py is its executable specification): a plane of a matrix
+// [Rp, Cp] (multiples of 256) is stored as 16 x 16 tiles of 512 bytes, tile (tr, tc) at ((tr * Cp / 16) + tc) * 256
+// elements, row-major inside with two twists that make the LDS reads of BOTH consumer roles conflict free: row i of a tile
+// sits at i ^ 4 when tc is odd, and the two 16-byte halves of a row are swapped when (i >> 3) & 1.  A GEMM consumes a
+// stored matrix either K-CONTIGUOUS (contraction over its columns: a half-stage is one tile column, 512-byte segments) or
+// K-STRIDED (contraction over its rows: a half-stage is one tile row, one contiguous run); both see every 1 KB LDS-DMA
+// piece as two whole tiles.  (Row-major planes, the first two versions of this kernel, fed the K-contiguous role with
+// 32- and 64-byte row segments: the DMA stream alone then took 340 / 240 us on the logits GEMM against 195 us for K-strided
+// operands -- ablation builds, profiles/r06_a_planes_ablation.md.)
+//
+// KERNEL (P6Cfg<4>; P6Cfg<2> below is the 128-row form): tile 256 x 128, 8 waves (4 x 2, two per SIMD, 64 x 64 outputs each),
+// every wave both loads and multiplies.
+//   * half-stage = 16 k of the three planes of both operands: 3 x (8 KB + 4 KB) = 36 KB = 36 LDS-DMA pieces
+//     (global_load_lds: no VGPRs, no VALU, no ds_write), 5 / 4 per wave; ring of FOUR slots (144 KB of the 160);
+//   * fragments are double buffered in REGISTERS: iteration j multiplies half-stage j (read during j - 1) while the
+//     ds_read_b128 / ds_read_b64_tr_b16 of half-stage j + 1 and the DMA of half-stage j + 4 (into the slot j held) are in
+//     flight; one raw s_barrier per half-stage, counted vmcnt: three half-stages (108 KB per CU) stay in flight;
+//   * 24 MFMAs per wave and half-stage = 1536 matrix-pipe cycles per SIMD.
 // Epilogue extras: `alpha_dev` (a device scalar folded into alpha: the upstream autograd gradient, no pass over the CE
 // gradient), and `col_out`: the LAST logical column of the product goes to a vector instead of C -- with a ones column
 // appended to B this is the bias gradient (column sums of A^T) for free, inside the padding of the last column tile.
@@ -31,22 +33,31 @@ struct P6Args {
     const __bf16* A;
     const __bf16* B;
     size_t a_plane, b_plane;      // elements between consecutive planes of an operand
-    int lda, ldb;                 // row stride (elements) of the stored matrices
+    int tca, tcb;                 // tiles per tile row (Cp / 16) of the stored matrices
     const float* alpha_dev;       // optional device scalar multiplied into alpha
     float* col_out;               // optional: logical column N - 1 is stored to col_out[row] (stride 1), columns < N - 1 to C
     SplitArgs out;                // M, N (logical columns incl. the col_out one), K, C, ldc, alpha, beta, bias, split-K fields
 };
 
-constexpr int P6_AIMG = 256 * 32;                      // bytes: one plane's A image of a k16 half-stage
-constexpr int P6_BIMG = 128 * 32;
-constexpr int P6_PIMG = P6_AIMG + P6_BIMG;             // one plane of a half-stage: A image, then B image (12 KB)
-constexpr int P6_STAGE = 3 * P6_PIMG;                  // 36 864 B
-constexpr int P6_SLOTS = 4;
-constexpr size_t P6_LDS = (size_t)P6_STAGE * P6_SLOTS; // 147 456 B
-constexpr int P6_MW = 8, P6_LW = 4;
-constexpr int P6_THREADS = 64 * (P6_MW + P6_LW);
-constexpr int P6_NPIECE = 3 * (8 + 4);
-constexpr int P6_PER = P6_NPIECE / P6_LW;              // 9 DMA pieces per loader wave and half-stage
+// Tile configuration: WM = rows of 64-row waves.  WM = 4: 256 x 128 tile, 8 waves, 4 ring slots (144 KB: ONE workgroup per
+// CU); WM = 2: 128 x 128 tile, 4 waves, 3 ring slots (72 KB: TWO workgroups per CU, whose barriers, prologues and C-store
+// epilogues cover each other as in gemm_split_kernel, at 4/3 of the DMA bytes per flop).
+template <int WM>
+struct P6Cfg {
+    static constexpr int NW = 2 * WM;                         // waves
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int APIECES = 2 * WM;                    // 1 KB DMA pieces of one plane's A image (two tiles each)
+    static constexpr int AIMG = APIECES * 1024;               // bytes: one plane's A image of a half-stage
+    static constexpr int BIMG = 4 * 1024;
+    static constexpr int PP = APIECES + 4;                    // pieces per plane
+    static constexpr int PIMG = AIMG + BIMG;
+    static constexpr int STAGE = 3 * PIMG;                    // 36 864 / 24 576 B
+    static constexpr int SLOTS = WM == 4 ? 4 : 3;
+    static constexpr size_t LDS = (size_t)STAGE * SLOTS;      // 147 456 / 73 728 B
+    static constexpr int NPIECE = 3 * PP;                     // 36 / 24 per half-stage
+    static constexpr int PER = (NPIECE + NW - 1) / NW;        // 5 (waves 0-3; 4 for waves 4-7) / 6
+    static constexpr bool UNEVEN = (NPIECE % NW) != 0;
+};
 
 __device__ __forceinline__ void p6_store_tile(const P6Args& pa, int m0, int n0, int z, int wm, int wn, int lane,
                                               const f32x16 (&acc)[2][2]) {
@@ -91,8 +102,12 @@ __device__ __forceinline__ void p6_store_tile(const P6Args& pa, int m0, int n0, 
         }
 }
 
-template <bool A_TR, bool B_TR>
-__global__ __launch_bounds__(P6_THREADS) void gemm_p6_kernel(P6Args pa) {
+struct P6Frags { bf16x8 a[2][3], b[2][3]; };              // [t][plane]
+
+template <bool A_TR, bool B_TR, int WM>
+__global__ __launch_bounds__(P6Cfg<WM>::THREADS, 2) void gemm_p6_kernel(P6Args pa) {
+    using Cfg = P6Cfg<WM>;
+    constexpr int P6_AIMG = Cfg::AIMG, P6_PIMG = Cfg::PIMG, P6_STAGE = Cfg::STAGE, NS = Cfg::SLOTS, PER = Cfg::PER;
     extern __shared__ __attribute__((aligned(16))) char ring6[];
     const SplitArgs& g = pa.out;
     const int tid = threadIdx.x;
@@ -100,107 +115,83 @@ __global__ __launch_bounds__(P6_THREADS) void gemm_p6_kernel(P6Args pa) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bx, by, z;
     tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by, z);
-    const int m0 = by * 256, n0 = bx * BN;
-    const int hs_total = (g.K + 15) / 16;                 // half-stages of 16 k; k_tiles_per_split counts them
-    const int s0 = z * g.k_tiles_per_split;
+    const int m0 = by * (64 * WM), n0 = bx * BN;
+    const int hs_total = (g.K + 15) / 16;                 // half-stages of 16 k; k_tiles_per_split counts them and is EVEN
+    const int s0 = z * g.k_tiles_per_split;               //   (the parity of a k block is then the parity of its loop index)
     const int s1 = min(hs_total, s0 + g.k_tiles_per_split);
     const int nh = max(s1 - s0, 0);
 
-    if (wave >= P6_MW) {
-        // ---------------- loader waves: 9 x 1 KB LDS-DMA pieces per half-stage each ----------------
-        if (nh == 0) return;
-        const int lw = wave - P6_MW;
-        const __bf16* src[P6_PER];
-        int dst[P6_PER];
+    // ---- this wave's DMA pieces: id = wave + NW i < NPIECE; plane id / PP; inside a plane pieces 0 .. APIECES-1 = A (two
+    // tiles each), then 4 of B.  (WM = 4: waves 0-3 issue 5 pieces per half-stage, waves 4-7 four; WM = 2: six each.)
+    const bool five = !Cfg::UNEVEN || wave < Cfg::NPIECE % Cfg::NW;        // this wave owns a piece in the last slot
+    const __bf16* src[PER];
+    size_t step[PER];
+    int dst[PER];
 #pragma unroll
-        for (int i = 0; i < P6_PER; ++i) {
-            // slot i of loader lw: plane i / 3; piece id lw + 4 (i % 3) in 0 .. 11 of that plane: A pieces 0..7, B pieces 8..11
-            // -- for every lw the plane and the operand (i % 3 == 2: B) of slot i are compile-time constants
-            const int plane = i / 3, idl = lw + P6_LW * (i % 3);
-            const int opnd = (i % 3) == 2 ? 1 : 0;
-            const int piece = opnd ? idl - 8 : idl;
-            const bool tr = opnd ? B_TR : A_TR;
-            const __bf16* base = opnd ? pa.B + (size_t)plane * pa.b_plane : pa.A + (size_t)plane * pa.a_plane;
-            const int ld = opnd ? pa.ldb : pa.lda;
-            const int r0 = opnd ? n0 : m0;
-            const size_t k0 = (size_t)s0 * 16;
-            size_t off;
-            int img_off;
-            if (!tr) {                                   // image [rows][16 k], 32-byte rows: piece = 32 rows
-                const int row = 32 * piece + (lane >> 1);
-                const int chunk = (lane & 1) ^ ((row >> 3) & 1);
-                off = (size_t)(r0 + row) * ld + k0 + chunk * 8;
-                img_off = piece * 1024;
-            } else {                                     // image [16 k][cols] in 128-column panels of 4 KB: piece = 4 k x 256 B
-                const int panel = piece >> 2, pc = piece & 3;
-                const int kk = 4 * pc + (lane >> 4);
-                const int log16 = (lane & 15) ^ (4 * (kk & 3));
-                off = (k0 + kk) * ld + r0 + panel * 128 + log16 * 8;
-                img_off = panel * 4096 + pc * 1024;
-            }
-            src[i] = base + off;
-            dst[i] = plane * P6_PIMG + (opnd ? P6_AIMG : 0) + img_off;
-        }
-        const size_t a_step = A_TR ? (size_t)16 * pa.lda : (size_t)16;
-        const size_t b_step = B_TR ? (size_t)16 * pa.ldb : (size_t)16;
-        auto issue_all = [&](int slot) {
-            char* base = ring6 + slot * P6_STAGE;
-#pragma unroll
-            for (int i = 0; i < P6_PER; ++i) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
-                                                 (__attribute__((address_space(3))) void*)(base + dst[i]), 16, 0, 0);
-                src[i] += (i % 3) == 2 ? b_step : a_step;
-            }
-        };
-        static_assert(P6_PER == 9, "counted waits below");
-        // wait until at most `left` half-stages issued by this wave are still in flight
-        auto wait_left = [&](int left) {
-            if (left >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-            else if (left == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        const int pre = min(nh, 3);
-        for (int j = 0; j < pre; ++j) issue_all(j);
-        wait_left(pre - 1);
-        __builtin_amdgcn_s_barrier();                                     // barrier 0: half-stage 0 visible
-        for (int j = 0; j < nh; ++j) {
-#ifdef RENET_P6_NODMA                 // probe builds only (tools/p6_probe.py): the k-loop without its DMA stream
-            if (j + 3 < nh && j < 1) issue_all((j + 3) & 3);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-            if (j + 3 < nh) issue_all((j + 3) & 3);                       // its slot held half-stage j - 1: consumed before barrier j
-            wait_left(min(j + 3, nh - 1) - (j + 1));                      // half-stage j + 1 landed; j + 2, j + 3 stay in flight
-#endif
-            __builtin_amdgcn_s_barrier();                                 // barrier j + 1: half-stage j + 1 visible, j consumed
-        }
-        return;
+    for (int i = 0; i < PER; ++i) {
+        const int id = min(wave + Cfg::NW * i, Cfg::NPIECE - 1);
+        const int plane = id / Cfg::PP, idl = id % Cfg::PP;
+        const int opnd = idl >= Cfg::APIECES ? 1 : 0;
+        const int piece = opnd ? idl - Cfg::APIECES : idl;
+        const bool tr = opnd ? B_TR : A_TR;
+        const __bf16* base = opnd ? pa.B + (size_t)plane * pa.b_plane : pa.A + (size_t)plane * pa.a_plane;
+        const size_t tcn = (size_t)(opnd ? pa.tcb : pa.tca);
+        const size_t t0 = (size_t)((opnd ? n0 : m0) >> 4) + 2 * piece + (lane >> 5);    // tile along the operand's M / N index
+        const size_t tile = tr ? (size_t)s0 * tcn + t0 : t0 * tcn + (size_t)s0;
+        src[i] = base + tile * 256 + (lane & 31) * 8;
+        step[i] = tr ? tcn * 256 : (size_t)256;
+        dst[i] = plane * P6_PIMG + (opnd ? P6_AIMG : 0) + piece * 1024;
     }
+    auto issue_piece = [&](char* base, auto ic) {
+        constexpr int i = decltype(ic)::value;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                         (__attribute__((address_space(3))) void*)(base + dst[i]), 16, 0, 0);
+        src[i] += step[i];
+    };
+    auto issue = [&](int slot) {
+        char* base = ring6 + slot * P6_STAGE;
+        static_for<0, PER - 1>([&](auto ic) { issue_piece(base, ic); });
+        if (five) issue_piece(base, std::integral_constant<int, PER - 1>{});
+    };
+    // wait until at most `left` of this wave's issue batches (PER or PER - 1 pieces each) are still in flight
+    auto wait_left = [&](int left) {
+        if constexpr (WM == 4) {
+            if (left >= 2) { if (five) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            else if (left == 1) { if (five) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            static_assert(WM == 4 || (PER == 6 && !Cfg::UNEVEN), "counted waits");
+            if (left >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
 
-    // ---------------- MFMA waves ----------------
-    const int wm = wave >> 1, wn = wave & 1;               // 4 x 2 waves, 64 x 64 outputs each
-    int offA[2][2], offB[2][2];                            // [t][u]: K-contiguous uses u = 0 only; K-strided: its two tr reads
+    // ---- fragment addresses (bytes inside an operand's image)
+    const int wm = wave >> 1, wn = wave & 1;               // WM x 2 waves, 64 x 64 outputs each
+    int offA[2][2], offB[2][2];                            // [t][u]: K-contiguous: u = parity of the k block; K-strided: its two tr reads
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if constexpr (!A_TR) {
-                const int row = wm * 64 + 32 * t + (lane & 31);
-                offA[t][u] = row * 32 + (((lane >> 5) ^ ((row >> 3) & 1)) * 16);
+                const int r = wm * 64 + 32 * t + (lane & 31);
+                offA[t][u] = (r >> 4) * 512 + (((r & 15) ^ (4 * u)) * 32) + (((lane >> 5) ^ ((r >> 3) & 1)) * 16);
             } else {
                 const int sl = lane & 15;
-                const int colf = wm * 64 + 32 * t + 16 * ((lane >> 4) & 1) + 4 * (sl & 3);
-                const int col = colf & 127;                  // inside its 128-column panel
+                const int c = wm * 64 + 32 * t + 16 * ((lane >> 4) & 1) + 4 * (sl & 3);
                 const int kk = 8 * (lane >> 5) + 4 * u + (sl >> 2);
-                offA[t][u] = (colf >> 7) * 4096 + kk * 256 + (((col >> 3) ^ (4 * (kk & 3))) * 16) + ((col >> 2) & 1) * 8;
+                offA[t][u] = (c >> 4) * 512 + ((kk ^ (4 * ((c >> 4) & 1))) * 32) + ((((c >> 3) & 1) ^ ((kk >> 3) & 1)) * 16) +
+                             ((c >> 2) & 1) * 8;
             }
             if constexpr (!B_TR) {
-                const int row = wn * 64 + 32 * t + (lane & 31);
-                offB[t][u] = row * 32 + (((lane >> 5) ^ ((row >> 3) & 1)) * 16);
+                const int r = wn * 64 + 32 * t + (lane & 31);
+                offB[t][u] = (r >> 4) * 512 + (((r & 15) ^ (4 * u)) * 32) + (((lane >> 5) ^ ((r >> 3) & 1)) * 16);
             } else {
                 const int sl = lane & 15;
-                const int col = wn * 64 + 32 * t + 16 * ((lane >> 4) & 1) + 4 * (sl & 3);
+                const int c = wn * 64 + 32 * t + 16 * ((lane >> 4) & 1) + 4 * (sl & 3);
                 const int kk = 8 * (lane >> 5) + 4 * u + (sl >> 2);
-                offB[t][u] = kk * 256 + (((col >> 3) ^ (4 * (kk & 3))) * 16) + ((col >> 2) & 1) * 8;
+                offB[t][u] = (c >> 4) * 512 + ((kk ^ (4 * ((c >> 4) & 1))) * 32) + ((((c >> 3) & 1) ^ ((kk >> 3) & 1)) * 16) +
+                             ((c >> 2) & 1) * 8;
             }
         }
     auto frag_tr = [&](const char* img, const int (&off)[2]) {
@@ -213,6 +204,21 @@ __global__ __launch_bounds__(P6_THREADS) void gemm_p6_kernel(P6Args pa) {
         }
         return r;
     };
+    auto read_frags = [&](P6Frags& F, int slot, auto parc) {
+        constexpr int par = decltype(parc)::value;
+        const char* st = ring6 + slot * P6_STAGE;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const char* ia = st + p * P6_PIMG;
+                const char* ib = ia + P6_AIMG;
+                if constexpr (!A_TR) F.a[t][p] = *reinterpret_cast<const bf16x8*>(ia + offA[t][par]);
+                else F.a[t][p] = frag_tr(ia, offA[t]);
+                if constexpr (!B_TR) F.b[t][p] = *reinterpret_cast<const bf16x8*>(ib + offB[t][par]);
+                else F.b[t][p] = frag_tr(ib, offB[t]);
+            }
+    };
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -220,37 +226,78 @@ __global__ __launch_bounds__(P6_THREADS) void gemm_p6_kernel(P6Args pa) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    if (nh > 0) __builtin_amdgcn_s_barrier();                             // barrier 0
-    for (int hs = 0; hs < nh; ++hs) {
-        const char* st = ring6 + (hs & 3) * P6_STAGE;
-#ifdef RENET_P6_NOMFMA                // probe builds only: DMA stream + barriers, no fragment reads / MFMAs
-        if (hs >= 0) { __builtin_amdgcn_s_barrier(); continue; }
-#endif
-        bf16x8 fa[2][3], fb[2][3];                                        // [t][plane]
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const char* ia = st + p * P6_PIMG;
-                const char* ib = ia + P6_AIMG;
-                if constexpr (!A_TR) fa[t][p] = *reinterpret_cast<const bf16x8*>(ia + offA[t][0]);
-                else fa[t][p] = frag_tr(ia, offA[t]);
-                if constexpr (!B_TR) fb[t][p] = *reinterpret_cast<const bf16x8*>(ib + offB[t][0]);
-                else fb[t][p] = frag_tr(ib, offB[t]);
-            }
-        // the six term pairs, smallest first (the order of mfma_tile: both kernels sum a k-slab's products alike)
+    // the six term pairs, smallest first (the order of mfma_tile: both kernels sum a k-slab's products alike); group q =
+    // the four MFMAs of one term pair
+    auto mfma_group = [&](const P6Frags& F, auto qc) {
+        constexpr int q = decltype(qc)::value;
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
         constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[q]], fb[j][PB[q]], acc[i][j], 0, 0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                     // barrier hs + 1
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.a[i][PA[q]], F.b[j][PB[q]], acc[i][j], 0, 0, 0);
+    };
+    // One half-stage of a wave, order pinned: the 12 fragment reads of the NEXT half-stage first (they complete under the
+    // MFMAs), then the six MFMA groups with this wave's DMA pieces of half-stage j + 4 between them, ONE piece per gap -- the
+    // two waves of a SIMD (w and w + 4) take different gaps (waves 0-3: behind groups 0..4, waves 4-7: behind groups 2..5):
+    // issued as a burst right behind the barrier, both partners sat in the vector-memory issue together and the matrix
+    // pipe idled (tools/planes_bench.py: 4096^3 640 us with the burst against 534 us without any DMA).
+    auto stage_body = [&](const P6Frags& Fcur, P6Frags& Fnext, int next_slot, auto parc, bool do_issue, char* dbase) {
+        read_frags(Fnext, next_slot, parc);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 6>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+#ifndef RENET_P6_NOMFMA               // (probe builds: DMA stream + barriers only)
+            mfma_group(Fcur, qc);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_issue) {
+                if constexpr (WM == 4) {
+                    if (five) { if constexpr (q < 5) issue_piece(dbase, std::integral_constant<int, q>{}); }
+                    else { if constexpr (q >= 2) issue_piece(dbase, std::integral_constant<int, q - 2>{}); }
+                } else {
+                    issue_piece(dbase, std::integral_constant<int, q>{});           // six pieces, six gaps
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    if (nh > 0) {
+        P6Frags F0, F1;
+        const int npre = min(nh, NS);
+        for (int j = 0; j < npre; ++j) issue(j);
+        wait_left(max(npre - 2, 0));                                      // half-stages 0 and 1 landed
+        __builtin_amdgcn_s_barrier();
+        read_frags(F0, 0, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_s_waitcnt(0xC07F);                               // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();                                     // slot 0 has been read by every wave
+        // iteration j (parity P): DMA of half-stage j + NS into slot j % NS (read during j - 1 / above), fragment reads of
+        // j + 1 into the other register set, MFMAs of j; then half-stage j + 2 must have landed
+        int slot = 0;                                                     // j % NS
+        auto iter = [&](int j, auto pc) {
+            constexpr int P = decltype(pc)::value;
+#ifdef RENET_P6_NODMA                 // probe builds only (tools/p6_probe.py): the k-loop without its DMA stream
+            const bool do_issue = j + NS < nh && j < 1;
+#else
+            const bool do_issue = j + NS < nh;
+#endif
+            char* dbase = ring6 + slot * P6_STAGE;
+            slot = slot + 1 == NS ? 0 : slot + 1;
+            // (the reads are unconditional: after the last half-stage they fetch a slot nobody uses)
+            if constexpr (P == 0) stage_body(F0, F1, slot, std::integral_constant<int, 1>{}, do_issue, dbase);
+            else stage_body(F1, F0, slot, std::integral_constant<int, 0>{}, do_issue, dbase);
+            wait_left(max(min(nh - 1, j + NS) - (j + 2), 0));
+            __builtin_amdgcn_s_waitcnt(0xC07F);                           // lgkmcnt(0), visible to the compiler's scoreboard
+            __builtin_amdgcn_s_barrier();
+        };
+        int j = 0;
+        for (; j + 1 < nh; j += 2) {
+            iter(j, std::integral_constant<int, 0>{});
+            iter(j + 1, std::integral_constant<int, 1>{});
+        }
+        if (j < nh) iter(j, std::integral_constant<int, 0>{});
     }
     p6_store_tile(pa, m0, n0, z, wm, wn, lane, acc);
 }
@@ -274,56 +321,60 @@ __global__ __launch_bounds__(256) void p6_reduce_kernel(const float* __restrict_
     }
 }
 
-// fp32 X[R, C] (row stride ldx) -> three bf16 planes [3][Rp][Cp] (x = p1 + p2 + p3, each term RNE of the running residual:
-// the split of store_items), padding written as zeros; ones_col >= 0: column `ones_col` (>= C) of rows < R is 1.0 (the
-// bias-gradient column, see col_out)
+// fp32 X[R, C] (row stride ldx) -> three bf16 planes in T16 format (x = p1 + p2 + p3, each term RNE of the running
+// residual: the split of store_items), padding written as zeros; ones_col >= 0: column `ones_col` (>= C) of rows < R is 1.0
+// (the bias-gradient column, see col_out).  A workgroup = one tile row x four adjacent tiles: wave w writes tile tc0 + w
+// WHOLE (512 contiguous bytes per plane; lane = (row of the tile, 4-column group)) and the four waves together read 256
+// contiguous bytes of each of the 16 source rows.  (Thread-per-row-segment order wrote 8-byte pieces 512 bytes apart: 3.5x
+// slower on the 188 MB CE gradient.)
 __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restrict__ X, int R, int C, int ldx, int Rp,
                                                           int Cp, int ones_col, __bf16* __restrict__ P, size_t plane) {
-    const size_t total = (size_t)Rp * Cp / 4;
+    const int nbc = Cp >> 6;                               // workgroups per tile row
+    const int tr = blockIdx.x / nbc;
+    const int tc = (blockIdx.x - tr * nbc) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int row = tr * 16 + (lane >> 2), c = tc * 16 + (lane & 3) * 4;
     const bool vec_ok = ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int row = (int)(i / (Cp / 4)), c = (int)(i % (Cp / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < R) {
-            const float* x = X + (size_t)row * ldx + c;
-            if (c + 3 < C && vec_ok) {
-                v = *reinterpret_cast<const float4*>(x);
-            } else {
-                if (c < C) v.x = x[0];
-                if (c + 1 < C) v.y = x[1];
-                if (c + 2 < C) v.z = x[2];
-                if (c + 3 < C) v.w = x[3];
-            }
-            if (ones_col >= c && ones_col < c + 4) {
-                const int d = ones_col - c;
-                if (d == 0) v.x = 1.f; else if (d == 1) v.y = 1.f; else if (d == 2) v.z = 1.f; else v.w = 1.f;
-            }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < R) {
+        const float* x = X + (size_t)row * ldx + c;
+        if (c + 3 < C && vec_ok) {
+            v = *reinterpret_cast<const float4*>(x);
+        } else {
+            if (c < C) v.x = x[0];
+            if (c + 1 < C) v.y = x[1];
+            if (c + 2 < C) v.z = x[2];
+            if (c + 3 < C) v.w = x[3];
         }
-        f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
-        __bf16* dst = P + (size_t)row * Cp + c;
+        if (ones_col >= c && ones_col < c + 4) {
+            const int d = ones_col - c;
+            if (d == 0) v.x = 1.f; else if (d == 1) v.y = 1.f; else if (d == 2) v.z = 1.f; else v.w = 1.f;
+        }
+    }
+    f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    __bf16* dst = P + renet_t16_off(row, c, Cp >> 4);      // 4 consecutive columns = 4 consecutive elements of a tile row half
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const bf16x2 blo = __builtin_convertvector(lo, bf16x2);
-            const bf16x2 bhi = __builtin_convertvector(hi, bf16x2);
-            *reinterpret_cast<uint2*>(dst + (size_t)p * plane) = pack4(blo, bhi);
-            if (p < 2) {
-                lo -= __builtin_convertvector(blo, f32x2);
-                hi -= __builtin_convertvector(bhi, f32x2);
-            }
+    for (int p = 0; p < 3; ++p) {
+        const bf16x2 blo = __builtin_convertvector(lo, bf16x2);
+        const bf16x2 bhi = __builtin_convertvector(hi, bf16x2);
+        *reinterpret_cast<uint2*>(dst + (size_t)p * plane) = pack4(blo, bhi);
+        if (p < 2) {
+            lo -= __builtin_convertvector(blo, f32x2);
+            hi -= __builtin_convertvector(bhi, f32x2);
         }
     }
 }
 
-template <bool A_TR, bool B_TR>
+template <bool A_TR, bool B_TR, int WM>
 int launch_p6(const P6Args& pa, dim3 grid, hipStream_t st) {
     static bool attr_set = false;      // benign race: the attribute is idempotent
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_p6_kernel<A_TR, B_TR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P6_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_p6_kernel<A_TR, B_TR, WM>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)P6Cfg<WM>::LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    RENET_LAUNCH((gemm_p6_kernel<A_TR, B_TR>), grid, dim3(P6_THREADS), P6_LDS, st, pa);
+    RENET_LAUNCH((gemm_p6_kernel<A_TR, B_TR, WM>), grid, dim3(P6Cfg<WM>::THREADS), P6Cfg<WM>::LDS, st, pa);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }

@@ -1749,9 +1749,9 @@ int renet_pack_planes(const float* X, int R, int C, int ldx, int ones_col, void*
     const int cols = ones_col ? C + 1 : C;
     const int Rp = (R + 255) & ~255, Cp = (cols + 255) & ~255;
     if (Rp == 0 || Cp == 0) return RENET_OK;
-    const size_t total = (size_t)Rp * Cp / 4;
-    const int blocks = (int)min((size_t)4096, (total + 255) / 256);
-    RENET_LAUNCH(pack_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, R, C, ldx, Rp, Cp,
+    const size_t blocks = (size_t)(Rp >> 4) * (size_t)(Cp >> 6);       // one workgroup per tile row x 4 tiles
+    if (blocks > 0x7fffffffu) return RENET_ERR_UNSUPPORTED;
+    RENET_LAUNCH(pack_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, R, C, ldx, Rp, Cp,
                  ones_col ? C : -1, (__bf16*)out, (size_t)Rp * Cp);
     RENET_LAUNCH_CHECK();
     return RENET_OK;
@@ -1765,8 +1765,9 @@ int renet_gemm_planes(int a_tr, int b_tr, int M, int N, int K, float alpha, cons
     const int n_main = col_out ? N - 1 : N;
     if (M < 0 || N < 0 || n_main < 0 || K < 1 || ldc < n_main || !Ap || !Bp) return RENET_ERR_BADARG;
     if (M == 0 || N == 0) return RENET_OK;
+    // lda / ldb: Cp (columns of the padded stored matrix, a multiple of 16: T16 tiles, gemm_p6.h)
     const int Mp = (M + 255) & ~255, Np = (N + 127) & ~127, Kp = (K + 15) & ~15;
-    if (lda < (a_tr ? Mp : Kp) || ldb < (b_tr ? Np : Kp) || (lda & 7) || (ldb & 7)) return RENET_ERR_BADARG;
+    if (lda < (a_tr ? Mp : Kp) || ldb < (b_tr ? Np : Kp) || (lda & 15) || (ldb & 15)) return RENET_ERR_BADARG;
     // the plane strides must cover the stored (padded) matrix
     if (a_plane < (size_t)(a_tr ? Kp : Mp) * lda || b_plane < (size_t)(b_tr ? Kp : Np) * ldb) return RENET_ERR_BADARG;
     if (split_k < 1) split_k = 1;
@@ -1776,23 +1777,35 @@ int renet_gemm_planes(int a_tr, int b_tr, int M, int N, int K, float alpha, cons
     P6Args pa;
     pa.A = (const __bf16*)Ap; pa.B = (const __bf16*)Bp;
     pa.a_plane = a_plane; pa.b_plane = b_plane;
-    pa.lda = lda; pa.ldb = ldb;
+    pa.tca = lda >> 4; pa.tcb = ldb >> 4;
     pa.alpha_dev = alpha_dev; pa.col_out = col_out;
     SplitArgs& g = pa.out;
     g.A = nullptr; g.B = nullptr; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
     g.lda = 0; g.ldb = 0; g.ldc = ldc; g.alpha = alpha; g.beta = beta;
     g.split_k = split_k;
-    g.k_tiles_per_split = max(1, (st_total + split_k - 1) / split_k);
+    g.k_tiles_per_split = (max(1, (st_total + split_k - 1) / split_k) + 1) & ~1;     // even: see gemm_p6_kernel
     g.partial = workspace;
     hipStream_t st = (hipStream_t)stream;
-    const int nbx = (N + BN - 1) / BN, nby = Mp / 256;
-    g.xcd_order = panel_width(tile_order(), nbx, nby, 256, K, split_k, 32);
+    // tile height: 128 rows (two workgroups per CU) unless RENET_P6_TILE=256 (one 8-wave workgroup per CU)
+    static int tile_h = 0;
+    if (!tile_h) {
+        const char* e_ = getenv("RENET_P6_TILE");
+        tile_h = (e_ && atoi(e_) == 256) ? 256 : 128;
+    }
+    const int nbx = (N + BN - 1) / BN, nby = (M + tile_h - 1) / tile_h;
+    g.xcd_order = panel_width(tile_order(), nbx, nby, tile_h, K, split_k, tile_h == 256 ? 32 : 64);
     dim3 grid(nbx, nby, split_k);
     int e;
-    if (!a_tr && !b_tr) e = launch_p6<false, false>(pa, grid, st);
-    else if (!a_tr && b_tr) e = launch_p6<false, true>(pa, grid, st);
-    else if (a_tr && !b_tr) e = launch_p6<true, false>(pa, grid, st);
-    else e = launch_p6<true, true>(pa, grid, st);
+#define RENET_P6_LAUNCH(WMV)                                                   \
+    do {                                                                       \
+        if (!a_tr && !b_tr) e = launch_p6<false, false, WMV>(pa, grid, st);    \
+        else if (!a_tr && b_tr) e = launch_p6<false, true, WMV>(pa, grid, st); \
+        else if (a_tr && !b_tr) e = launch_p6<true, false, WMV>(pa, grid, st); \
+        else e = launch_p6<true, true, WMV>(pa, grid, st);                     \
+    } while (0)
+    if (tile_h == 256) RENET_P6_LAUNCH(4);
+    else RENET_P6_LAUNCH(2);
+#undef RENET_P6_LAUNCH
     if (e != RENET_OK) return e;
     if (split_k > 1) {
         const size_t total = (size_t)M * N;

@@ -417,11 +417,17 @@ __device__ __forceinline__ void split3_f4(float4 v, sq_u32x2 (&out)[3]) {
 // 4 t + 2048 q, q < NQ4 (<= 12: C <= 24 576); needs 16-byte aligned rows (ld % 4 == 0).
 template <int NQ4>
 __global__ __launch_bounds__(512, 4) void softmax_ce_planes_kernel(const float* __restrict__ logits,
-                                                                   const int32_t* __restrict__ target, int C, int ld,
+                                                                   const int32_t* __restrict__ target, int B, int C, int ld,
                                                                    float grad_scale, float* __restrict__ row_loss,
                                                                    __bf16* __restrict__ P, size_t plane, int ld16) {
     __shared__ float red_m[8], red_s[8];
-    const int b = blockIdx.x;
+    // row of this workgroup: the 16 rows of a T16 tile row share every 128-byte line of the output (a row contributes 32
+    // bytes per tile), and the dispatcher deals workgroups to the XCDs round-robin (block L -> XCD L & 7, each with its own
+    // write-back L2) -- so the 16 workgroups of a tile row are given CONSECUTIVE slots of ONE XCD: its L2 merges their
+    // pieces into whole lines before they leave for HBM.  (With row = blockIdx.x eight L2s each held an eighth of every
+    // line: 236 us instead of 95 for the 2048 x 23033 gradient.)
+    const int b = ((((int)blockIdx.x >> 7) * 8 + ((int)blockIdx.x & 7)) << 4) + (((int)blockIdx.x >> 3) & 15);
+    if (b >= B) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = target[b];
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
@@ -468,14 +474,19 @@ __global__ __launch_bounds__(512, 4) void softmax_ce_planes_kernel(const float* 
 #pragma unroll
     for (int w = 0; w < 8; ++w) s += red_s[w];
     if (mine) row_loss[b] = logf(s) + m - xt;
-    // stores through one descriptor per plane: exactly the C64 (<= ld16) bf16 of the row; groups beyond are dropped
-    const int C64 = min((C + 63) & ~63, ld16);
+    // stores in T16 format (common.h): row b lives in tile row b >> 4; this thread's float4 group q covers columns
+    // 4 t + 2048 q = tile column (t >> 2) + 128 q, tile-row half (t >> 1) & 1, 8 bytes at (t & 1) * 8 -- all per-thread
+    // constants but the 64 KB step per q.  One descriptor per plane over the tile row (ld16 / 16 tiles of 512 bytes).
+    const int i16 = b & 15;
+    const int tcl = (int)threadIdx.x >> 2;
+    const int vo = tcl * 512 + ((i16 ^ ((tcl & 1) << 2)) * 32) + (((((int)threadIdx.x >> 1) & 1) ^ ((i16 >> 3) & 1)) * 16) +
+                   ((int)threadIdx.x & 1) * 8;
     __amdgpu_buffer_rsrc_t rout[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
-        rout[p] = __builtin_amdgcn_make_buffer_rsrc(P + (size_t)p * plane + (size_t)b * ld16, (short)0, C64 * 2, 0x00020000);
+        rout[p] = __builtin_amdgcn_make_buffer_rsrc(P + (size_t)p * plane + (size_t)(b >> 4) * ld16 * 16, (short)0,
+                                                    ld16 * 32, 0x00020000);
     const float inv = 1.f / s;
-    const int vo = (int)threadIdx.x * 8;
 #pragma unroll
     for (int q = 0; q < NQ4; ++q) {
         float4 o = make_float4(v[q].x * inv, v[q].y * inv, v[q].z * inv, v[q].w * inv);
@@ -485,8 +496,10 @@ __global__ __launch_bounds__(512, 4) void softmax_ce_planes_kernel(const float* 
         o = f4_scale(o, grad_scale);
         sq_u32x2 pk[3];
         split3_f4(o, pk);
+        if (c0 < ld16 - 2048 * q) {                     // (columns in [C, ld16) are exact zeros: the k / tile padding)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) __builtin_amdgcn_raw_buffer_store_b64(pk[p], rout[p], vo, 4096 * q, 0);
+            for (int p = 0; p < 3; ++p) __builtin_amdgcn_raw_buffer_store_b64(pk[p], rout[p], vo, 65536 * q, 0);
+        }
     }
 }
 
@@ -515,14 +528,14 @@ __global__ __launch_bounds__(256) void softmax_ce_planes_generic_kernel(const fl
     const int t = target[b];
     if (threadIdx.x == 0) row_loss[b] = logf(s) + m - x[t];
     const float inv = 1.f / s;
-    const int C64 = min((C + 63) & ~63, ld16);
-    __bf16* dx = P + (size_t)b * ld16;
-    for (int c = threadIdx.x; c < C64; c += 256) {
+    const int tcn = ld16 >> 4;
+    for (int c = threadIdx.x; c < ld16; c += 256) {
         float r = c < C ? (expf(x[c] - m) * inv - (c == t ? 1.f : 0.f)) * grad_scale : 0.f;
+        __bf16* dx = P + renet_t16_off(b, c, tcn);
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const __bf16 h = (__bf16)r;
-            dx[(size_t)p * plane + c] = h;
+            dx[(size_t)p * plane] = h;
             r -= (float)h;
         }
     }
@@ -792,26 +805,27 @@ static int softmax_ce_impl(const float* logits, const int32_t* target, int B, in
 
 int renet_softmax_ce_planes(const float* logits, const int32_t* target, int B, int C, int ld, float grad_scale,
                             float* row_loss, void* dl_planes, size_t plane, int ld16, int rows16, void* stream) {
-    if (B < 0 || C <= 0 || ld < C || !dl_planes || ld16 < C || (ld16 & 3) || rows16 < B) return RENET_ERR_BADARG;
+    if (B < 0 || C <= 0 || ld < C || !dl_planes || ld16 < C || (ld16 & 15) || rows16 < ((B + 15) & ~15)) return RENET_ERR_BADARG;
     if (plane < (size_t)rows16 * ld16) return RENET_ERR_BADARG;
     if (B == 0) return RENET_OK;
     hipStream_t st = (hipStream_t)stream;
     __bf16* P = (__bf16*)dl_planes;
-    // rows [B, rows16): the k padding of dW = dl^T feat (contraction over the rows) must be zero in every plane
-    if (rows16 > B) {
+    // rows [B, ceil16(B)): the k padding of dW = dl^T feat (contraction over the rows, 16 per half-stage) must be zero in
+    // every plane: with T16 tiles that is the rest of tile row B >> 4 -- zeroed here, BEFORE the kernel writes its rows < B
+    if ((B & 15) != 0) {
         for (int p = 0; p < 3; ++p) {
-            hipError_t e = hipMemsetAsync(P + (size_t)p * plane + (size_t)B * ld16, 0,
-                                          (size_t)(rows16 - B) * ld16 * sizeof(__bf16), st);
+            hipError_t e = hipMemsetAsync(P + (size_t)p * plane + (size_t)(B >> 4) * ld16 * 16, 0,
+                                          (size_t)ld16 * 16 * sizeof(__bf16), st);
             if (e != hipSuccess) return (int)e;
         }
     }
     const bool aligned = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(dl_planes) & 7) == 0 && (plane & 3) == 0;
-    if (aligned && C >= 2048 && C <= 12 * 2048) {
-        const dim3 grid(B), blk(512);
-        if (C <= 4 * 2048) RENET_LAUNCH((softmax_ce_planes_kernel<4>), grid, blk, 0, st, logits, target, C, ld, grad_scale, row_loss, P, plane, ld16);
-        else if (C <= 8 * 2048) RENET_LAUNCH((softmax_ce_planes_kernel<8>), grid, blk, 0, st, logits, target, C, ld, grad_scale, row_loss, P, plane, ld16);
-        else RENET_LAUNCH((softmax_ce_planes_kernel<12>), grid, blk, 0, st, logits, target, C, ld, grad_scale, row_loss, P, plane, ld16);
+    if (aligned && C >= 2048 && ld16 <= 12 * 2048) {
+        const dim3 grid((unsigned)((B + 127) & ~127)), blk(512);     // whole groups of 8 XCDs x 16 rows (see the kernel)
+        if (ld16 <= 4 * 2048) RENET_LAUNCH((softmax_ce_planes_kernel<4>), grid, blk, 0, st, logits, target, B, C, ld, grad_scale, row_loss, P, plane, ld16);
+        else if (ld16 <= 8 * 2048) RENET_LAUNCH((softmax_ce_planes_kernel<8>), grid, blk, 0, st, logits, target, B, C, ld, grad_scale, row_loss, P, plane, ld16);
+        else RENET_LAUNCH((softmax_ce_planes_kernel<12>), grid, blk, 0, st, logits, target, B, C, ld, grad_scale, row_loss, P, plane, ld16);
     } else {
         RENET_LAUNCH(softmax_ce_planes_generic_kernel, dim3(B), dim3(256), 0, st, logits, target, C, ld, grad_scale,
                      row_loss, P, plane, ld16);

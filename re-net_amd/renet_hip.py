@@ -688,7 +688,10 @@ PLANES_MIN_CLASSES = int(os.environ.get('RENET_PLANES_MIN_CLASSES', '2048'))
 
 
 class PlanesMat(object):
-    """A matrix [R, C] as three bf16 planes in ONE tensor p [3, Rp, Cp] (Rp, Cp multiples of 256, zero padding)."""
+    """A matrix [R, C] as three bf16 planes in ONE tensor p [3, Rp, Cp] (Rp, Cp multiples of 256, zero padding).  The
+    elements of a plane are NOT row-major: they are stored in the T16 tile format of csrc/gemm_p6.h (16 x 16 tiles of 512
+    bytes; csrc/common.h renet_t16_off, tools/p6_layout_sim.py) -- p's trailing two dimensions only size the buffer;
+    planes_to_dense() gives the row-major view (tests)."""
     __slots__ = ('p', 'R', 'C')
 
     def __init__(self, p, R, C):
@@ -701,6 +704,17 @@ class PlanesMat(object):
     @property
     def plane(self):
         return self.p.shape[1] * self.p.shape[2]
+
+
+def planes_to_dense(m):
+    """-> float32 [3, Rp, Cp]: the planes of PlanesMat m in row-major order (undoes the T16 tiling; tests / debugging)."""
+    rp, cp = m.p.shape[1], m.p.shape[2]
+    dev = m.p.device
+    r = torch.arange(rp, device=dev).view(-1, 1)
+    c = torch.arange(cp, device=dev).view(1, -1)
+    i, j, tc = r & 15, c & 15, c >> 4
+    idx = ((r >> 4) * (cp // 16) + tc) * 256 + (i ^ ((tc & 1) << 2)) * 16 + ((j >> 3) ^ ((i >> 3) & 1)) * 8 + (j & 7)
+    return m.p.reshape(3, -1)[:, idx.reshape(-1)].reshape(3, rp, cp).float()
 
 
 def planes_empty(r, c, device, zero=False):

@@ -30,7 +30,7 @@ def test_pack_planes_is_the_three_term_rne_split(dev):
     for ones in (False, True):
         m = K.pack_planes(xd, ones_col=ones)
         assert m.p.shape == (3, 512, 256) and (m.R, m.C) == (300, 77 + int(ones))
-        p = m.p.float().cpu().numpy()
+        p = K.planes_to_dense(m).cpu().numpy()
         r = torch.from_numpy(x)
         for k in range(3):
             t = r.to(torch.bfloat16).float()
@@ -70,6 +70,36 @@ def test_gemm_planes_matches_fp64_and_the_in_loop_split(dev, m, n, k, ta, tb, sk
     # the in-loop split computes the same six products per element pair: equal up to fp32 summation order
     old = K.gemm(ad, bd, ta=bool(ta), tb=bool(tb), bias=_to(bias, dev), mode='bf16x6')
     np.testing.assert_allclose(out.cpu().numpy(), old.cpu().numpy(), rtol=2e-6, atol=2e-6 * max(1, k) ** 0.5)
+
+
+_TILE_CHECK = r'''
+import sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import renet_hip as K
+dev = torch.device('cuda:0')
+for m, n, k, ta, tb, sk in %r:
+    rng = np.random.RandomState(m + n + k)
+    a = rng.uniform(-1, 1, (k, m) if ta else (m, k)).astype(np.float32)
+    b = rng.uniform(-1, 1, (n, k) if tb else (k, n)).astype(np.float32)
+    ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+    out = K.gemm_planes(K.pack_planes(torch.from_numpy(a).to(dev)), K.pack_planes(torch.from_numpy(b).to(dev)),
+                        ta=bool(ta), tb=bool(tb), split_k=sk)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * max(1, k) ** 0.5)
+print('ok')
+'''
+
+
+def test_gemm_planes_256_row_tile_variant(dev):
+    """RENET_P6_TILE=256 selects the 8-wave 256 x 128 tile (one workgroup per CU) instead of the default 128 x 128 one:
+    the same cases in a child process (the switch is read once)."""
+    import os
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 're-net_amd')
+    r = subprocess.run([sys.executable, '-c', _TILE_CHECK % (CASES,), pkg], env=dict(os.environ, RENET_P6_TILE='256'),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
 
 
 @pytest.mark.parametrize('m,n,k,sk', [(700, 130, 520, 1), (2100, 600, 300, 1), (600, 200, 5000, 6)])
@@ -124,16 +154,15 @@ def test_softmax_ce_planes_equals_the_fp32_kernel(dev, b, c):
     ref_in = _to(x, dev).clone()
     loss_f = K.softmax_ce(ref_in, _to(t, dev), gs, True)
     np.testing.assert_allclose(loss_p.cpu().numpy(), loss_f.cpu().numpy(), rtol=1e-6, atol=1e-6)
-    p = dl.p.float().cpu().numpy()
+    p = K.planes_to_dense(dl).cpu().numpy()
     grad = ref_in.cpu().numpy()
     rec = p[0, :b, :c].astype(np.float64) + p[1, :b, :c] + p[2, :b, :c]
     np.testing.assert_allclose(rec, grad, rtol=2e-6, atol=1e-9)
     r = torch.from_numpy(rec.astype(np.float32))
     assert np.array_equal(p[0, :b, :c], r.to(torch.bfloat16).float().numpy()) or \
         np.mean(p[0, :b, :c] != r.to(torch.bfloat16).float().numpy()) < 1e-3      # (rec is a rounded sum: rare ties)
-    c64 = min((c + 63) & ~63, p.shape[2])
-    assert np.all(p[:, :b, c:c64] == 0.0)
-    assert np.all(p[:, b:((b + 31) & ~31), :c64] == 0.0)
+    assert np.all(p[:, :b, c:] == 0.0)                                 # the whole column padding of the written rows
+    assert np.all(p[:, b:((b + 15) & ~15), :] == 0.0)                  # the k padding of dW (16 rows per half-stage)
     assert np.array_equal(buf[:, :c].cpu().numpy(), x)               # the logits are left untouched
 
 
