@@ -87,8 +87,12 @@ def compact_line(out, detail_path=None):
     if out.get('kernel_only'):
         optional.append(('kernel_only', _pick(out['kernel_only'], ('ms_per_step', 'glue_ms_per_step',
                                                                    'timed_pass_ms_per_step'))))
-    for k in ('e2e_device_builder', 'host_enqueue_ms_per_step', 'launches_per_step', 'host_build_ms', 'last_loss',
-              'rccl_ranks_seen', 'scaling_mode'):
+    if out.get('value_median'):
+        optional.insert(0, ('value_median', _pick(out['value_median'], ('value', 'ms_per_step', 'steps', 'p10_ms', 'p90_ms'))))
+    if out.get('value_list_api'):
+        optional.append(('value_list_api', _pick(out['value_list_api'], ('value', 'ms_per_step', 'steps'))))
+    for k in ('e2e_device_builder', 'host_enqueue_ms_per_step', 'plan_entries_per_step', 'launches_per_step', 'host_build_ms',
+              'last_loss', 'rccl_ranks_seen', 'scaling_mode'):
         if out.get(k) is not None:
             optional.append((k, _r(out[k])))
     if out.get('encoder_only'):
@@ -124,7 +128,21 @@ def compact_line(out, detail_path=None):
         line.pop(k, None)
         line['dropped'] = line.get('dropped', 0) + 1
         text = json.dumps(line, separators=(',', ':'))
-    assert len(text) < LINE_LIMIT, len(text)
+    # the mandatory part alone over the limit (a very long workload / sample / metric string): shorten its free-text fields
+    # rather than lose the line after the whole benchmark has run
+    for holder, key in ((line.get('cpu_baseline') or {}, 'sample'), (line['config'], 'workload'), (line, 'metric'),
+                        (line, 'detail'), (line, 'data')):
+        if len(text) < LINE_LIMIT:
+            break
+        v = holder.get(key)
+        if isinstance(v, str) and len(v) > 48:
+            holder[key] = v[:45] + '...'
+            line['truncated'] = line.get('truncated', 0) + 1
+            text = json.dumps(line, separators=(',', ':'))
+    if len(text) >= LINE_LIMIT:
+        text = json.dumps({k: line[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
+                                                'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')},
+                          separators=(',', ':'))[:LINE_LIMIT - 1]
     return text
 
 
@@ -164,6 +182,10 @@ def parse():
                          'them as scaling_strong / scaling_exact in the same JSON line (0 = skip)')
     ap.add_argument('--cpu-threads', type=int, default=0, help='torch threads for the CPU baseline (0 = min(32, cores))')
     ap.add_argument('--e2e-steps', type=int, default=5)
+    ap.add_argument('--list-steps', type=int, default=30,
+                    help="steps of `value_list_api`: the reference's own loop body (train.py:133-142: nested history lists, two "
+                         'model() calls, loss.backward(), clip_grad_norm_, torch.optim.Adam, loss.item()) timed end to end '
+                         '(0 = skip)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong', 'exact'],
                     help='weak: --batch quadruples per GPU (default); strong: --batch quadruples per step in total, '
                          'batch / N per GPU, each rank with its own (smaller) reference batch; exact: ONE reference '
@@ -212,6 +234,7 @@ def main():
     args = parse()
     if args.plain:
         args.cpu_steps = args.enc_steps = args.e2e_steps = args.f32_steps = args.other_steps = args.companions = 0
+        args.list_steps = 0
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -343,7 +366,6 @@ def main():
             t0 = time.perf_counter()
             for k in range(args.warmup, n_total):
                 loss = self.train_step(*prepared[k])
-            self.enqueue_s = time.perf_counter() - t0      # host time to ENQUEUE the K steps (no sync inside a step)
             sync_all()
             elapsed = time.perf_counter() - t0
             K.set_timer(None)
@@ -354,6 +376,31 @@ def main():
                 elapsed = float(tmax.item())
             return elapsed, last, host_ms, prepared
 
+        def per_step_pass(self, prepared, n_steps):
+            """`n_steps` more steps over the prepared batches (cyclically) with ONE HIP event between consecutive steps ->
+            the per-step device times in ms (median / spread: a K-step wall-clock window of 55 ms decides nothing).
+            Product configuration (no per-kernel events); parameters keep training."""
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
+            sync_all()
+            evs[0].record()
+            for k in range(n_steps):
+                self.train_step(*prepared[args.warmup + k % args.steps])
+                evs[k + 1].record()
+            sync_all()
+            return [evs[k].elapsed_time(evs[k + 1]) for k in range(n_steps)]
+
+        def enqueue_pass(self, prepared, n_steps=16):
+            """Host time to ENQUEUE a step (no synchronisation inside), over a window short enough that the launch queues
+            never fill: once the host is hundreds of launches ahead of the GPU it blocks on queue space and the figure
+            degenerates into the device time per step."""
+            sync_all()
+            t0 = time.perf_counter()
+            for k in range(n_steps):
+                self.train_step(*prepared[args.warmup + k % args.steps])
+            dt = time.perf_counter() - t0
+            sync_all()
+            return dt * 1e3 / n_steps
+
     mode = Mode(args.scaling)
     args.passes = mode.passes
     exact_split, rank_batch = mode.exact, mode.rank_batch
@@ -362,7 +409,18 @@ def main():
     # the timed region of `value`: the product configuration (side streams on, no per-kernel events) ...
     elapsed, last_loss, host_build_ms, prepared = mode.run()
     value = mode.global_batch * args.steps / elapsed
-    host_enqueue_ms = mode.enqueue_s * 1e3 / args.steps
+    # the same step measured two more ways (product configuration, same prepared batches): per-step HIP events over >= 100
+    # steps whatever --steps says (median and spread), and the host's enqueue time over a 16-step window
+    per_step = mode.per_step_pass(prepared, max(100, args.steps) if not args.child else max(20, args.steps))
+    per_step_sorted = sorted(per_step)
+    ms_median = per_step_sorted[len(per_step_sorted) // 2]
+    median_block = {'value': mode.global_batch * 1e3 / ms_median, 'ms_per_step': ms_median, 'steps': len(per_step),
+                    'p10_ms': per_step_sorted[len(per_step_sorted) // 10], 'p90_ms': per_step_sorted[(len(per_step_sorted) * 9) // 10],
+                    'what': 'median of per-step HIP-event intervals (one event between consecutive steps, product '
+                            'configuration); `value` is the contract\'s K-step wall-clock window'}
+    host_enqueue_ms = mode.enqueue_pass(prepared)
+    import step_plan as step_plan_mod
+    plan_entries = sum(step_plan_mod.StepFn.last_launches) if (step_plan_mod.ENABLED and sum(step_plan_mod.StepFn.last_launches)) else None
     # ... then the SAME K steps once more with HIP events around every C-ABI launch: the per-class kernel table, the
     # roofline's average launch durations and `kernel_only` come from this second pass (its wall time is reported too)
     timer = K.KernelTimer()
@@ -407,6 +465,53 @@ def main():
                         'steps': args.enc_steps,
                         'what': 'RGCN x2 + sequence assembly + GRU x2 (both encoders), both directions, forward + '
                                 'backward incl. their parameter gradients; no score heads, clip or Adam'}
+
+    # ---- the reference's loop body through the API it calls (train.py:133-142), unmodified statement by statement:
+    # nested history lists as train.py holds them in memory (unpickled once, sliced per batch by utils.make_batch2), the
+    # TWO model() calls of a batch, loss.backward(), torch's clip_grad_norm_, torch.optim.Adam, zero_grad, loss.item().
+    # `fuse_directions` (the two calls share one merged pass) and the device batch builder are the package's switches for
+    # this API; everything else is what a user of the reference runs.  End to end: list flattening, upload, batch build,
+    # step and the per-step host sync are all inside the timed region.
+    value_list_api = None
+    if args.list_steps > 0 and world == 1:
+        model = M.RENet(num_ent, args.hidden, num_rels, dropout=args.dropout, seq_len=args.seq_len, num_k=1000)
+        model.global_emb = net.global_emb
+        model.to(dev)
+        model.train()
+        model.fuse_directions = True
+        optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+        n_list = args.list_steps + 3
+        batches = []
+        for k in range(n_list):
+            idx = parallel.shard_indices(perm, n_total + 5000 + k, 0, 1, args.batch)
+            s_hist, s_hist_t = hist_s.to_lists(idx)
+            o_hist, o_hist_t = hist_o.to_lists(idx)
+            batches.append((quads[idx], s_hist, s_hist_t, o_hist, o_hist_t))
+        loss_epoch = 0
+        t0 = None
+        for k, (batch_data, s_hist, s_hist_t, o_hist, o_hist_t) in enumerate(batches):
+            if k == 3:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            batch_data = torch.from_numpy(batch_data).long()
+            batch_data = batch_data.cuda()
+            loss_s = model(batch_data, (s_hist, s_hist_t), (o_hist, o_hist_t), graph_dict, subject=True)
+            loss_o = model(batch_data, (s_hist, s_hist_t), (o_hist, o_hist_t), graph_dict, subject=False)
+            loss = loss_s + loss_o
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)  # clip gradients
+            optimizer.step()
+            optimizer.zero_grad()
+            loss_epoch += loss.item()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        value_list_api = {'value': args.batch * args.list_steps / dt, 'unit': 'triples/s',
+                          'ms_per_step': dt * 1e3 / args.list_steps, 'steps': args.list_steps,
+                          'what': "the reference's loop body (train.py:133-142) over this package's RENet: nested lists, "
+                                  'two model() calls (fuse_directions on), loss.backward(), clip_grad_norm_, '
+                                  'torch.optim.Adam, zero_grad, loss.item() -- end to end incl. list flattening, upload, '
+                                  'device batch build and the per-step host sync'}
+        del model, optimizer, batches
 
     # ---- end-to-end rates with the host builder in the loop (extras, never `value`) ----------------
     #  e2e_inline : builder on the training thread (one batch at a time)
@@ -652,7 +757,7 @@ def main():
         import subprocess
         cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(steps), '--warmup', str(args.warmup),
                '--batch', str(args.batch), '--dropout', str(args.dropout), '--cpu-steps', str(cpu_steps),
-               '--cpu-warmup', '0', '--e2e-steps', '0', '--f32-steps', '0', '--enc-steps', '0', '--other-steps', '0',
+               '--cpu-warmup', '0', '--e2e-steps', '0', '--list-steps', '0', '--f32-steps', '0', '--enc-steps', '0', '--other-steps', '0',
                '--passes', args.passes, '--child', '1'] + extra_args
         r = subprocess.run(cmd, env=dict(os.environ, **env_extra), capture_output=True, text=True)
         try:
@@ -721,7 +826,10 @@ def main():
         'other_configs': other_configs,
         'pmc_source': pmc_file,
         'traffic_source': ('%s: rocprofv3 --pmc passes of this command (tools/pmc_traffic.py), NOT measured in this run' % pmc_file) if pmc_file else None, 'kernels': kernels, 'gemm_shapes': gemm_shapes, 'cpu_baseline': cpu,
-        'launches_per_step': sum(e_['calls_per_step'] for e_ in kernels.values()) or None,     # C-ABI launches
+        'launches_per_step': sum(e_['calls_per_step'] for e_ in kernels.values()) or None,     # C-ABI launches (autograd path, timed pass)
+        'plan_entries_per_step': plan_entries,
+        'value_list_api': value_list_api,             # launches the C launch list issues per step (csrc/step.cpp: forward + backward)
+        'value_median': median_block,
         'host_enqueue_ms_per_step': host_enqueue_ms,       # host time to enqueue a step of the `value` run; close to
                                                            # ms_per_step = the host, not the GPU, paces the step
         'host_build_ms': host_build_ms, 'e2e_value': e2e, 'e2e_workers': e2e_workers, 'e2e_inline': e2e_inline, 'e2e_threads8': e2e_threads,
@@ -740,10 +848,13 @@ def main():
 
 
 def cpu_baseline(args, quads, num_ent, num_rels, hist_s, hist_o, net, perm):
-    """Times the oracle (oracle/renet_oracle.py: the reference's algorithm restated on torch-CPU; the reference
-    itself is not on this box) on a bounded sample of the SAME workload: `cpu_steps` training steps (forward both
-    directions + backward, eval-mode dropout) at the same batch size after `cpu_warmup` untimed ones, per-stage medians.
-    Returns (record, oracle losses per timed step, the step indices used).  Reported baseline, not a target."""
+    """Times the oracle (oracle/renet_oracle.py: the reference's algorithm restated on torch-CPU; the reference itself
+    -- Python + DGL -- cannot travel to this box) on a bounded sample of the SAME workload, in the SAME mode as the GPU
+    step: `cpu_steps` TRAINING steps (forward both directions with the five dropout sites at --dropout, backward) at the
+    same batch size after `cpu_warmup` untimed ones, per-stage medians.  The parity check needs deterministic losses: a few
+    of the same batches are evaluated once more in eval mode (not timed).
+    Returns (record, eval-mode oracle losses, their step indices, the eval-mode gradient of the first).  Reported baseline,
+    not a target."""
     from oracle import renet_oracle as O
     import parallel
     threads = args.cpu_threads or min(32, os.cpu_count() or 1)
@@ -752,41 +863,54 @@ def cpu_baseline(args, quads, num_ent, num_rels, hist_s, hist_o, net, perm):
     params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.state_dict().items()}
     ge = {t: v.view(-1).cpu() for t, v in net.global_emb.items()}
     ogd = O.build_graph_dict(quads, num_rels)
-    times, stages, losses, steps_idx = [], [], [], []
     warm = max(0, args.cpu_warmup)
-    first_grad = None
-    for k in range(args.cpu_steps + warm):
-        step = 1000 + k
+
+    def one_step(step, dropout, tm=None):
         idx = parallel.shard_indices(perm, step, 0, 1, args.batch)
         hs, hst = hist_s.to_lists(idx)
         ho, hot = hist_o.to_lists(idx)
-        tm = O.StageTimer()
         t0 = time.perf_counter()
         loss = O.renet_forward_loss(params, quads[idx], hs, hst, ogd, ge, num_rels, args.seq_len, subject=True,
-                                    timer=tm) + \
-            O.renet_forward_loss(params, quads[idx], ho, hot, ogd, ge, num_rels, args.seq_len, subject=False, timer=tm)
-        tm.reset()
+                                    timer=tm, dropout=dropout) + \
+            O.renet_forward_loss(params, quads[idx], ho, hot, ogd, ge, num_rels, args.seq_len, subject=False, timer=tm,
+                                 dropout=dropout)
+        if tm is not None:
+            tm.reset()
         loss.backward()
-        tm.mark('backward')
-        dt = time.perf_counter() - t0
-        if k == warm:          # gradient of the first timed step, for bench `parity.grad_rel_err`
-            first_grad = {n: (p.grad.detach().double().numpy() if p.grad is not None else np.zeros(tuple(p.shape)))
-                          for n, p in params.items()}
+        if tm is not None:
+            tm.mark('backward')
+        return loss, time.perf_counter() - t0
+
+    times, stages = [], []
+    torch.manual_seed(1234)
+    for k in range(args.cpu_steps + warm):                 # the TIMED sample: train mode, like the GPU step
+        tm = O.StageTimer()
+        loss, dt = one_step(1000 + k, args.dropout, tm)
         for p in params.values():
             p.grad = None
         if k >= warm:
             times.append(dt)
             stages.append(dict(tm.t))
-            losses.append(float(loss.item()))
-            steps_idx.append(step)
+    losses, steps_idx, first_grad = [], [], None
+    for k in range(min(3, args.cpu_steps)):                # the checker: eval mode (deterministic), not timed
+        step = 1000 + warm + k
+        loss, _ = one_step(step, 0.0)
+        if first_grad is None:                             # for bench `parity.grad_rel_err`
+            first_grad = {n: (p.grad.detach().double().numpy() if p.grad is not None else np.zeros(tuple(p.shape)))
+                          for n, p in params.items()}
+        for p in params.values():
+            p.grad = None
+        losses.append(float(loss.item()))
+        steps_idx.append(step)
     torch.set_num_threads(old_threads)
     t = float(np.median(times))
     stage_ms = {k: float(np.median([s_[k] for s_ in stages])) * 1e3 for k in stages[0]}
     rec = {'value': args.batch / t, 'unit': 'triples/s', 'cores': int(threads), 'kind': 'port',
-           'host_cpus': os.cpu_count(), 'ms_per_step': t * 1e3, 'stage_ms_median': stage_ms,
-           'sample': '%d training steps (fwd both directions + bwd, eval-mode dropout) of batch %d after %d warm-ups, '
-                     'oracle/renet_oracle.py (restated reference; the unmodified reference + DGL does not travel to the '
-                     'GPU box) on torch-CPU with %d threads; medians' % (len(times), args.batch, warm, threads)}
+           'host_cpus': os.cpu_count(), 'ms_per_step': t * 1e3, 'stage_ms_median': stage_ms, 'mode': 'train',
+           'sample': '%d TRAINING steps (fwd both directions with dropout %.2f at the five nn.Dropout sites + bwd) of batch '
+                     '%d after %d warm-ups, oracle/renet_oracle.py (restated reference; the Python + DGL reference cannot '
+                     'travel to the GPU box) on torch-CPU with %d threads; medians'
+                     % (len(times), args.dropout, args.batch, warm, threads)}
     return rec, losses, steps_idx, first_grad
 
 

@@ -569,6 +569,77 @@ int renet_build_batch_both(const RenetStoreDev* store, const int32_t* idx_dev, i
                            size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * THE MERGED TRAINING STEP AS ONE LAUNCH LIST (round 6; csrc/step.cpp): one iteration of train.py:136-139 --
+ *     loss = model(batch, ..., subject=True) + model(batch, ..., subject=False);  loss.backward()
+ * on the merged batch of both directions (renet_build_batch_both / graph.build_batch_both) -- issued from C: the forward
+ * call enqueues the ~25 launches of  RGCN x2 (RGCN.py:33-51,79-94) -> sequence assembly (Aggregator.py:139-165) -> GRU x2
+ * (model.py:86,94) -> both score heads + CE (model.py:89-103), the backward call the ~35 launches of their gradients, on two
+ * HIP streams with the fork / join events between them (the relation head and encoder_r's projection next to the entity
+ * head / encoder; parameter-gradient kernels that feed nothing but the optimizer on the side stream).  Every launch goes
+ * through the entry points of this header with exactly the arguments the Python autograd path (re-net_amd/ops.py) passes,
+ * so losses and gradients are BIT-identical to that path (tests/test_gpu_step_plan.py); the host cost of a step drops from
+ * ~55 Python-level C-ABI calls to two.
+ *   RenetStepModel : parameters and their gradient buffers (gradients ACCUMULATE: beta = 1 everywhere, as into an existing
+ *                    .grad), the global-embedding matrix, optionally the planes of the entity head's weight
+ *   RenetStepBatch : the device arrays of one merged batch (graph.DeviceGraph / gpu_builder.DeviceBatch) + its sizes
+ *   RenetStepRun   : dropout seeds, loss scales, the workspace, the two streams
+ *   renet_step_workspace : bytes of workspace for (model, batch); activations live there between forward and backward
+ *   renet_step_forward   : writes the 2 B per-row losses (entity head rows, then relation head rows) to row_loss
+ *   renet_step_backward  : upstream scalar g (device); defer_side != 0 leaves the side stream UN-joined (the caller joins it
+ *                          before it reads a parameter gradient: parallel.HipAdam.step); ev_head_done (optional hipEvent_t)
+ *                          is recorded when the entity head's weight / bias gradients are complete (early all-reduce bucket)
+ *   both return the number of C-ABI launches they issued in *n_launches (optional).
+ * fp32-class default mode only (bf16x6 GEMMs, bf16x6 recurrences); tensors below 2 GiB. */
+typedef struct { const int32_t *order, *seg_ptr, *target; int num_segments; } RenetSegPlan;
+typedef struct {
+    int D, num_ent, T, C2;                     /* n_hidden; entities; 2 * num_rels relation types; classes of the relation head */
+    float drop_p;                              /* 0 in eval mode */
+    const float *ent, *rel;                    /* [num_ent, D], [T, D] */
+    const float *w1, *loop1, *w2, *loop2;      /* rgcn1 / rgcn2: weight [T, D * D / 100], loop_weight [D, D] */
+    const float *wih, *whh, *bih, *bhh;        /* encoder   (4D -> D): [3D, 4D], [3D, D], [3D], [3D] */
+    const float *wih_r, *whh_r, *bih_r, *bhh_r;/* encoder_r (3D -> D): [3D, 3D], ... */
+    const float *lin_w, *lin_b;                /* linear   [num_ent, 3D], [num_ent] */
+    const float *linr_w, *linr_b;              /* linear_r [C2, 2D], [C2] */
+    float *g_ent, *g_rel, *g_w1, *g_loop1, *g_w2, *g_loop2, *g_wih, *g_whh, *g_bih, *g_bhh, *g_wih_r, *g_whh_r, *g_bih_r,
+          *g_bhh_r, *g_lin_w, *g_lin_b, *g_linr_w, *g_linr_b;
+    const float* glob;                         /* [n_glob, D] global embeddings (a constant of the step) */
+    const void* lin_w_planes;                  /* optional: renet_pack_planes(lin_w); NULL = the in-loop-split head */
+    size_t lin_w_plane;                        /*   elements per plane */
+    int lin_w_ld;                              /*   Cp of the planes */
+} RenetStepModel;
+typedef struct {
+    int N, E, nA, S, B, L, n_items;            /* nodes, edges, rows of layer 2, packed rows, sequences, steps, items */
+    int n_groups, n_groups_out, n_heavy, n_heavy_out, n_chunks, n_chunks2;
+    const int32_t* step_off_host;              /* [L + 1] HOST copy of step_off */
+    const int32_t *node_ent, *row_ptr, *col, *etype;
+    const float* norm;
+    const int32_t *it_src, *it_type, *grp_ptr, *heavy_rows, *heavy_rows_out;
+    const int32_t *it_src_t, *it_type_t, *col_t, *e_src_t;        /* renet_compose_table_items */
+    const int32_t *e_src, *e_dst, *chunk_ptr, *chunk_type, *type_chunk_ptr;
+    const int32_t *e_src2, *e_dst2, *chunk_ptr2, *chunk_type2, *type_chunk_ptr2;
+    const int32_t *subj_row, *row_ent, *row_rel, *glob_row, *step_off;
+    const int32_t *s_idx, *r_idx, *ent_label, *rel_label;
+    RenetSegPlan plan_node_ent, plan_subj_row, plan_s, plan_r;
+} RenetStepBatch;
+typedef struct {
+    uint64_t seed_rgcn1, seed_rgcn2, seed_x, seed_xr, seed_head1, seed_head2;
+    float scale_ent, scale_rel;                /* CE gradient scales: loss_scale / B and loss_scale * 0.1 / B (model.py:103) */
+    void* workspace;
+    size_t workspace_bytes;
+    void *stream, *side_stream;                /* hipStream_t; side_stream may equal stream (everything in stream order) */
+} RenetStepRun;
+size_t renet_step_workspace(const RenetStepModel* m, const RenetStepBatch* b);
+int renet_step_forward(const RenetStepModel* m, const RenetStepBatch* b, const RenetStepRun* r, float* row_loss,
+                       int* n_launches);
+int renet_step_backward(const RenetStepModel* m, const RenetStepBatch* b, const RenetStepRun* r, const float* g,
+                        int defer_side, void* ev_head_done, int* n_launches);
+/* x[0..n) += y[0..n) (the two heads' gradients wrt the same gathered rows ent[s], model.py:89,98, before ONE scatter-add) */
+int renet_add_inplace(float* x, const float* y, size_t n, void* stream);
+/* x[0..n) = 0 as an ordinary kernel launch (the zero-initialised scatter-add targets of the backward pass: hipMemsetAsync goes
+ * through the runtime's blit path, whose packets do not pipeline with the neighbouring kernel dispatches) */
+int renet_zero(float* x, size_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HOST-side batch-graph builder passes (no device work; pointers are HOST arrays): the native form of
  * graph.build_batch's heavy middle, replacing the reference's per-batch DGL subgraph/batch calls
  * (utils.py:115-131,158-170,236-241).  See csrc/host_builder.cpp for the contracts. */

@@ -191,12 +191,22 @@ def rgcn_layer(h, src, dst, etype, norm, weight, loop_weight, relu, dropout_mask
     return torch.relu(out) if relu else out                             # RGCN.py:47-48
 
 
-def rgcn_two_layers(params, prefix, h0, bg_src, bg_dst, etype, norm):
-    """Aggregator.py:119-122,136-137: rgcn1 (ReLU) then rgcn2 (identity), both with self loop."""
+def _drop_mask(shape, dropout, dtype):
+    """nn.Dropout's multiplicative mask (train mode) for a tensor of `shape`, or None in eval mode (dropout == 0)."""
+    if not dropout:
+        return None
+    return torch.nn.functional.dropout(torch.ones(shape, dtype=dtype), p=float(dropout), training=True)
+
+
+def rgcn_two_layers(params, prefix, h0, bg_src, bg_dst, etype, norm, dropout=0.0):
+    """Aggregator.py:119-122,136-137: rgcn1 (ReLU) then rgcn2 (identity), both with self loop.  dropout > 0: the train-mode
+    masks of RGCN.py:36-37 on the two self-loop messages (torch's generator: statistical, not bit, parity with a device)."""
+    m1 = _drop_mask(h0.shape, dropout, h0.dtype)
     h1 = rgcn_layer(h0, bg_src, bg_dst, etype, norm, params[prefix + 'rgcn1.weight'],
-                    params[prefix + 'rgcn1.loop_weight'], relu=True)
+                    params[prefix + 'rgcn1.loop_weight'], relu=True, dropout_mask=m1)
+    m2 = _drop_mask(h0.shape, dropout, h0.dtype)
     return rgcn_layer(h1, bg_src, bg_dst, etype, norm, params[prefix + 'rgcn2.weight'],
-                      params[prefix + 'rgcn2.loop_weight'], relu=False)
+                      params[prefix + 'rgcn2.loop_weight'], relu=False, dropout_mask=m2)
 
 
 # --------------------------------------------------------------------------------------------
@@ -261,9 +271,10 @@ class StageTimer(object):
 
 
 def aggregator_sequences(params, hist, hist_t, s, r, rel_embeds, graph_dict, global_emb, reverse,
-                         seq_len, sort=True, timer=None):
-    """Returns (bg, h2, X[B_nz, L, 4D], Xr[B_nz, L, 3D]) in eval mode (no dropout) -- the padded
-    tensors of Aggregator.py:144-155 before packing.  global_emb: dict t -> tensor[..., D]."""
+                         seq_len, sort=True, timer=None, dropout=0.0):
+    """Returns (bg, h2, X[B_nz, L, 4D], Xr[B_nz, L, 3D]) -- the padded tensors of Aggregator.py:144-155 before packing; in
+    eval mode by default, with dropout > 0 in train mode (RGCN.py:36-37 and Aggregator.py:157-158).  global_emb: dict
+    t -> tensor[..., D]."""
     if timer is not None:
         timer.reset()
     bg = batch_for_histories(hist, hist_t, s, graph_dict, sort=sort)
@@ -273,7 +284,7 @@ def aggregator_sequences(params, hist, hist_t, s, r, rel_embeds, graph_dict, glo
     d = ent.shape[1]
     h0 = ent[torch.as_tensor(bg.ent)]                                   # utils.py:239
     etype = bg.type_o if reverse else bg.type_s                         # RGCN.py:80-85
-    h2 = rgcn_two_layers(params, 'aggregator.', h0, bg.src, bg.dst, etype, bg.norm)
+    h2 = rgcn_two_layers(params, 'aggregator.', h0, bg.src, bg.dst, etype, bg.norm, dropout=dropout)
     if timer is not None:
         timer.mark('rgcn_x2')
     rows = h2[torch.as_tensor(bg.subj_row)]                             # Aggregator.py:139-140
@@ -298,14 +309,19 @@ def aggregator_sequences(params, hist, hist_t, s, r, rel_embeds, graph_dict, glo
         pos += li
     if nnz:
         x, xr = torch.stack(xs), torch.stack(xrs)
+    if dropout:                                                         # Aggregator.py:157-158 (train mode)
+        x = torch.nn.functional.dropout(x, p=float(dropout), training=True)
+        xr = torch.nn.functional.dropout(xr, p=float(dropout), training=True)
     if timer is not None:
         timer.mark('sequence_assembly')
     return bg, h2, x, xr
 
 
 def renet_forward_loss(params, triplets, hist, hist_t, graph_dict, global_emb, num_rels, seq_len,
-                       subject=True, return_parts=False, timer=None):
-    """model.py:64-104 in eval mode (dropout = identity).  triplets: int array [B, >=3] (s, r, o)."""
+                       subject=True, return_parts=False, timer=None, dropout=0.0):
+    """model.py:64-104; eval mode (dropout = identity) by default, train mode with dropout > 0 (the five nn.Dropout sites:
+    RGCN.py:36-37 x2, Aggregator.py:157-158, model.py:90, model.py:99 -- torch's generator).  triplets: int array
+    [B, >=3] (s, r, o)."""
     triplets = np.asarray(triplets, dtype=np.int64)
     if subject:                                                         # model.py:65-71
         rel_embeds = params['rel_embeds'][:num_rels]
@@ -319,7 +335,7 @@ def renet_forward_loss(params, triplets, hist, hist_t, graph_dict, global_emb, n
     d = ent.shape[1]
     b = len(s)
     bg, h2, x, xr = aggregator_sequences(params, hist, hist_t, s, r, rel_embeds, graph_dict,
-                                         global_emb, reverse, seq_len, sort=True, timer=timer)
+                                         global_emb, reverse, seq_len, sort=True, timer=timer, dropout=dropout)
     nnz = len(bg.lens)
     pad = torch.zeros(b - nnz, d, dtype=ent.dtype)                      # model.py:88
     s_h = gru_last_state(x, bg.lens, params['encoder.weight_ih_l0'], params['encoder.weight_hh_l0'],
@@ -330,6 +346,8 @@ def renet_forward_loss(params, triplets, hist, hist_t, graph_dict, global_emb, n
     sp = torch.as_tensor(s[bg.perm])
     rp = torch.as_tensor(r[bg.perm])
     feat = torch.cat((ent[sp], s_h, rel_embeds[rp]), dim=1)             # model.py:89-90
+    if dropout:
+        feat = torch.nn.functional.dropout(feat, p=float(dropout), training=True)       # model.py:90 (train mode)
     ob_pred = feat @ params['linear.weight'].t() + params['linear.bias']
     loss_sub = cross_entropy_mean(ob_pred, o[bg.perm])                  # model.py:91
     if timer is not None:
@@ -340,6 +358,8 @@ def renet_forward_loss(params, triplets, hist, hist_t, graph_dict, global_emb, n
     if timer is not None:
         timer.mark('gru')
     feat_r = torch.cat((ent[sp], s_q), dim=1)                           # model.py:98-99
+    if dropout:
+        feat_r = torch.nn.functional.dropout(feat_r, p=float(dropout), training=True)   # model.py:99 (train mode)
     ob_pred_r = feat_r @ params['linear_r.weight'].t() + params['linear_r.bias']
     loss_r = cross_entropy_mean(ob_pred_r, r[bg.perm])                  # model.py:100
     loss = loss_sub + 0.1 * loss_r                                      # model.py:103

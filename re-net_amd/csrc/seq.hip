@@ -541,6 +541,18 @@ __global__ __launch_bounds__(256) void softmax_ce_planes_generic_kernel(const fl
     }
 }
 
+__global__ __launch_bounds__(256) void zero_kernel(float4* __restrict__ x, size_t n4, float* __restrict__ xt, int tail) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) x[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) xt[threadIdx.x] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(float4* __restrict__ x, const float4* __restrict__ y, size_t n4,
+                                                          float* __restrict__ xt, const float* __restrict__ yt, int tail) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) x[i] = f4_add(x[i], y[i]);
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) xt[threadIdx.x] += yt[threadIdx.x];
+}
+
 // ---- dgl.max_nodes / mean_nodes (Aggregator.py:58-61) ------------------------------------------
 __global__ __launch_bounds__(256) void segment_pool_fwd_kernel(const float* __restrict__ h,
                                                                const int32_t* __restrict__ seg_ptr, int D,
@@ -830,6 +842,27 @@ int renet_softmax_ce_planes(const float* logits, const int32_t* target, int B, i
         RENET_LAUNCH(softmax_ce_planes_generic_kernel, dim3(B), dim3(256), 0, st, logits, target, C, ld, grad_scale,
                      row_loss, P, plane, ld16);
     }
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_zero(float* x, size_t n, void* stream) {
+    if (n == 0) return RENET_OK;
+    if (!x || (reinterpret_cast<uintptr_t>(x) & 15)) return RENET_ERR_BADARG;
+    const size_t n4 = n / 4;
+    const int blocks = (int)max((size_t)1, min((size_t)2048, (n4 + 255) / 256));
+    RENET_LAUNCH(zero_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)x, n4, x + n4 * 4, (int)(n & 3));
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_add_inplace(float* x, const float* y, size_t n, void* stream) {
+    if (n == 0) return RENET_OK;
+    if (!x || !y || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15)) return RENET_ERR_BADARG;
+    const size_t n4 = n / 4;
+    const int blocks = (int)max((size_t)1, min((size_t)2048, (n4 + 255) / 256));
+    RENET_LAUNCH(add_inplace_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)x, (const float4*)y, n4,
+                 x + n4 * 4, y + n4 * 4, (int)(n & 3));
     RENET_LAUNCH_CHECK();
     return RENET_OK;
 }

@@ -274,6 +274,10 @@ class RENet(nn.Module):
         with M (or K) doubled.  Each CE is a mean over its B rows: the sum of the two is 2 x the mean over 2B."""
         g = prep.g
         self.aggregator.last_batch = g
+        # the same launch sequence issued from C (csrc/step.cpp): two C-ABI calls per step instead of ~55; bit-identical
+        import step_plan
+        if DUAL_HEAD and step_plan.eligible(self, prep):
+            return step_plan.StepFn.apply(self, prep, row_tap, *step_plan.model_params(self))
         # a shard of a batch whose graph every rank replicates (prepare_both(shard=...)): rank-independent dropout
         # masks at the graph-side sites, so that the N-rank step equals the 1-rank step
         with ops.shared_graph_seeds(getattr(prep, 'sharded', False) or ops.SHARED_GRAPH_SEEDS):
@@ -449,7 +453,7 @@ class RENet(nn.Module):
 class PreparedBatch(object):
     """Device-resident inputs of one direction of one step (see RENet.prepare)."""
     __slots__ = ('g', 'subject', 'b', 'perm', 's_idx', 'r_idx', 'o_idx', 'plan_s', 'plan_r', 'batch_sizes',
-                 'step_off', 'r_label', 'share', 'sharded')
+                 'step_off', 'r_label', 'share', 'sharded', '_step_batch')
 
 
 def _device_plan(idx, device):

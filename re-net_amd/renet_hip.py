@@ -92,6 +92,11 @@ _SIGNATURES = {
                                   c_void_p, c_size_t, c_void_p]),
     'renet_softmax_ce_planes': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_size_t,
                                         c_int, c_int, c_void_p]),
+    'renet_step_workspace': (c_size_t, [c_void_p, c_void_p]),
+    'renet_step_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'renet_step_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'renet_add_inplace': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'renet_zero': (c_int, [c_void_p, c_size_t, c_void_p]),
     'renet_colsum_workspace': (c_size_t, [c_int, c_int]),
     'renet_colsum': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     'renet_scale_by_device_scalar': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),

@@ -72,3 +72,30 @@ def test_oversized_optional_blocks_are_dropped_not_truncated():
     assert len(text) < 4096 and line['dropped'] >= 1 and 'other_configs' not in line
     for k in CONTRACT:
         assert k in line
+
+
+def test_oversized_mandatory_fields_are_shortened_and_a_plain_record_still_gives_a_line():
+    """the line must come out even when the MANDATORY part alone is too long (free-text fields are shortened, never
+    an AssertionError after the whole benchmark has run), and for a --plain record (no kernel table, no roofline, no CPU
+    baseline, no parity)."""
+    import bench
+    out = copy.deepcopy(_full(RECORDED[0]))
+    out['config']['workload'] = 'w' * 6000
+    out['cpu_baseline'] = dict(out.get('cpu_baseline') or {'value': 1.0, 'unit': 'triples/s', 'cores': 1, 'kind': 'port'},
+                               sample='s' * 3000)
+    text = bench.compact_line(out, 'bench_detail.json')
+    line = json.loads(text)
+    assert len(text) < 4096 and line.get('truncated', 0) >= 1
+    for k in CONTRACT:
+        assert k in line
+    plain = copy.deepcopy(_full(RECORDED[0]))
+    plain.update({'roofline': None, 'cpu_baseline': None, 'parity': None, 'kernels': {}, 'gemm_shapes': [],
+                  'roofline_rgcn_gather': {}, 'roofline_gru': None, 'kernel_only': {'ms_per_step': 0.0, 'glue_ms_per_step': 0.0},
+                  'other_configs': None, 'value_f16x3': None, 'value_exact_f32': None, 'launches_per_step': None,
+                  'value_median': {'value': 3.7e5, 'ms_per_step': 2.76, 'steps': 100, 'p10_ms': 2.7, 'p90_ms': 2.8},
+                  'value_list_api': {'value': 2.2e5, 'ms_per_step': 4.6, 'steps': 30}, 'plan_entries_per_step': 61})
+    line = json.loads(bench.compact_line(plain, 'bench_detail.json'))
+    assert line['roofline'] is None and line['value_median']['steps'] == 100 and line['value_list_api']['steps'] == 30
+    assert line['plan_entries_per_step'] == 61
+    for k in CONTRACT:
+        assert k in line

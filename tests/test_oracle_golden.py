@@ -299,3 +299,23 @@ def test_oracle_global_model_matches_reference_at_pretrain_scale(name):
         sel = np.nonzero(idx // full.shape[1] == k)[0]
         assert len(sel)
         np.testing.assert_allclose(v[idx[sel] % full.shape[1]], samp[sel], rtol=2e-4, atol=2e-5)
+
+
+def test_oracle_train_mode_applies_the_five_dropout_sites():
+    """bench.py's cpu_baseline times the oracle in TRAIN mode (dropout at RGCN.py:36-37 x2, Aggregator.py:157-158,
+    model.py:90,99), as the GPU step it stands beside runs; dropout = 0 is the eval-mode path the golden vectors pin."""
+    import torch
+    from helpers import O, train_case
+    c = train_case('tiny', 200)
+    cfg = c['cfg']
+    params = {k: torch.from_numpy(v) for k, v in c['params'].items()}
+    ogd = O.build_graph_dict(c['train'], cfg['num_rels'])
+    ge = {t: torch.from_numpy(v) for t, v in c['global_emb'].items()}
+    args = (params, c['batch'], c['hists']['s'][0], c['hists']['s'][1], ogd, ge, cfg['num_rels'], c['seq_len'])
+    base = float(O.renet_forward_loss(*args, subject=True))
+    assert float(O.renet_forward_loss(*args, subject=True, dropout=0.0)) == base
+    torch.manual_seed(0)
+    a = float(O.renet_forward_loss(*args, subject=True, dropout=0.5))
+    torch.manual_seed(1)
+    b = float(O.renet_forward_loss(*args, subject=True, dropout=0.5))
+    assert a != base and a != b and all(x == x and abs(x) < 1e4 for x in (a, b))       # masks drawn, finite
