@@ -90,7 +90,7 @@ def compact_line(out, detail_path=None):
     if out.get('value_median'):
         optional.insert(0, ('value_median', _pick(out['value_median'], ('value', 'ms_per_step', 'steps', 'p10_ms', 'p90_ms'))))
     if out.get('value_list_api'):
-        optional.append(('value_list_api', _pick(out['value_list_api'], ('value', 'ms_per_step', 'steps'))))
+        optional.append(('value_list_api', _pick(out['value_list_api'], ('value', 'ms_per_step', 'ms_per_step_median', 'steps'))))
     for k in ('e2e_device_builder', 'host_enqueue_ms_per_step', 'plan_entries_per_step', 'launches_per_step', 'host_build_ms',
               'last_loss', 'rccl_ranks_seen', 'scaling_mode'):
         if out.get(k) is not None:
@@ -480,7 +480,7 @@ def main():
         model.train()
         model.fuse_directions = True
         optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
-        n_list = args.list_steps + 3
+        n_list = args.list_steps + 5
         batches = []
         for k in range(n_list):
             idx = parallel.shard_indices(perm, n_total + 5000 + k, 0, 1, args.batch)
@@ -489,10 +489,12 @@ def main():
             batches.append((quads[idx], s_hist, s_hist_t, o_hist, o_hist_t))
         loss_epoch = 0
         t0 = None
+        marks = []
         for k, (batch_data, s_hist, s_hist_t, o_hist, o_hist_t) in enumerate(batches):
-            if k == 3:
+            if k == 5:                                   # (5 warm-up steps: builder capacities, allocator, first-use uploads)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
+            marks.append(time.perf_counter())            # (every step ends in loss.item(): a host sync)
             batch_data = torch.from_numpy(batch_data).long()
             batch_data = batch_data.cuda()
             loss_s = model(batch_data, (s_hist, s_hist_t), (o_hist, o_hist_t), graph_dict, subject=True)
@@ -505,8 +507,12 @@ def main():
             loss_epoch += loss.item()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        marks.append(time.perf_counter())
+        per = sorted((b_ - a_) * 1e3 for a_, b_ in zip(marks[5:-1], marks[6:]))
         value_list_api = {'value': args.batch * args.list_steps / dt, 'unit': 'triples/s',
                           'ms_per_step': dt * 1e3 / args.list_steps, 'steps': args.list_steps,
+                          'ms_per_step_median': per[len(per) // 2], 'ms_per_step_max': per[-1],
+                          'c_launch_list': bool(step_plan_mod.ENABLED),
                           'what': "the reference's loop body (train.py:133-142) over this package's RENet: nested lists, "
                                   'two model() calls (fuse_directions on), loss.backward(), clip_grad_norm_, '
                                   'torch.optim.Adam, zero_grad, loss.item() -- end to end incl. list flattening, upload, '

@@ -9,8 +9,10 @@ path does with ops.INPLACE_GRADS), activations live in one workspace tensor that
 Every kernel receives exactly the arguments of the autograd path: losses and gradients are bit-identical
 (tests/test_gpu_step_plan.py).  Mirrors one iteration of the reference's train.py:136-139.
 
-Used when: default fp32-class mode (bf16x6), every parameter owns a contiguous .grad (parallel.FlatGrads / HipAdam, or
-zero_grad(set_to_none=False)), no kernel timer / debug tap, RENET_STEP_PLAN != 0.  Anything else takes the autograd path."""
+Used when: default fp32-class mode (bf16x6), no kernel timer / debug tap, RENET_STEP_PLAN != 0.  A parameter that owns a
+contiguous .grad (parallel.FlatGrads / HipAdam, zero_grad(set_to_none=False)) is accumulated into in place; for parameters
+without one (train.py's loop: torch's zero_grad() drops them) the gradients are materialised in one zeroed flat buffer and
+returned to autograd.  Anything else takes the autograd path."""
 import ctypes
 import os
 
@@ -98,9 +100,11 @@ def eligible(net, prep, row_tap=None):
     ptrs = _pointers(ps)
     ent = net.__dict__.get('_step_model')
     if ent is None or ent[0] != ptrs:
-        # first step, or a tensor was replaced: validate everything once for this set of pointers
-        if 0 in ptrs[1] or not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.requires_grad and
-                                   _grad_ok(p) for p in ps):
+        # first step, or a tensor was replaced: validate everything once for this set of pointers.  A parameter either owns
+        # a usable .grad buffer (accumulated into in place) or none at all (train.py's loop: torch's zero_grad() sets it to
+        # None -- its gradient is then materialised in backward and handed to autograd).
+        if not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.requires_grad and
+                   (p.grad is None or _grad_ok(p)) for p in ps):
             return False
         net.__dict__['_step_model'] = (ptrs, None)
     d = net.h_dim
@@ -117,7 +121,7 @@ def _model_struct(net, params, planes):
         m.D, m.num_ent, m.T, m.C2 = net.h_dim, net.ent_embeds.shape[0], net.rel_embeds.shape[0], net.linear_r.weight.shape[0]
         for n, pp, gp in zip(_PARAMS, ptrs[0], ptrs[1]):
             setattr(m, n, pp)
-            setattr(m, 'g_' + n, gp)
+            setattr(m, 'g_' + n, gp or None)
         net.__dict__['_step_model'] = (ptrs, m)
     m.drop_p = float(net.drop_p) if net.training else 0.0
     if planes is not None:
@@ -247,20 +251,31 @@ class StepFn(Function):
                                'the same graph is not supported')
         ctx.consumed = True
         params = model_params(ctx.net)
-        if not all(_grad_ok(p) for p in params):
-            raise RuntimeError('StepFn: a parameter lost its .grad buffer between forward and backward (zero_grad with '
-                               'set_to_none=True?); set RENET_STEP_PLAN=0 or keep the gradient buffers')
         m, b, r = ctx.m, ctx.b, ctx.r
-        gp = _pointers(params)[1]
-        for n, ptr in zip(_PARAMS, gp):                                   # (the buffers may have been replaced since forward)
-            setattr(m, 'g_' + n, ptr)
+        # gradient targets: the parameter's own .grad buffer (accumulated into, autograd gets None) or, where there is none,
+        # a slice of one freshly zeroed flat buffer that is returned to autograd (which then sets .grad)
+        missing = [i for i, p in enumerate(params) if not _grad_ok(p)]
+        fresh = [None] * len(params)
+        if missing:
+            if any(params[i].grad is not None for i in missing):
+                raise RuntimeError('StepFn: a parameter has an unusable .grad (non-contiguous / wrong dtype); set '
+                                   'RENET_STEP_PLAN=0')
+            offs, tot = [], 0
+            for i in missing:
+                offs.append(tot)
+                tot += (params[i].numel() + 3) & ~3
+            flat = torch.zeros(tot, device=params[0].device, dtype=torch.float32)
+            for i, o in zip(missing, offs):
+                fresh[i] = flat[o:o + params[i].numel()].view_as(params[i])
+        for i, (n, p) in enumerate(zip(_PARAMS, params)):
+            setattr(m, 'g_' + n, (fresh[i] if fresh[i] is not None else p.grad).data_ptr())
         dev = ctx.net.ent_embeds.device
         side = ctx.side
         r.stream = K._stream()
         r.side_stream = side.cuda_stream if side is not None else None
-        defer = bool(ops.DEFER_WEIGHT_GRADS and side is not None)
+        defer = bool(ops.DEFER_WEIGHT_GRADS and side is not None and not missing)
         lin_w, lin_b = params[14], params[15]
-        hooked = bool(ops._grad_done_hooks.get(id(lin_w)) or ops._grad_done_hooks.get(id(lin_b)))
+        hooked = bool(ops._grad_done_hooks.get(id(lin_w)) or ops._grad_done_hooks.get(id(lin_b))) and not missing
         ev = hs = None
         if hooked:
             ev, hs = _head_event(dev)
@@ -287,7 +302,7 @@ class StepFn(Function):
             # step -- measured: 3.6 ms of host time per step over 200 steps.)
             ops._deferred.append((torch.cuda.current_stream(dev), side, keep))
         ctx.ws = None
-        return (None, None, None) + (None,) * len(params)
+        return (None, None, None) + tuple(fresh)
 
 
 StepFn.last_launches = [0, 0]
