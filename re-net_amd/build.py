@@ -46,12 +46,16 @@ def build_listwalk(force=False, verbose=True):
         extra = ['-DRENET_LISTWALK_NUMPY', '-I' + numpy.get_include()]
     except Exception:
         pass
-    cmd = [os.environ.get('CC', 'gcc'), '-O2', '-shared', '-fPIC', '-I' + str(inc)] + extra + [WALK_SRC, '-o', WALK_LIB]
+    tmp = WALK_LIB + '.%d.tmp' % os.getpid()            # built beside the target, then renamed: concurrent builds stay atomic
+    cmd = [os.environ.get('CC', 'gcc'), '-O2', '-shared', '-fPIC', '-I' + str(inc)] + extra + [WALK_SRC, '-o', tmp]
     if verbose:
         print(' '.join(cmd), flush=True)
     try:
         subprocess.check_call(cmd)
+        os.replace(tmp, WALK_LIB)
     except (OSError, subprocess.CalledProcessError) as e:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         print('listwalk.c not built (%s): FlatHistory.from_lists uses its numpy formulation' % e, flush=True)
         return None
     return WALK_LIB

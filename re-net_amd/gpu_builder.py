@@ -133,15 +133,23 @@ _graph_stores = {}
 
 def graph_store_for(graph_dict, global_emb, num_ent, num_rels, device):
     """The resident GraphDeviceStore of (graph_dict, global_emb) on `device`; rebuilt when the graph store object changed
-    (graph.store_for re-creates it when the dict gained timestamps) or the global-embedding table grew."""
+    (graph.store_for re-creates it when the dict gained timestamps) or the global-embedding table's TIMESTAMPS changed (the
+    store holds their sorted list: the same count with different keys must not reuse it).  Entries die with their
+    graph_dict (weak reference), at most 8 stay resident."""
+    import weakref
     store = G.store_for(graph_dict)
     key = (id(graph_dict), str(device))
+    stamp = hash(tuple(sorted(int(t) for t in global_emb.keys())))
     ent = _graph_stores.get(key)
-    if ent is None or ent[0] is not store or ent[1] != len(global_emb):
+    if ent is None or ent[0] is not store or ent[1] != stamp:
         if len(_graph_stores) > 8:
             _graph_stores.clear()
-        ent = (store, len(global_emb), GraphDeviceStore(graph_dict, global_emb, num_ent, num_rels, device))
+        ent = (store, stamp, GraphDeviceStore(graph_dict, global_emb, num_ent, num_rels, device))
         _graph_stores[key] = ent
+        try:
+            weakref.finalize(graph_dict, _graph_stores.pop, key, None)
+        except TypeError:                    # (a plain dict cannot be weakly referenced: the size bound above applies)
+            pass
     return ent[2]
 
 

@@ -278,7 +278,7 @@ class FlatHistory(object):
             try:
                 lens, cnt, nbr_o, step_t = (np.frombuffer(b, dtype=np.int64) for b in _listwalk.flatten(hist, hist_t))
                 return cls(np.concatenate(([0], np.cumsum(lens))), step_t, np.concatenate(([0], np.cumsum(cnt))), nbr_o)
-            except (TypeError, ValueError, OverflowError):
+            except (TypeError, ValueError, OverflowError, BufferError):
                 pass
         lens = np.fromiter(map(len, hist), dtype=np.int64, count=len(hist))
         seq_ptr = np.concatenate(([0], np.cumsum(lens)))

@@ -138,6 +138,13 @@ class RENet(nn.Module):
         self.shadow_pick = None
         self._shadow = {}
 
+    def train(self, mode=True):
+        """nn.Module.train / eval; also drops a half-finished fused step (a subject=True call whose subject=False
+        partner never came -- an exception, an early exit -- must not leave its loss, histories and batch alive, nor make
+        the next training step raise)."""
+        self._fused_pending = None
+        return super().train(mode)
+
     def _reset_candidates(self):
         self.preds_list_s = defaultdict(lambda: torch.zeros(self.num_k))
         self.preds_ind_s = defaultdict(lambda: torch.zeros(self.num_k))
@@ -373,6 +380,8 @@ class RENet(nn.Module):
         """Training loss of one direction (model.py:64-104): CE over objects + 0.1 * CE over relations.
         triplets: int tensor [B, >=3]; s_hist / o_hist: (histories, timestamps) in the reference's nested
         list layout, or graph.FlatHistory objects."""
+        if not torch.is_grad_enabled():
+            self._fused_pending = None                 # (a no_grad forward between the two calls of a fused step: start over)
         if self.fuse_directions and self.training and torch.is_grad_enabled() and DUAL_HEAD:
             out = self._forward_fused(triplets, s_hist, o_hist, graph_dict, subject)
             if out is not None:
