@@ -411,14 +411,19 @@ def main():
     value = mode.global_batch * args.steps / elapsed
     # the same step measured two more ways (product configuration, same prepared batches): per-step HIP events over >= 100
     # steps whatever --steps says (median and spread), and the host's enqueue time over a 16-step window
-    per_step = mode.per_step_pass(prepared, max(100, args.steps) if not args.child else max(20, args.steps))
-    per_step_sorted = sorted(per_step)
-    ms_median = per_step_sorted[len(per_step_sorted) // 2]
-    median_block = {'value': mode.global_batch * 1e3 / ms_median, 'ms_per_step': ms_median, 'steps': len(per_step),
-                    'p10_ms': per_step_sorted[len(per_step_sorted) // 10], 'p90_ms': per_step_sorted[(len(per_step_sorted) * 9) // 10],
-                    'what': 'median of per-step HIP-event intervals (one event between consecutive steps, product '
-                            'configuration); `value` is the contract\'s K-step wall-clock window'}
-    host_enqueue_ms = mode.enqueue_pass(prepared)
+    median_block = host_enqueue_ms = None
+    if not args.plain:                       # (--plain: the W + K steps of `value` alone, for a profiler)
+        per_step = mode.per_step_pass(prepared, max(100, args.steps) if not args.child else max(20, args.steps))
+        per_step_sorted = sorted(per_step)
+        ms_median = per_step_sorted[len(per_step_sorted) // 2]
+        median_block = {'value': mode.global_batch * 1e3 / ms_median, 'ms_per_step': ms_median, 'steps': len(per_step),
+                        'p10_ms': per_step_sorted[len(per_step_sorted) // 10],
+                        'p90_ms': per_step_sorted[(len(per_step_sorted) * 9) // 10],
+                        'what': 'median of per-step HIP-event intervals (one event between consecutive steps, product '
+                                'configuration); `value` is the contract\'s K-step wall-clock window'}
+        host_enqueue_ms = mode.enqueue_pass(prepared)
+    elif os.environ.get('RENET_BENCH_PLAIN_ENQUEUE') == '1':
+        host_enqueue_ms = mode.enqueue_pass(prepared)
     import step_plan as step_plan_mod
     plan_entries = sum(step_plan_mod.StepFn.last_launches) if (step_plan_mod.ENABLED and sum(step_plan_mod.StepFn.last_launches)) else None
     # ... then the SAME K steps once more with HIP events around every C-ABI launch: the per-class kernel table, the

@@ -34,6 +34,7 @@ struct P6Args {
     const __bf16* B;
     size_t a_plane, b_plane;      // elements between consecutive planes of an operand
     int tca, tcb;                 // tiles per tile row (Cp / 16) of the stored matrices
+    int nbx, nby, nbz;            // output tiles in N, in M, k slices: the kernel is PERSISTENT over nbx * nby * nbz work items
     const float* alpha_dev;       // optional device scalar multiplied into alpha
     float* col_out;               // optional: logical column N - 1 is stored to col_out[row] (stride 1), columns < N - 1 to C
     SplitArgs out;                // M, N (logical columns incl. the col_out one), K, C, ldc, alpha, beta, bias, split-K fields
@@ -58,6 +59,26 @@ struct P6Cfg {
     static constexpr int PER = (NPIECE + NW - 1) / NW;        // 5 (waves 0-3; 4 for waves 4-7) / 6
     static constexpr bool UNEVEN = (NPIECE % NW) != 0;
 };
+
+// Work item L (the order in which a plain grid would have dispatched its workgroups: x fastest, then y, then z) -> tile.
+// The arithmetic of tile_of_block (gemm_split.hip) with the grid passed explicitly: the persistent kernel below walks
+// L = blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x a multiple of 8 whenever it is smaller than the item count, so a
+// workgroup stays on "its" XCD's eighth of the virtual tile sequence).
+__device__ __forceinline__ void p6_tile_of_index(int L, int nbx, int nby, int nbz, int xcd_order, int& bx, int& by, int& bz) {
+    const int nb = nbx * nby;
+    if (!xcd_order) { bz = L / nb; const int r = L - bz * nb; by = r / nbx; bx = r - by * nbx; return; }
+    const int total = nb * nbz, per = total >> 3;
+    const int v = L < 8 * per ? (L & 7) * per + (L >> 3) : L;
+    bz = v / nb;
+    const int t = v - bz * nb;
+    const int ns = min(nbx, nby), nl = max(nbx, nby);
+    const int w = min(ns, xcd_order);
+    const int p = t / (w * nl), r = t - p * (w * nl);
+    const int wp = min(w, ns - p * w);
+    const int l = r / wp, sh = p * w + (r - l * wp);
+    if (nby <= nbx) { bx = l; by = sh; }
+    else { by = l; bx = sh; }
+}
 
 __device__ __forceinline__ void p6_store_tile(const P6Args& pa, int m0, int n0, int z, int wm, int wn, int lane,
                                               const f32x16 (&acc)[2][2]) {
@@ -113,13 +134,10 @@ __global__ __launch_bounds__(P6Cfg<WM>::THREADS, 2) void gemm_p6_kernel(P6Args p
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bx, by, z;
-    tile_of_block(gridDim.x, gridDim.y, g.xcd_order, bx, by, z);
-    const int m0 = by * (64 * WM), n0 = bx * BN;
     const int hs_total = (g.K + 15) / 16;                 // half-stages of 16 k; k_tiles_per_split counts them and is EVEN
-    const int s0 = z * g.k_tiles_per_split;               //   (the parity of a k block is then the parity of its loop index)
-    const int s1 = min(hs_total, s0 + g.k_tiles_per_split);
-    const int nh = max(s1 - s0, 0);
+                                                          //   (the parity of a k block is then the parity of its loop index)
+    const int n_items = pa.nbx * pa.nby * pa.nbz;
+    int m0 = 0, n0 = 0, z = 0, s0 = 0, nh = 0;            // the tile being computed
 
     // ---- this wave's DMA pieces: id = wave + NW i < NPIECE; plane id / PP; inside a plane pieces 0 .. APIECES-1 = A (two
     // tiles each), then 4 of B.  (WM = 4: waves 0-3 issue 5 pieces per half-stage, waves 4-7 four; WM = 2: six each.)
@@ -127,21 +145,23 @@ __global__ __launch_bounds__(P6Cfg<WM>::THREADS, 2) void gemm_p6_kernel(P6Args p
     const __bf16* src[PER];
     size_t step[PER];
     int dst[PER];
+    auto setup_tile = [&]() {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int id = min(wave + Cfg::NW * i, Cfg::NPIECE - 1);
-        const int plane = id / Cfg::PP, idl = id % Cfg::PP;
-        const int opnd = idl >= Cfg::APIECES ? 1 : 0;
-        const int piece = opnd ? idl - Cfg::APIECES : idl;
-        const bool tr = opnd ? B_TR : A_TR;
-        const __bf16* base = opnd ? pa.B + (size_t)plane * pa.b_plane : pa.A + (size_t)plane * pa.a_plane;
-        const size_t tcn = (size_t)(opnd ? pa.tcb : pa.tca);
-        const size_t t0 = (size_t)((opnd ? n0 : m0) >> 4) + 2 * piece + (lane >> 5);    // tile along the operand's M / N index
-        const size_t tile = tr ? (size_t)s0 * tcn + t0 : t0 * tcn + (size_t)s0;
-        src[i] = base + tile * 256 + (lane & 31) * 8;
-        step[i] = tr ? tcn * 256 : (size_t)256;
-        dst[i] = plane * P6_PIMG + (opnd ? P6_AIMG : 0) + piece * 1024;
-    }
+        for (int i = 0; i < PER; ++i) {
+            const int id = min(wave + Cfg::NW * i, Cfg::NPIECE - 1);
+            const int plane = id / Cfg::PP, idl = id % Cfg::PP;
+            const int opnd = idl >= Cfg::APIECES ? 1 : 0;
+            const int piece = opnd ? idl - Cfg::APIECES : idl;
+            const bool tr = opnd ? B_TR : A_TR;
+            const __bf16* base = opnd ? pa.B + (size_t)plane * pa.b_plane : pa.A + (size_t)plane * pa.a_plane;
+            const size_t tcn = (size_t)(opnd ? pa.tcb : pa.tca);
+            const size_t t0 = (size_t)((opnd ? n0 : m0) >> 4) + 2 * piece + (lane >> 5);    // tile along the operand's M / N index
+            const size_t tile = tr ? (size_t)s0 * tcn + t0 : t0 * tcn + (size_t)s0;
+            src[i] = base + tile * 256 + (lane & 31) * 8;
+            step[i] = tr ? tcn * 256 : (size_t)256;
+            dst[i] = plane * P6_PIMG + (opnd ? P6_AIMG : 0) + piece * 1024;
+        }
+    };
     auto issue_piece = [&](char* base, auto ic) {
         constexpr int i = decltype(ic)::value;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
@@ -244,7 +264,9 @@ __global__ __launch_bounds__(P6Cfg<WM>::THREADS, 2) void gemm_p6_kernel(P6Args p
     // issued as a burst right behind the barrier, both partners sat in the vector-memory issue together and the matrix
     // pipe idled (tools/planes_bench.py: 4096^3 640 us with the burst against 534 us without any DMA).
     auto stage_body = [&](const P6Frags& Fcur, P6Frags& Fnext, int next_slot, auto parc, bool do_issue, char* dbase) {
+#ifndef RENET_P6_NOREAD               // (probe builds: MFMAs on whatever the registers hold -- no LDS fragment reads in the loop)
         read_frags(Fnext, next_slot, parc);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         static_for<0, 6>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
@@ -264,11 +286,34 @@ __global__ __launch_bounds__(P6Cfg<WM>::THREADS, 2) void gemm_p6_kernel(P6Args p
         });
     };
 
-    if (nh > 0) {
-        P6Frags F0, F1;
+    // PERSISTENT over the work items (round 6, v6): a workgroup stores a finished tile with asynchronous stores, zeroes its
+    // accumulators and immediately issues the DMA prologue of its next tile -- the stores drain and the prologue lands while
+    // the co-resident workgroup multiplies.  (One workgroup per tile paid ~16 us of launch + prologue + C-store per tile: 30 %
+    // of the logits GEMM, whose K = 600 is only 38 half-stages.)
+    P6Frags F0, F1;
+    bool have_tile = false;
+    int pm0 = 0, pn0 = 0, pz = 0;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        if (have_tile) {
+            p6_store_tile(pa, pm0, pn0, pz, wm, wn, lane, acc);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        int bx, by;
+        p6_tile_of_index(item, pa.nbx, pa.nby, pa.nbz, g.xcd_order, bx, by, z);
+        m0 = by * (64 * WM); n0 = bx * BN;
+        s0 = z * g.k_tiles_per_split;
+        nh = max(min(hs_total, s0 + g.k_tiles_per_split) - s0, 0);
+        have_tile = true; pm0 = m0; pn0 = n0; pz = z;
+        if (nh == 0) continue;
+        setup_tile();
         const int npre = min(nh, NS);
         for (int j = 0; j < npre; ++j) issue(j);
-        wait_left(max(npre - 2, 0));                                      // half-stages 0 and 1 landed
+        wait_left(max(npre - 2, 0));                                      // half-stages 0 and 1 landed (the stores are older)
         __builtin_amdgcn_s_barrier();
         read_frags(F0, 0, std::integral_constant<int, 0>{});
         __builtin_amdgcn_s_waitcnt(0xC07F);                               // lgkmcnt(0)
@@ -299,7 +344,7 @@ __global__ __launch_bounds__(P6Cfg<WM>::THREADS, 2) void gemm_p6_kernel(P6Args p
         }
         if (j < nh) iter(j, std::integral_constant<int, 0>{});
     }
-    p6_store_tile(pa, m0, n0, z, wm, wn, lane, acc);
+    if (have_tile) p6_store_tile(pa, pm0, pn0, pz, wm, wn, lane, acc);
 }
 
 // split-K reduction of the planes GEMM: C / col_out = alpha * sum_z partial[z] (+ bias) (+ beta * old)

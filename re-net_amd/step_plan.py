@@ -15,6 +15,7 @@ without one (train.py's loop: torch's zero_grad() drops them) the gradients are 
 returned to autograd.  Anything else takes the autograd path."""
 import ctypes
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -23,6 +24,17 @@ import ops
 import renet_hip as K
 
 ENABLED = os.environ.get('RENET_STEP_PLAN', '1') != '0'
+
+# per-model caches (the parameter tuple, the filled RenetStepModel) live HERE, keyed weakly by the module -- not in the
+# module's __dict__: a ctypes struct there would make copy.deepcopy(model) / torch.save(model) fail
+_cache = weakref.WeakKeyDictionary()
+
+
+def _slot(net):
+    c = _cache.get(net)
+    if c is None:
+        c = _cache[net] = {}
+    return c
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -65,15 +77,15 @@ class StepRunC(ctypes.Structure):
 def model_params(net):
     """The 18 parameters of a RENet in the order of RenetStepModel (cached on the module: nn.Module attribute lookups are
     a dozen microseconds per step otherwise; re-derived when a Parameter object was replaced)."""
-    c = net.__dict__.get('_step_params')
+    c = _slot(net).get('params')
     if c is not None and c[0] is net._parameters.get('ent_embeds') and c[14] is net.linear._parameters.get('weight'):
         return c
     a, e, er = net.aggregator, net.encoder, net.encoder_r
     c = (net.ent_embeds, net.rel_embeds, a.rgcn1.weight, a.rgcn1.loop_weight, a.rgcn2.weight, a.rgcn2.loop_weight,
          e.weight_ih_l0, e.weight_hh_l0, e.bias_ih_l0, e.bias_hh_l0, er.weight_ih_l0, er.weight_hh_l0, er.bias_ih_l0,
          er.bias_hh_l0, net.linear.weight, net.linear.bias, net.linear_r.weight, net.linear_r.bias)
-    net.__dict__['_step_params'] = c
-    net.__dict__.pop('_step_model', None)
+    _slot(net)['params'] = c
+    _slot(net).pop('model', None)
     return c
 
 
@@ -98,7 +110,7 @@ def eligible(net, prep, row_tap=None):
         return False
     ps = model_params(net)
     ptrs = _pointers(ps)
-    ent = net.__dict__.get('_step_model')
+    ent = _slot(net).get('model')
     if ent is None or ent[0] != ptrs:
         # first step, or a tensor was replaced: validate everything once for this set of pointers.  A parameter either owns
         # a usable .grad buffer (accumulated into in place) or none at all (train.py's loop: torch's zero_grad() sets it to
@@ -106,7 +118,7 @@ def eligible(net, prep, row_tap=None):
         if not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.requires_grad and
                    (p.grad is None or _grad_ok(p)) for p in ps):
             return False
-        net.__dict__['_step_model'] = (ptrs, None)
+        _slot(net)['model'] = (ptrs, None)
     d = net.h_dim
     return max(g.N, net.ent_embeds.shape[0]) * d * 4 < (1 << 31) and g.S > 0 and g.L > 0
 
@@ -114,7 +126,7 @@ def eligible(net, prep, row_tap=None):
 def _model_struct(net, params, planes):
     """RenetStepModel for the current pointers (the struct is kept while they do not change)."""
     ptrs = _pointers(params)
-    ent = net.__dict__.get('_step_model')
+    ent = _slot(net).get('model')
     m = ent[1] if (ent is not None and ent[0] == ptrs) else None
     if m is None:
         m = StepModelC()
@@ -122,7 +134,7 @@ def _model_struct(net, params, planes):
         for n, pp, gp in zip(_PARAMS, ptrs[0], ptrs[1]):
             setattr(m, n, pp)
             setattr(m, 'g_' + n, gp or None)
-        net.__dict__['_step_model'] = (ptrs, m)
+        _slot(net)['model'] = (ptrs, m)
     m.drop_p = float(net.drop_p) if net.training else 0.0
     if planes is not None:
         m.lin_w_planes, m.lin_w_plane, m.lin_w_ld = planes.p.data_ptr(), planes.plane, planes.p.shape[2]

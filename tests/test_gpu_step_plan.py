@@ -196,4 +196,7 @@ def test_c_launch_list_counts_its_launches_and_costs_less_host_time(dev):
     fwd, bwd = step_plan.StepFn.last_launches
     assert 15 <= fwd <= 40 and 25 <= bwd <= 60, (fwd, bwd)
     assert t_c < 0.5 * t_py, (t_c, t_py)
+    import copy
+    twin = copy.deepcopy(net)                       # (the launch list's caches must not live inside the module)
+    assert torch.equal(twin.ent_embeds, net.ent_embeds)
     opt.close()

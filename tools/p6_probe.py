@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 're-net_amd', 'csrc')
 OUT = os.path.join(ROOT, 'tools', '_trace')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-VARIANTS = {'nodma': ['-DRENET_P6_NODMA'], 'nomfma': ['-DRENET_P6_NOMFMA']}
+VARIANTS = {'nodma': ['-DRENET_P6_NODMA'], 'nomfma': ['-DRENET_P6_NOMFMA'],
+            'noread': ['-DRENET_P6_NODMA', '-DRENET_P6_NOREAD']}
 
 
 def build(extra=None):
