@@ -262,21 +262,10 @@ __device__ __forceinline__ float4 fix_item_h(float4 v, int rows, int K, int row0
 // registers -> three bf16 planes in LDS.  EDGE (workgroup-uniform: the tile touches the end of the matrix
 // in either dimension) enables the out-of-range fix-up of the clamped loads; interior tiles -- almost all of
 // them -- run the bare split: 6 v_cvt_pk_bf16_f32, 4 packed subtractions and 3 ds_write_b64 per item.
-// SWZ (round 6): the 64-byte-row image -- row stride 32 bf16, the four 16-byte chunks of a row XOR-swizzled by (row >> 2) & 3
-// (the image of the bf16-storage / planes kernels): fragment reads and K-contiguous stores are free of bank conflicts
-// (the 80-byte-row image pays 2-way conflicts on every store: SQ_LDS_BANK_CONFLICT = 1/3 of SQ_LDS_IDX_ACTIVE,
-// profiles/r06_a_planes_ablation.md) and a 128 x 128 tile needs 48 KB instead of 60: THREE workgroups per CU.
-constexpr int LDS_ROW_SWZ = 32;
-template <bool SWZ>
-__device__ __forceinline__ int lds_off(int row, int k) {
-    if constexpr (SWZ) return row * LDS_ROW_SWZ + ((((k >> 3) ^ (row >> 2)) & 3) << 3) + (k & 7);
-    else return row * LDS_ROW + k;
-}
-
-template <bool CONTIG_K, bool EDGE, int NT = 256, int ROWS = 128, int NI = 4, bool RAW = false, bool SWZ = false>
+template <bool CONTIG_K, bool EDGE, int NT = 256, int ROWS = 128, int NI = 4, bool RAW = false>
 __device__ __forceinline__ void store_items(__bf16* __restrict__ S, int rows, int K, int row0, int k0, int tid,
                                             const float4 (&r)[NI]) {
-    constexpr int PLANE = ROWS * (SWZ ? LDS_ROW_SWZ : LDS_ROW);
+    constexpr int PLANE = ROWS * LDS_ROW;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         int row, k;
@@ -287,7 +276,7 @@ __device__ __forceinline__ void store_items(__bf16* __restrict__ S, int rows, in
             else v = fix_item<CONTIG_K>(v, rows, K, row0, k0, row, k);
         }
         f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
-        __bf16* dst = S + lds_off<SWZ>(row, k);
+        __bf16* dst = S + row * LDS_ROW + k;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const bf16x2 blo = __builtin_convertvector(lo, bf16x2);        // v_cvt_pk_bf16_f32 (RNE)
@@ -352,22 +341,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 // sit in the load issue for ~1000-1500 cycles before their first MFMA (tools/gemm_trace.py).  Order pinned with
 // sched_barrier: slab-0 fragments, then 48 MFMAs with the slab-1 fragment reads behind the first 12 and one
 // load piece behind every fifth.
-// SWZ: arow / brow = row * 32 + ((lane >> 5) ^ swz(row)) * 8 (the lane's chunk of k slab 0); slab 1 is that offset ^ 16
-// elements (chunk index ^ 2); ksel is unused.
-template <int PLANE_A, int PLANE_B, int NPIECES, bool SWZ = false, class LoadFn>
+template <int PLANE_A, int PLANE_B, int NPIECES, class LoadFn>
 __device__ __forceinline__ void mfma_tile_ld(const __bf16* __restrict__ sA, const __bf16* __restrict__ sB, int arow,
                                              int brow, int ksel, f32x16 (&acc)[2][2], LoadFn&& load_piece) {
     bf16x8 F0[12], F1[12];                       // index = operand + 2 * t + 4 * plane
     auto read = [&](auto frc, bf16x8 (&F)[12], int slab) {
         constexpr int fr = frc.value, op = fr & 1, t = (fr >> 1) & 1, p = fr >> 2;
-        if constexpr (SWZ) {
-            const int row_off = (op ? brow : arow) ^ (slab << 4);
-            const __bf16* base = op ? sB + p * PLANE_B : sA + p * PLANE_A;
-            F[fr] = *reinterpret_cast<const bf16x8*>(base + t * 32 * LDS_ROW_SWZ + row_off);
-        } else {
-            const __bf16* base = op ? sB + p * PLANE_B + brow : sA + p * PLANE_A + arow;
-            F[fr] = *reinterpret_cast<const bf16x8*>(base + t * 32 * LDS_ROW + slab * 16 + ksel);
-        }
+        const __bf16* base = op ? sB + p * PLANE_B + brow : sA + p * PLANE_A + arow;
+        F[fr] = *reinterpret_cast<const bf16x8*>(base + t * 32 * LDS_ROW + slab * 16 + ksel);
     };
     // in the order the term pairs consume them (lgkmcnt retires LDS reads in order: the first MFMA waits for
     // two fragments, not twelve)
@@ -435,10 +416,11 @@ __device__ __forceinline__ void store_tile(const SplitArgs& g, int m0, int n0, i
 
 // RAW: operands addressed through raw buffer descriptors (TileLoaderH; both operands below 2^30 elements of reach, checked
 // on the host) -- the generic ItemLoader otherwise.
-template <bool TA, bool TB, bool RAW, int SWZV = 0>       // SWZV: 0 = 80-byte rows, 1 = swizzled image + 3 WGs / CU, 2 = swizzled, 2 WGs
-__global__ __launch_bounds__(THREADS, SWZV == 1 ? 3 : 2) void gemm_split_kernel(SplitArgs g) {
-    constexpr bool SWZ = SWZV != 0;
-    constexpr int PL = BM * (SWZ ? LDS_ROW_SWZ : LDS_ROW);
+// (Round 6 tried a 64-byte-row image with XOR-swizzled chunks here -- no LDS bank conflicts, 48 KB per tile: no change at two
+// workgroups per CU, 15-50 % SLOWER at three (168 registers: spills); profiles/r06_a_planes_ablation.md.  Not kept.)
+template <bool TA, bool TB, bool RAW>
+__global__ __launch_bounds__(THREADS) void gemm_split_kernel(SplitArgs g) {
+    constexpr int PL = BM * LDS_ROW;
     __shared__ __attribute__((aligned(16))) __bf16 sA[3 * PL];
     __shared__ __attribute__((aligned(16))) __bf16 sB[3 * PL];
     const int tid = threadIdx.x;
@@ -472,8 +454,7 @@ __global__ __launch_bounds__(THREADS, SWZV == 1 ? 3 : 2) void gemm_split_kernel(
     }
     const bool a_edge = m0 + BM > g.M, b_edge = n0 + BN > g.N;
     const int ra_ = wm * 64 + (lane & 31), rb_ = wn * 64 + (lane & 31);
-    const int arow = SWZ ? lds_off<true>(ra_, (lane >> 5) * 8) : ra_ * LDS_ROW;
-    const int brow = SWZ ? lds_off<true>(rb_, (lane >> 5) * 8) : rb_ * LDS_ROW;
+    const int arow = ra_ * LDS_ROW, brow = rb_ * LDS_ROW;
     const int ksel = (lane >> 5) * 8;
 
     TRACE_V(wave, TRACE_STEPS - 1, 0, __builtin_amdgcn_s_getreg((31 << 11) | 4));      // HW_ID
@@ -482,15 +463,15 @@ __global__ __launch_bounds__(THREADS, SWZV == 1 ? 3 : 2) void gemm_split_kernel(
         __syncthreads();                               // previous tile fully consumed
         TRACE_T(wave, kt - kt0, 0);
         const bool k_edge = (kt + 1) * BK > g.K;
-        if (a_edge || k_edge) store_items<A_CK, true, THREADS, BM, 4, RAW, SWZ>(sA, g.M, g.K, m0, kt * BK, tid, ra);
-        else store_items<A_CK, false, THREADS, BM, 4, RAW, SWZ>(sA, g.M, g.K, m0, kt * BK, tid, ra);
-        if (b_edge || k_edge) store_items<B_CK, true, THREADS, BN, 4, RAW, SWZ>(sB, g.N, g.K, n0, kt * BK, tid, rb);
-        else store_items<B_CK, false, THREADS, BN, 4, RAW, SWZ>(sB, g.N, g.K, n0, kt * BK, tid, rb);
+        if (a_edge || k_edge) store_items<A_CK, true, THREADS, BM, 4, RAW>(sA, g.M, g.K, m0, kt * BK, tid, ra);
+        else store_items<A_CK, false, THREADS, BM, 4, RAW>(sA, g.M, g.K, m0, kt * BK, tid, ra);
+        if (b_edge || k_edge) store_items<B_CK, true, THREADS, BN, 4, RAW>(sB, g.N, g.K, n0, kt * BK, tid, rb);
+        else store_items<B_CK, false, THREADS, BN, 4, RAW>(sB, g.N, g.K, n0, kt * BK, tid, rb);
         TRACE_T(wave, kt - kt0, 1);
         __syncthreads();
         TRACE_T(wave, kt - kt0, 2);
         const int k0n = min(kt + 1, kt1 - 1) * BK;     // next tile (the last step reloads its own: harmless)
-        mfma_tile_ld<PL, PL, 8, SWZ>(sA, sB, arow, brow, ksel, acc, [&](auto ic) {
+        mfma_tile_ld<PL, PL, 8>(sA, sB, arow, brow, ksel, acc, [&](auto ic) {
             constexpr int i = ic.value;
             if constexpr (i < 4) la.load_item(i, k0n, ra[i]);
             else lb.load_item(i - 4, k0n, rb[i - 4]);
@@ -559,7 +540,7 @@ __global__ __launch_bounds__(THREADS_T) void gemm_split_tall_kernel(SplitArgs g)
         else store_items<B_CK, false, THREADS_T, BN, NIB, RAW>(sB, g.N, g.K, n0, kt * BK, tid, rb);
         __syncthreads();
         const int k0n = min(kt + 1, kt1 - 1) * BK;     // next tile (the last step reloads its own: harmless)
-        mfma_tile_ld<PLANE_T, PLANE, NIA + NIB, false>(sA, sB, arow, brow, ksel, acc, [&](auto ic) {
+        mfma_tile_ld<PLANE_T, PLANE, NIA + NIB>(sA, sB, arow, brow, ksel, acc, [&](auto ic) {
             constexpr int i = ic.value;
             if constexpr (i < NIA) la.load_item(i, k0n, ra[i]);
             else lb.load_item(i - NIA, k0n, rb[i - NIA]);
@@ -1522,22 +1503,15 @@ static int gemm_split_launch(bool bf16_mode, int ta, int tb, int M, int N, int K
         else RENET_TALL_LAUNCH(false);
 #undef RENET_TALL_LAUNCH
     } else {
-#define RENET_SPLIT_LAUNCH(RAWV, SWZV)                                                                                    \
+#define RENET_SPLIT_LAUNCH(RAWV)                                                                                    \
         do {                                                                                                        \
-            if (!ta && !tb) RENET_LAUNCH((gemm_split_kernel<false, false, RAWV, SWZV>), grid, dim3(THREADS), 0, st, g);   \
-            else if (!ta && tb) RENET_LAUNCH((gemm_split_kernel<false, true, RAWV, SWZV>), grid, dim3(THREADS), 0, st, g); \
-            else if (ta && !tb) RENET_LAUNCH((gemm_split_kernel<true, false, RAWV, SWZV>), grid, dim3(THREADS), 0, st, g); \
-            else RENET_LAUNCH((gemm_split_kernel<true, true, RAWV, SWZV>), grid, dim3(THREADS), 0, st, g);                \
+            if (!ta && !tb) RENET_LAUNCH((gemm_split_kernel<false, false, RAWV>), grid, dim3(THREADS), 0, st, g);   \
+            else if (!ta && tb) RENET_LAUNCH((gemm_split_kernel<false, true, RAWV>), grid, dim3(THREADS), 0, st, g); \
+            else if (ta && !tb) RENET_LAUNCH((gemm_split_kernel<true, false, RAWV>), grid, dim3(THREADS), 0, st, g); \
+            else RENET_LAUNCH((gemm_split_kernel<true, true, RAWV>), grid, dim3(THREADS), 0, st, g);                \
         } while (0)
-        static int swz = -1;               // RENET_GEMM_SWZ=0: the 80-byte-row image (two workgroups per CU), for A/B runs
-        if (swz < 0) {
-            const char* e_ = getenv("RENET_GEMM_SWZ");
-            swz = e_ ? atoi(e_) : 1;
-        }
-        if (raw && swz == 1) RENET_SPLIT_LAUNCH(true, 1);
-        else if (raw && swz == 2) RENET_SPLIT_LAUNCH(true, 2);
-        else if (raw) RENET_SPLIT_LAUNCH(true, 0);
-        else RENET_SPLIT_LAUNCH(false, 0);
+        if (raw) RENET_SPLIT_LAUNCH(true);
+        else RENET_SPLIT_LAUNCH(false);
 #undef RENET_SPLIT_LAUNCH
     }
     if (e != RENET_OK) return e;
