@@ -21,6 +21,8 @@
 #include <cstdlib>
 #include <cstring>
 #include "common.h"
+#include <utility>
+#include <type_traits>
 
 namespace {
 
@@ -61,7 +63,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 constexpr int GT_BLOCKS = 32, GT_SLOTS = 8;
 __device__ unsigned long long* g_gru_trace = nullptr;      // [GT_BLOCKS][NW][MAXL][GT_SLOTS]
 __device__ __forceinline__ void gt_put(int wave, int step, int slot, unsigned long long v) {
-    if (g_gru_trace && blockIdx.y == 0 && blockIdx.x < GT_BLOCKS && (threadIdx.x & 63) == 0)
+    if (g_gru_trace && wave < NW && blockIdx.y == 0 && blockIdx.x < GT_BLOCKS && (threadIdx.x & 63) == 0)
         g_gru_trace[(((size_t)blockIdx.x * NW + wave) * MAXL + step) * GT_SLOTS + slot] = v;
 }
 #define GT_NOW() __builtin_amdgcn_s_memtime()
@@ -388,7 +390,9 @@ __global__ __launch_bounds__(WV * 64) void gru_fwd_bf_kernel(FwdProbsB ps, Layou
     float* Hs = smem;                                                    // [MT][LDH] h of the current step (fp32)
     float* Hn = smem + MT * C::LDH;                                      // [MT][LDH] h being produced
     __bf16* Hp = reinterpret_cast<__bf16*>(smem + 2 * MT * C::LDH);      // [NPL][MT][LDP] bf16 planes of Hs
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (the wave index through readfirstlane: everything derived from it -- unit block, fragment addresses -- is then
+    // known to be wave-uniform and lives in scalar registers)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i0 = blockIdx.x * MT;
     for (int t = tid; t < 2 * MT * C::LDH; t += NTW) Hs[t] = 0.f;      // h0 = 0
     for (int t = tid; t < NPL * MT * Bc::LDP / 2; t += NTW) reinterpret_cast<unsigned*>(Hp)[t] = 0u;   // and its planes
@@ -405,6 +409,47 @@ __global__ __launch_bounds__(WV * 64) void gru_fwd_bf_kernel(FwdProbsB ps, Layou
     // rotated (workgroups stay on the same unit block, whose chunks are then fetched into L2 once): rotating the
     // unit blocks as well measured 101.8 k instead of 91.8 k cycles per step
     const int rot_k = rot_id % Bc::KG, rot_u = H <= 200 ? (rot_id / Bc::KG) % C::NUB : 0;
+    // W_hh fragments through a register ring, PF chunks ahead of the MFMAs that consume them (left to itself the compiler
+    // re-uses four register quads and keeps 1-3 loads in flight: the loop then runs at one L2 latency per k group,
+    // 8.5 k cycles per unit block against 2 k of MFMA time).  A chunk = the NPL plane fragments of one (k group, gate).
+    // Round 6: the ring runs CONTINUOUSLY over the unit blocks and time steps of a wave -- the stream does not depend on
+    // h, so the first PF chunks of the wave's NEXT unit block (of the next time step after its last one) are requested
+    // during the last chunks of the current one and fly under the gate epilogue, the barriers and the plane split.  A
+    // unit block is VP = roundup(CH, RS) virtual chunks long (the surplus ones carry neither loads nor MFMAs), which
+    // keeps every ring slot index a compile-time constant.
+    // Ring depth: (PF_kgroups + 1) * 3 chunks with <= 8 waves (256 registers per wave); 5 chunks when the workgroup has
+    // one wave per unit block (13 waves at H = 200: 4 waves on a SIMD, 128 registers each).
+    constexpr int CH = Bc::KG * 3;                                      // chunks per unit block
+    constexpr int RS = (NPL == 3 && WV > 8) ? 5 : ((Bc::KG > 8 ? 2 : (Bc::KG > 3 ? 3 : Bc::KG - 1)) + 1) * 3;
+    constexpr int PF = RS - 1, VP = (CH + RS - 1) / RS * RS;
+    static_assert(PF <= CH, "ring deeper than a unit block");
+    bf16x8 wb[RS][NPL];                                                 // [slot][plane]
+    auto rotc = [&](int c) {                                            // chunk -> its position in the fragment stream
+        const int kg = c / 3 + rot_k;
+        return (kg >= Bc::KG ? kg - Bc::KG : kg) * 3 + c % 3;
+    };
+    // fragment order (split_frag_kernel): chunk = NPL consecutive 1 KB fragments.  Buffer loads: the descriptor and the
+    // chunk's byte offset are wave-uniform (scalar registers), the only address VGPR is lane * 16 -- with flat pointers
+    // every chunk in flight kept its own 64-bit address pair alive (74 spilled registers in the 13-wave kernel)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16x8*>(Wp), (short)0, (int)((size_t)C::NUB * CH * NPL * 1024), 0x00020000);
+    const int lane16 = lane * 16;
+    auto frag_base = [&](int ub0) {                                     // byte offset of a unit block's fragments
+        const int ub = ub0 + rot_u >= C::NUB ? ub0 + rot_u - C::NUB : ub0 + rot_u;
+        return ub * (CH * NPL * 1024);
+    };
+    auto frag = [&](int base, int c, int p) {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16 + p * 1024, base + rotc(c) * (NPL * 1024), 0);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    if (wave < C::NUB) {
+        const int wf0 = frag_base(wave);
+#pragma unroll
+        for (int q = 0; q < PF; ++q)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) wb[q][p] = frag(wf0, q, p);
+    }
 
     for (int j = 0; j < L; ++j) {
         const int p0 = so.off[j];
@@ -433,36 +478,39 @@ __global__ __launch_bounds__(WV * 64) void gru_fwd_bf_kernel(FwdProbsB ps, Layou
                 gr[reg] = gi[0]; gz[reg] = gi[H]; gn[reg] = gi[2 * H];
             }
             const float b_r = bhh[uc], b_z = bhh[H + uc], b_n = bhh[2 * H + uc];
-            constexpr int NF = 3 * NPL;                                 // fragments per (unit block, k group)
-            const bf16x8* wf = Wp + (size_t)ub * Bc::KG * NF * 64 + lane;       // fragment order (split_frag_kernel)
+            const int wf = frag_base(ub0);
+            const int wfn = frag_base(ub0 + WV < C::NUB ? ub0 + WV : wave);         // this wave's next unit block
             const __bf16* ha = Hp + ai * Bc::LDP + kq * 8;
-            // W_hh fragments through a register ring, PF k groups ahead of the MFMAs that consume them (left to
-            // itself the compiler re-uses four registers quads and keeps 1-3 loads in flight: the loop then runs at
-            // one L2 latency per k group, 8.5 k cycles per unit block against 2 k of MFMA time)
-            constexpr int PF = Bc::KG > 8 ? 2 : (Bc::KG > 3 ? 3 : Bc::KG - 1);
-            bf16x8 wb[PF + 1][3][NPL];                                  // [slot][gate][plane]
+            bf16x8 a[NPL];
 #pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                const int kq_ = q + rot_k >= Bc::KG ? q + rot_k - Bc::KG : q + rot_k;
+            for (int v = 0; v < VP; ++v) {
+                const int tq = v + PF;                                  // virtual chunk requested now
+#ifndef RENET_GRU_NOLOAD                                                // (ablation builds of tools/gru_trace.py)
+                if (tq < CH) {
 #pragma unroll
-                for (int f = 0; f < NF; ++f) wb[q][f / NPL][f % NPL] = wf[(kq_ * NF + f) * 64];
-            }
+                    for (int p = 0; p < NPL; ++p) wb[tq % RS][p] = frag(wf, tq, p);
+                } else if (tq >= VP) {
 #pragma unroll
-            for (int kg0 = 0; kg0 < Bc::KG; ++kg0) {
-                const int kg = kg0 + rot_k >= Bc::KG ? kg0 + rot_k - Bc::KG : kg0 + rot_k;
-                if (kg0 + PF < Bc::KG) {
-                    const int kn = kg0 + PF + rot_k >= Bc::KG ? kg0 + PF + rot_k - Bc::KG : kg0 + PF + rot_k;
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) wb[(kg0 + PF) % (PF + 1)][f / NPL][f % NPL] = wf[(kn * NF + f) * 64];
+                    for (int p = 0; p < NPL; ++p) wb[tq % RS][p] = frag(wfn, tq - VP, p);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                bf16x8 a[NPL];
+#endif
+                if (v < CH) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (v % 3 == 0) {
+                        const int kg = v / 3 + rot_k >= Bc::KG ? v / 3 + rot_k - Bc::KG : v / 3 + rot_k;
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) a[p] = *reinterpret_cast<const bf16x8*>(ha + p * MT * Bc::LDP + kg * 32);
-                ar = mfma_p<NPL>(a, wb[kg0 % (PF + 1)][0], ar);
-                az = mfma_p<NPL>(a, wb[kg0 % (PF + 1)][1], az);
-                an = mfma_p<NPL>(a, wb[kg0 % (PF + 1)][2], an);
-                __builtin_amdgcn_sched_barrier(0);
+                        for (int p = 0; p < NPL; ++p) a[p] = *reinterpret_cast<const bf16x8*>(ha + p * MT * Bc::LDP + kg * 32);
+                    }
+#ifdef RENET_GRU_NOMFMA
+                    f32x4& acc_ = v % 3 == 0 ? ar : (v % 3 == 1 ? az : an);
+                    acc_[0] += (float)a[0][v % 3] * (float)wb[v % RS][0][0] + (float)wb[v % RS][NPL - 1][7];
+#else
+                    if (v % 3 == 0) ar = mfma_p<NPL>(a, wb[v % RS], ar);
+                    else if (v % 3 == 1) az = mfma_p<NPL>(a, wb[v % RS], az);
+                    else an = mfma_p<NPL>(a, wb[v % RS], an);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             // C layout: column = lane & 15 (unit u), row = 4 * (lane >> 4) + reg (sequence)
 #ifdef RENET_GRU_TRACE
@@ -514,6 +562,202 @@ __global__ __launch_bounds__(WV * 64) void gru_fwd_bf_kernel(FwdProbsB ps, Layou
     }
 }
 
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for_n(F&& f) {                   // f(integral_constant<int, 0>) ... f(<N - 1>)
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 6: the bf16x6 forward recurrence as ONE continuous W_hh stream (H <= 200).
+//
+// What bounded gru_fwd_bf_kernel (tools/gru_trace.py + its NOLOAD / NOMFMA builds, profiles/r06_f_gru.md): a workgroup
+// pulls its 0.8 MB of W_hh planes through the CU's L1 at exactly the L1 fill rate (64 B/clk: 12.8 k cycles per step,
+// the same with 16 or with 256 workgroups on the chip -- it is not an L2 limit), but only while its waves are inside
+// their k loops; the gate epilogues, the two barriers and the plane split (another ~12 k cycles per step) ran with the
+// L1 idle, and with 13 unit blocks on 8 waves the step waited for the five waves that own two blocks.
+// Here (a) the work items are (unit block, gate) pairs -- 39 at H = 200, five per wave -- so every wave streams the
+// same number of bytes; the gate pre-activations are exchanged through LDS and the gate epilogue is one flat pass of
+// all 512 threads that also writes the next step's planes (the old copy + split pass); (b) the fragments go through
+// a 12-chunk register ring that never drains: a step's chunk list is the same at every step, so the ring simply
+// wraps -- the first 11 chunks of step t + 1 are requested during the last chunks of step t and fly under its
+// epilogue and barriers.  Per step: one k loop of 7 k groups x 5 items (5 independent accumulator chains per wave).
+// ---------------------------------------------------------------------------------------------
+template <int H>
+struct XCfg {
+    static constexpr int WV = 8;
+    static constexpr int NTW = WV * 64;
+    static constexpr int NIT = (3 * Cfg<H>::NUB + WV - 1) / WV;        // items per wave (5 at H = 200; the last wave: 4)
+    static constexpr int KG = BCfg<H>::KG;
+    static constexpr int CHW = KG * NIT;                                // chunks per wave and step
+    static constexpr int RS = 8, PF = RS - 1;                           // 7 chunks = 21 KB in flight per wave (7 or >= 9 slots: spills, and every spill reload drains vmcnt)
+    static constexpr int VPW = (CHW + RS - 1) / RS * RS;                // virtual chunks per step (ring period)
+    static constexpr int HP = Cfg<H>::NUB * 16;                         // padded units per gate in the exchange tile
+    static constexpr int LDG = 3 * HP + 4;                              // fp32 row stride of the exchange tile
+    static constexpr size_t lds_bytes() {
+        return ((size_t)MT * Cfg<H>::LDH + (size_t)MT * LDG + 3 * H) * sizeof(float) +
+               (size_t)3 * MT * BCfg<H>::LDP * sizeof(__bf16);
+    }
+};
+
+template <int H>
+__global__ __launch_bounds__(XCfg<H>::NTW) void gru_fwd_x_kernel(FwdProbsB ps, Layouts ly) {
+    using C = Cfg<H>;
+    using Bc = BCfg<H>;
+    using X = XCfg<H>;
+    constexpr int NPL = 3, NTW = X::NTW, NIT = X::NIT, RS = X::RS, PF = X::PF, CHW = X::CHW, VPW = X::VPW;
+    static_assert(PF <= CHW, "ring deeper than a step");
+    const int lay = ly.lay_of[blockIdx.y];
+    const StepOff& so = ly.so[lay];
+    const int L = ly.L[lay], out_rows = ly.rows[lay];
+    if ((int)blockIdx.x * MT >= out_rows) return;
+    const float* __restrict__ Gi = ps.p[blockIdx.y].Gi;
+    const bf16x8* __restrict__ Wp = ps.p[blockIdx.y].Wp;
+    const float* __restrict__ bhh = ps.p[blockIdx.y].bhh;
+    float* __restrict__ h_last = ps.p[blockIdx.y].h_last;
+    float* __restrict__ saved = ps.p[blockIdx.y].saved;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;                                                    // [MT][LDH]  h (fp32), updated in place
+    float* Gh = Hs + MT * C::LDH;                                        // [MT][LDG]  h W_hh^T of the step (r | z | n)
+    float* Bs = Gh + MT * X::LDG;                                        // [3H]       b_hh
+    __bf16* Hp = reinterpret_cast<__bf16*>(Bs + 3 * H);                  // [3][MT][LDP] bf16 planes of Hs
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i0 = blockIdx.x * MT;
+    for (int t = tid; t < MT * C::LDH; t += NTW) Hs[t] = 0.f;           // h0 = 0
+    for (int t = tid; t < 3 * H; t += NTW) Bs[t] = bhh[t];
+    for (int t = tid; t < NPL * MT * Bc::LDP / 2; t += NTW) reinterpret_cast<unsigned*>(Hp)[t] = 0u;
+    __syncthreads();
+    const int jj = lane & 15, kq = lane >> 4;
+    // workgroups that share an XCD's L2 start at different k groups / unit blocks of the same cyclic order (see
+    // gru_fwd_bf_kernel: L2 channel hot-spotting)
+    const int rot_id = (int)((blockIdx.x + gridDim.x * blockIdx.y) >> 3);
+    const int rot_k = rot_id % X::KG, rot_u = (rot_id / X::KG) % C::NUB;
+    // this wave's items: (unit block, gate) pairs wave, wave + 8, ...; item_off = byte offset of the item's first fragment,
+    // item_col = its first column in the exchange tile
+    int item_off[NIT], item_col[NIT];
+    bool item_on[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int id = wave + X::WV * it;
+        item_on[it] = id < 3 * C::NUB;
+        const int idc = item_on[it] ? id : 3 * C::NUB - 1;              // a surplus slot streams (and discards) a real item:
+        const int ub0 = idc / 3, g = idc % 3;                           // no branch inside the k loop
+        const int ub = ub0 + rot_u >= C::NUB ? ub0 + rot_u - C::NUB : ub0 + rot_u;
+        item_off[it] = ((ub * X::KG) * 3 + g) * (NPL * 1024);           // fragment order of split_frag_kernel
+        item_col[it] = g * X::HP + ub * 16;
+    }
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16x8*>(Wp), (short)0, (int)((size_t)C::NUB * X::KG * 3 * NPL * 1024), 0x00020000);
+    const int lane16 = lane * 16;
+    auto rotk = [&](int q) { return q + rot_k >= X::KG ? q + rot_k - X::KG : q + rot_k; };
+    bf16x8 wb[RS][NPL];
+    // chunk c of a step = (k group c / NIT in rotated order, item c % NIT)
+    auto request = [&](auto slot, int c) {
+        constexpr int S = decltype(slot)::value;
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        const int soff = item_off[c % NIT] + rotk(c / NIT) * (3 * NPL * 1024);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+            wb[S][p] = __builtin_bit_cast(bf16x8, (u32x4_)__builtin_amdgcn_raw_buffer_load_b128(wrs, lane16 + p * 1024, soff, 0));
+    };
+    {
+        auto pro = [&](auto q) { request(q, decltype(q)::value); };
+        static_for_n<PF>(pro);
+    }
+    constexpr int P1 = (MT * H + NTW - 1) / NTW;                        // (sequence, unit) pairs per thread in the epilogue
+
+    for (int j = 0; j < L; ++j) {
+        const int p0 = so.off[j];
+        const int bs = so.off[j + 1] - p0;
+        if (i0 >= bs) break;                                            // whole tile finished (sorted batch)
+        GT_PUT(wave, j, 0, GT_NOW());
+        // the input-gate pre-activations of this thread's epilogue pairs: requested before the matrix work (dead rows
+        // read the tile's last live row).  (Staging them in LDS by DMA instead cost a drained ring per step: the
+        // waitcnt pass orders the next LDS access behind vmcnt(0) whatever the DMA's destination object.)
+        float gir[P1], giz[P1], gin[P1];
+#pragma unroll
+        for (int q = 0; q < P1; ++q) {
+            const int e = min(tid + NTW * q, MT * H - 1);
+            const int i = e / H, u = e - i * H;
+            const float* gi = Gi + (size_t)(p0 + min(i0 + i, bs - 1)) * C::K3 + u;
+            gir[q] = gi[0]; giz[q] = gi[H]; gin[q] = gi[2 * H];
+        }
+        f32x4 acc[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) acc[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const __bf16* ha = Hp + jj * Bc::LDP + kq * 8;
+        bf16x8 a[NPL];
+        auto body = [&](auto vc) {
+            constexpr int v = decltype(vc)::value;
+            constexpr int tq = v + PF;                                  // virtual chunk requested now
+#ifndef RENET_GRU_NOLOAD
+            if constexpr (tq < CHW) request(std::integral_constant<int, tq % RS>{}, tq);
+            else if constexpr (tq >= VPW && tq - VPW < CHW) request(std::integral_constant<int, tq % RS>{}, tq - VPW);
+#endif
+            if constexpr (v < CHW) {
+                constexpr int it = v % NIT;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (it == 0) {
+                    const int kg = rotk(v / NIT);
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) a[p] = *reinterpret_cast<const bf16x8*>(ha + p * MT * Bc::LDP + kg * 32);
+                }
+#ifdef RENET_GRU_NOMFMA
+                acc[it][0] += (float)a[0][it] * (float)wb[v % RS][0][0] + (float)wb[v % RS][NPL - 1][7];
+#else
+                acc[it] = mfma6(a, wb[v % RS], acc[it]);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        static_for_n<VPW>(body);
+        GT_PUT(wave, j, 1, GT_NOW());
+        // C layout: column = lane & 15 (unit), row = 4 * (lane >> 4) + reg (sequence)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            if (item_on[it]) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Gh[(4 * kq + reg) * X::LDG + item_col[it] + jj] = acc[it][reg];
+            }
+        GT_PUT(wave, j, 3, GT_NOW());
+        __syncthreads();
+        GT_PUT(wave, j, 4, GT_NOW());
+#pragma unroll
+        for (int q = 0; q < P1; ++q) {
+            const int e = tid + NTW * q;
+            if (e < MT * H) {
+                const int i = e / H, u = e - i * H;
+                if (i0 + i < bs) {
+                    const float* gh = Gh + i * X::LDG + u;
+                    const float hp = Hs[i * C::LDH + u];
+                    const float hn = gh[2 * X::HP] + Bs[2 * H + u];
+                    const float r = sigmoidf_(gir[q] + gh[0] + Bs[u]);
+                    const float z = sigmoidf_(giz[q] + gh[X::HP] + Bs[H + u]);
+                    const float n = tanhf(gin[q] + r * hn);
+                    const float hv = (1.f - z) * n + z * hp;
+                    float* sv = saved + (size_t)(p0 + i0 + i) * 5 * H;
+                    sv[u] = r; sv[H + u] = z; sv[2 * H + u] = n; sv[3 * H + u] = hn; sv[4 * H + u] = hp;
+                    Hs[i * C::LDH + u] = hv;
+                    const Planes3 s = split3(hv);
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) Hp[p * MT * Bc::LDP + i * Bc::LDP + u] = s.p[p];
+                }
+            }
+            if (q % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // a few pairs at a time: the ring's registers stay live through this pass
+        }
+        GT_PUT(wave, j, 5, GT_NOW());
+        __syncthreads();
+        GT_PUT(wave, j, 6, GT_NOW());
+    }
+    for (int t = tid; t < MT * H; t += NTW) {                  // rows >= B were never touched: still h0 = 0
+        const int i = t / H, u = t - i * H;
+        if (i0 + i < out_rows) h_last[(size_t)(i0 + i) * H + u] = Hs[i * C::LDH + u];
+    }
+}
+
 // WTp: bf16 planes of W_hh^T (unit = hidden unit, k over the 3H gate columns) in fragment order (G = 1)
 // OUT16: dGi / dGh are written as bf16 (RNE) into matrices with row stride out_ld (elements): the operand format of
 // the bf16-storage GEMMs that consume them (dW_ih, dX, dW_hh); the recurrence itself keeps its fp32 values in LDS.
@@ -541,7 +785,7 @@ __global__ __launch_bounds__(WV * 64) void gru_bwd_bf_kernel(BwdProbsB ps, Layou
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* dHs = smem;                                                   // [MT][LDH] fp32
     __bf16* Gp = reinterpret_cast<__bf16*>(smem + MT * C::LDH);          // [3][MT][LDP3] planes of the dGh tile
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: scalar registers)
     const int i0 = blockIdx.x * MT;
     const int B = so.off[1] - so.off[0];
     for (int t = tid; t < MT * C::LDH; t += NTW) {
@@ -557,6 +801,33 @@ __global__ __launch_bounds__(WV * 64) void gru_bwd_bf_kernel(BwdProbsB ps, Layou
     const int rmod = ly.rot_mod > 0 ? min(ly.rot_mod, Bc::KG3) : (H > 200 ? 6 : Bc::KG3);
     const int rot_k = (rot_id % rmod) * (Bc::KG3 / rmod), rot_u = H <= 200 ? (rot_id / Bc::KG3) % C::NUB : 0;
     constexpr int PLG = MT * Bc::LDP3;
+    // W_hh^T fragments through a register ring, PFB k groups ahead; continuous over the unit blocks and time steps of a
+    // wave (see gru_fwd_bf_kernel): the first PFB k groups of the next unit block fly under phase 1 and the barriers
+    // (buffer loads: descriptor and chunk offset in scalar registers, one address VGPR -- see gru_fwd_bf_kernel; with one
+    // wave per unit block, 128 registers per wave, the ring is 4 k groups deep: the L2 -> L1 stream of a CU saturates
+    // at ~45 B/clk whatever the depth, profiles/r06_f_gru.md)
+    constexpr int PFB = Bc::KG3 > 5 ? (WV > 8 && NPL == 3 ? 3 : 5) : Bc::KG3 - 1, RB = PFB + 1, VPB = (Bc::KG3 + RB - 1) / RB * RB;
+    bf16x8 wb[RB][NPL];
+    auto rotk = [&](int q) { return q + rot_k >= Bc::KG3 ? q + rot_k - Bc::KG3 : q + rot_k; };
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16x8*>(WTp), (short)0, (int)((size_t)C::NUB * Bc::KG3 * NPL * 1024), 0x00020000);
+    const int lane16 = lane * 16;
+    auto frag_base = [&](int ub0) {                                     // byte offset of a unit block's fragments
+        const int ub = ub0 + rot_u >= C::NUB ? ub0 + rot_u - C::NUB : ub0 + rot_u;
+        return ub * (Bc::KG3 * NPL * 1024);
+    };
+    auto frag = [&](int base, int kgr, int p) {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16 + p * 1024, base + kgr * (NPL * 1024), 0);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    if (wave < C::NUB) {
+        const int wf0 = frag_base(wave);
+#pragma unroll
+        for (int q = 0; q < PFB; ++q)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) wb[q][p] = frag(wf0, rotk(q), p);
+    }
 
     for (int j = L - 1; j >= 0; --j) {
         const int p0 = so.off[j];
@@ -630,30 +901,27 @@ __global__ __launch_bounds__(WV * 64) void gru_bwd_bf_kernel(BwdProbsB ps, Layou
                     f32x4 acc;
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) acc[reg] = dHs[(4 * kq + reg) * C::LDH + (uok ? u : 0)];
-                    const bf16x8* wf = WTp + (size_t)ub * Bc::KG3 * NPL * 64 + lane;
+                    const int wf = frag_base(ub0);
+                    const int wfn = frag_base(ub0 + WV < C::NUB ? ub0 + WV : wave);
                     const __bf16* ga = Gp + ai * Bc::LDP3 + kq * 8;
                     f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};                  // two chains: no MFMA waits on the previous one
-                    // W_hh^T fragments through a register ring, PFB k groups ahead (see gru_fwd_bf_kernel)
-                    constexpr int PFB = 5, RB = PFB + 1;
-                    bf16x8 wb[RB][NPL];
-#pragma unroll
-                    for (int q = 0; q < PFB; ++q) {
-                        const int kq_ = q + rot_k >= Bc::KG3 ? q + rot_k - Bc::KG3 : q + rot_k;
-#pragma unroll
-                        for (int p = 0; p < NPL; ++p) wb[q][p] = wf[(kq_ * NPL + p) * 64];
-                    }
 #pragma unroll 1
-                    for (int base = 0; base < Bc::KG3; base += RB) {
+                    for (int base = 0; base < VPB; base += RB) {
 #pragma unroll
                         for (int r = 0; r < RB; ++r) {
                             const int kg0 = base + r;
-                            if (kg0 < Bc::KG3) {
-                                const int kg = kg0 + rot_k >= Bc::KG3 ? kg0 + rot_k - Bc::KG3 : kg0 + rot_k;
-                                if (kg0 + PFB < Bc::KG3) {
-                                    const int kn = kg0 + PFB + rot_k >= Bc::KG3 ? kg0 + PFB + rot_k - Bc::KG3 : kg0 + PFB + rot_k;
+                            const int tq = kg0 + PFB;                   // virtual k group requested now
+                            if (tq < Bc::KG3) {
+                                const int kn = rotk(tq);
 #pragma unroll
-                                    for (int p = 0; p < NPL; ++p) wb[(r + PFB) % RB][p] = wf[(kn * NPL + p) * 64];
-                                }
+                                for (int p = 0; p < NPL; ++p) wb[(r + PFB) % RB][p] = frag(wf, kn, p);
+                            } else if (tq >= VPB) {
+                                const int kn = rotk(tq - VPB);
+#pragma unroll
+                                for (int p = 0; p < NPL; ++p) wb[(r + PFB) % RB][p] = frag(wfn, kn, p);
+                            }
+                            if (kg0 < Bc::KG3) {
+                                const int kg = rotk(kg0);
                                 __builtin_amdgcn_sched_barrier(0);
                                 bf16x8 a[NPL];
 #pragma unroll
@@ -1038,10 +1306,38 @@ int launch_fwd(const FwdProbs& ps, int np, const Layouts& ly, hipStream_t st) {
 // where 16 waves spill 17-39 registers
 template <int H> constexpr int nw1() { return H > 200 ? 12 : 16; }
 
+// waves per workgroup of the bf16x6 forward recurrence: ONE wave per unit block where the blocks fit a workgroup (H = 200:
+// 13 waves) -- with 8 waves five of them own two blocks and the step waits for those (profiles/r06_f_gru.md)
+template <int H> constexpr int nw3() { return (Cfg<H>::NUB > 8 && Cfg<H>::NUB <= 16) ? Cfg<H>::NUB : NW; }
+
+template <int H>
+int launch_fwd_x(const FwdProbsB& ps, int np, const Layouts& ly, hipStream_t st) {
+    const size_t lds = XCfg<H>::lds_bytes();
+    static bool attr_set = false;
+    const int e = set_lds(gru_fwd_x_kernel<H>, lds, attr_set);
+    if (e != RENET_OK) return e;
+    RENET_LAUNCH((gru_fwd_x_kernel<H>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(XCfg<H>::NTW), lds, st, ps, ly);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+// RENET_GRU_FWD=ring selects the per-unit-block kernel (gru_fwd_bf_kernel) at H <= 200 as well, for A/B runs
+inline bool fwd_stream_kernel() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RENET_GRU_FWD");
+        v = (e && strcmp(e, "ring") == 0) ? 0 : 1;
+    }
+    return v == 1;
+}
+
 template <int H, int NPL = 3>
 int launch_fwd_bf(const FwdProbsB& ps, int np, const Layouts& ly, hipStream_t st) {
     using C = Cfg<H>;
-    constexpr int WV = NPL == 1 ? nw1<H>() : NW;
+    if constexpr (NPL == 3 && H <= 200) {
+        if (fwd_stream_kernel()) return launch_fwd_x<H>(ps, np, ly, st);
+    }
+    constexpr int WV = NPL == 1 ? nw1<H>() : nw3<H>();
     const size_t lds = (size_t)2 * MT * C::LDH * sizeof(float) + (size_t)3 * MT * BCfg<H>::LDP * sizeof(__bf16);
     static bool attr_set = false;
     const int e = set_lds(gru_fwd_bf_kernel<H, NPL, WV>, lds, attr_set);
@@ -1068,7 +1364,7 @@ int launch_bwd_bf(const BwdProbsB& ps, int np, const Layouts& ly, hipStream_t st
     using C = Cfg<H>;
     const size_t lds = (size_t)MT * C::LDH * sizeof(float) + (size_t)3 * MT * BCfg<H>::LDP3 * sizeof(__bf16);
     static bool attr_set = false;
-    constexpr int WV = NPL == 1 ? nw1<H>() : NW;
+    constexpr int WV = NPL == 1 ? nw1<H>() : nw3<H>();      // (H = 200: 13 waves, 118 -> 99 us per launch; profiles/r06_f_gru.md)
     const int e = set_lds(gru_bwd_bf_kernel<H, NPL, OUT16, WV>, lds, attr_set);
     if (e != RENET_OK) return e;
     RENET_LAUNCH((gru_bwd_bf_kernel<H, NPL, OUT16, WV>), dim3((max_rows(ly) + MT - 1) / MT, np), dim3(WV * 64), lds, st, ps, ly);

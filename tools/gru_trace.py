@@ -72,6 +72,11 @@ def run():
     print('H %d, 2 x %d sequences, L %d, S %d: launch %.1f us (traced)' % (H, B, L, S, e0.elapsed_time(e1) * 1e3))
     t = trace.cpu().numpy().reshape(BLOCKS, NW, MAXL, SLOTS).astype(np.int64)
     # workgroups 0..31 hold the 512 longest sequences: alive for all L steps
+    alive = [b for b in range(BLOCKS) if (t[b, :, L - 1, 0] > 0).all() and (b + 1) * 16 <= int(bs[L - 1])]
+    print('workgroups alive for all %d steps among the first %d: %d' % (L, BLOCKS, len(alive)))
+    t = t[alive]
+    span = (t[:, 0, L - 1, 6] - t[:, 0, 0, 0]).mean()
+    print('first stamp to last stamp: %.0f cycles = %.2f of the launch at 2.4 GHz' % (span, span / 2.4e3 / (e0.elapsed_time(e1) * 1e3)))
     st = t[:, :, 1:L - 1, :]
     step_len = (t[:, :, 2:L, 0] - t[:, :, 1:L - 1, 0])
     print('cycles per step (start to start)        %8.0f' % step_len.mean())
