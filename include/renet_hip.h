@@ -499,6 +499,17 @@ int renet_adam_step_scaled(float* p, float* g, float* m, float* v, size_t n, flo
                            int zero_grad, float* workspace, size_t workspace_bytes, float* grad_norm_out,
                            void* stream);
 
+/* The same step with the sum of squares ALREADY accumulated per region of the flat gradient (data-parallel runs: each
+ * all-reduce bucket's partials are computed on the reducer's stream as the bucket arrives, so that only this scalar combine
+ * is left of clip_grad_norm_, train.py:140, when the last bucket lands):
+ *   renet_sumsq_partials      : partial[0..n_slots) = per-workgroup sums of g[i]^2 over g[0..n) (fixed order: deterministic;
+ *                               slots without elements receive 0); g 16-byte aligned; n_slots <= 2048
+ *   renet_adam_step_presummed : renet_adam_step_scaled without its own norm pass: ||g||^2 = sum of partial[0..n_partial) */
+int renet_sumsq_partials(const float* g, size_t n, float* partial, int n_slots, void* stream);
+int renet_adam_step_presummed(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, float max_norm, float grad_scale, int step, int zero_grad,
+                              const float* partial, int n_partial, float* grad_norm_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Inference: the joint (relation, object) distribution of pred_r_rank2 and its top-k (model.py:205-209,239).
  *   renet_joint_softmax : logits [n * R, N] (row stride ld) is overwritten, row (e, r) with
@@ -587,7 +598,8 @@ int renet_build_batch_both(const RenetStoreDev* store, const int32_t* idx_dev, i
  *   renet_step_forward   : writes the 2 B per-row losses (entity head rows, then relation head rows) to row_loss
  *   renet_step_backward  : upstream scalar g (device); defer_side != 0 leaves the side stream UN-joined (the caller joins it
  *                          before it reads a parameter gradient: parallel.HipAdam.step); ev_head_done (optional hipEvent_t)
- *                          is recorded when the entity head's weight / bias gradients are complete (early all-reduce bucket)
+ *                          is recorded when the entity head's weight / bias gradients are complete (early all-reduce bucket),
+ *                          ev_gru_done (optional) when both encoders' parameter gradients are (the middle bucket)
  *   both return the number of C-ABI launches they issued in *n_launches (optional).
  * fp32-class default mode only (bf16x6 GEMMs, bf16x6 recurrences); tensors below 2 GiB. */
 typedef struct { const int32_t *order, *seg_ptr, *target; int num_segments; } RenetSegPlan;
@@ -632,7 +644,7 @@ size_t renet_step_workspace(const RenetStepModel* m, const RenetStepBatch* b);
 int renet_step_forward(const RenetStepModel* m, const RenetStepBatch* b, const RenetStepRun* r, float* row_loss,
                        int* n_launches);
 int renet_step_backward(const RenetStepModel* m, const RenetStepBatch* b, const RenetStepRun* r, const float* g,
-                        int defer_side, void* ev_head_done, int* n_launches);
+                        int defer_side, void* ev_head_done, void* ev_gru_done, int* n_launches);
 /* x[0..n) += y[0..n) (the two heads' gradients wrt the same gathered rows ent[s], model.py:89,98, before ONE scatter-add) */
 int renet_add_inplace(float* x, const float* y, size_t n, void* stream);
 /* x[0..n) = 0 as an ordinary kernel launch (the zero-initialised scatter-add targets of the backward pass: hipMemsetAsync goes

@@ -104,6 +104,45 @@ int renet_adam_step(float* p, float* g, float* m, float* v, size_t n, float lr, 
                                   workspace, workspace_bytes, grad_norm_out, stream);
 }
 
+int renet_sumsq_partials(const float* g, size_t n, float* partial, int n_slots, void* stream) {
+    if (!g || !partial || n_slots < 1 || n_slots > kBlocks) return RENET_ERR_BADARG;
+    if (reinterpret_cast<uintptr_t>(g) & 15) return RENET_ERR_BADARG;
+    const size_t n4 = n / 4;
+    // exactly n_slots workgroups: the ones without elements write 0 (every slot of the region is defined)
+    RENET_LAUNCH(sumsq_partial_kernel, dim3(n_slots), dim3(256), 0, (hipStream_t)stream, (const float4*)g, n4, g + n4 * 4,
+                       (int)(n & 3), partial);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+static int adam_launch(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float max_norm, float grad_scale, int step, int zero_grad, const float* partial,
+                       int n_partial, float* grad_norm_out, hipStream_t st) {
+    const size_t n4 = n / 4;
+    const int blocks = (int)max((size_t)1, min((size_t)kBlocks, (n4 + 255) / 256));
+    AdamCfg c;
+    c.lr = lr; c.beta1 = beta1; c.beta2 = beta2; c.eps = eps; c.wd = weight_decay; c.max_norm = max_norm;
+    c.bc1 = 1.f - powf(beta1, (float)step);
+    c.bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    c.zero_grad = zero_grad;
+    c.grad_scale = grad_scale;
+    RENET_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, partial, n_partial, c, grad_norm_out);
+    RENET_LAUNCH_CHECK();
+    return RENET_OK;
+}
+
+int renet_adam_step_presummed(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, float max_norm, float grad_scale, int step, int zero_grad,
+                              const float* partial, int n_partial, float* grad_norm_out, void* stream) {
+    if (step < 1 || lr < 0.f || beta1 < 0.f || beta1 >= 1.f || beta2 < 0.f || beta2 >= 1.f) return RENET_ERR_BADARG;
+    if (n == 0) return RENET_OK;
+    if (!partial || n_partial < 1 || n_partial > kBlocks) return RENET_ERR_BADARG;
+    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+         reinterpret_cast<uintptr_t>(v)) & 15) return RENET_ERR_BADARG;
+    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, step, zero_grad, partial,
+                       n_partial, grad_norm_out, (hipStream_t)stream);
+}
+
 int renet_adam_step_scaled(float* p, float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                            float eps, float weight_decay, float max_norm, float grad_scale, int step, int zero_grad,
                            float* workspace, size_t workspace_bytes, float* grad_norm_out, void* stream) {
@@ -118,16 +157,9 @@ int renet_adam_step_scaled(float* p, float* g, float* m, float* v, size_t n, flo
     RENET_LAUNCH(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)g, n4, g + n4 * 4,
                        (int)(n & 3), workspace);
     RENET_LAUNCH_CHECK();
-    AdamCfg c;
-    c.lr = lr; c.beta1 = beta1; c.beta2 = beta2; c.eps = eps; c.wd = weight_decay; c.max_norm = max_norm;
-    c.bc1 = 1.f - powf(beta1, (float)step);
-    c.bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
-    c.zero_grad = zero_grad;
-    c.grad_scale = grad_scale;
-    RENET_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, workspace, blocks, c,
-                       grad_norm_out);
-    RENET_LAUNCH_CHECK();
-    return RENET_OK;
+    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, max_norm, grad_scale, step, zero_grad, workspace,
+                       blocks, grad_norm_out, st);
 }
+
 
 }  // extern "C"

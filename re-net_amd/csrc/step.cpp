@@ -298,7 +298,7 @@ int renet_step_forward(const RenetStepModel* mp, const RenetStepBatch* bp, const
 }
 
 int renet_step_backward(const RenetStepModel* mp, const RenetStepBatch* bp, const RenetStepRun* r, const float* g,
-                        int defer_side, void* ev_head_done, int* n_launches) {
+                        int defer_side, void* ev_head_done, void* ev_gru_done, int* n_launches) {
     if (!args_ok(mp, bp) || !r || !r->workspace || !g) return RENET_ERR_BADARG;
     const RenetStepModel& m = *mp;
     const RenetStepBatch& b = *bp;
@@ -387,9 +387,14 @@ int renet_step_backward(const RenetStepModel* mp, const RenetStepBatch* bp, cons
         }
         return 0;
     };
+    auto gru_done = [&]() -> int {                     // both encoders' parameter gradients are complete (third all-reduce bucket)
+        if (!ev_gru_done) return 0;
+        return (int)hipEventRecord((hipEvent_t)ev_gru_done, s.side);
+    };
     if (!late_fork) {
         s.fork();
-        const int rc_ = gru_param_grads();
+        int rc_ = gru_param_grads();
+        if (!rc_) rc_ = gru_done();
         if (rc_) return rc_;
     }
     // dX: only the columns the sequence assembly reads (the trailing D columns are the constant global embedding)
@@ -397,7 +402,8 @@ int renet_step_backward(const RenetStepModel* mp, const RenetStepBatch* bp, cons
     CK(gemm(s.main, wsm, L.gemm_ws_bytes, 0, 0, S, 2 * D, 3 * D, F(L.dgi1), 3 * D, m.wih_r, 3 * D, 0.f, F(L.dXr), 3 * D, nullptr));
     if (late_fork) {
         s.fork();
-        const int rc_ = gru_param_grads();
+        int rc_ = gru_param_grads();
+        if (!rc_) rc_ = gru_done();
         if (rc_) return rc_;
     }
 

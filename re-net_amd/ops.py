@@ -582,6 +582,7 @@ class MultiGRUFn(Function):
             with sd():
                 for k in range(n):
                     param_grads(k, ops_[k])
+                _gru_grads_done(ctx)                                   # (on the side stream: the reducer orders behind it)
             live_ops = ops_ + (list(ctx.x_ops) if ctx.x_ops is not None else [])
             for t in list(d_gis) + list(d_ghs) + list(xs) + list(svs) + \
                     [getattr(o, 'part', None) for o in live_ops] + [getattr(o, 't', None) for o in live_ops]:
@@ -611,10 +612,22 @@ class MultiGRUFn(Function):
             if not on_side[k]:
                 res[k] = problem(k)
         sd.join()
+        if all_in_place:
+            _gru_grads_done(ctx)
         out = [None, None, None]
         for k in range(n):
             out += res[k]
         return tuple(out)
+
+
+def _gru_grads_done(ctx):
+    """MultiGRUFn.backward accumulated into every encoder parameter's .grad: tell whoever registered (the reducer's middle
+    bucket).  A parameter shared by two problems of one call (the subject / object pair) is reported once per problem."""
+    if not _grad_done_hooks:
+        return
+    for k in range(len(ctx.src_w)):
+        for t in list(ctx.src_w[k]) + list(ctx.src_b[k]):
+            grad_done(t)
 
 
 def dual_gru(x, xr, enc, enc_r, step_off, total_rows):

@@ -11,7 +11,10 @@ W = 8, a fifth of the step, so the exchange is cut into TWO large buckets (few, 
 per-link bound) and the first one overlaps the backward pass: the score head's parameters (linear.weight +
 bias: 55 of the 81 MB) receive their last gradient contribution when the second entity-head backward has run
 -- the FIRST thing the backward pass does -- so their all-reduce is launched on a side stream at that point
-(ops.register_grad_done_hook) and runs under the GRU / RGCN backward (~1.5 ms); the rest follows in step().
+(ops.register_grad_done_hook) and runs under the GRU / RGCN backward (~1.5 ms).  Round 6: a THIRD bucket, the two
+encoders' parameters (4.5 MB), leaves when the GRU parameter-gradient GEMMs are queued (under the sequence-assembly /
+RGCN backward); the rest follows in step(); each region's sum of squares is accumulated right behind its all-reduce on
+the reducer's stream, so that the clip of train.py:140 only waits for a scalar combine after the last bucket.
 No measured multi-GPU curve exists yet (one-GPU boxes only): the logic is covered by world-size-2 gloo tests.
 """
 import os
@@ -31,10 +34,15 @@ def flat_layout(params):
 
 
 def ordered_params(module, first=()):
-    """The trainable parameters of `module` in parameter order, those in `first` moved to the front (same relative order)."""
+    """The trainable parameters of `module` in parameter order, those in `first` moved to the front IN THE ORDER GIVEN."""
     ps = [p for p in module.parameters() if p.requires_grad]
-    ids = {id(p) for p in first}
-    return [p for p in ps if id(p) in ids] + [p for p in ps if id(p) not in ids]
+    own = {id(p) for p in ps}
+    front, seen = [], set()
+    for p in first:
+        if id(p) in own and id(p) not in seen:
+            front.append(p)
+            seen.add(id(p))
+    return front + [p for p in ps if id(p) not in seen]
 
 
 class FlatGrads(object):
@@ -86,47 +94,125 @@ class FlatGrads(object):
         return lo, hi - lo
 
 
+class _Bucket(object):
+    """One region of the flat gradient whose all-reduce is launched as soon as its last accumulation has been queued."""
+
+    def __init__(self, name, span, params, flat):
+        self.name = name
+        self.lo, self.n = span
+        self.ids = {id(p) for p in params}
+        self.uses_per_pass = len(self.ids)
+        self.expected = 0
+        self.count, self.work = 0, None
+        self.view = flat[self.lo:self.lo + self.n]
+
+
 class OverlapReducer(object):
-    """Two-bucket gradient all-reduce with the first bucket overlapped with the backward pass.
+    """Bucketed gradient all-reduce with the early buckets overlapped with the backward pass.
 
     early = the flat region of the parameters whose gradient is complete EARLY in the backward pass (RE-Net: the
-    entity score head, model.py:38, whose backward runs first).  A step DECLARES how many in-place accumulations
-    complete that bucket (`begin_step(head_passes)`: 2 for the subject + object passes, 1 for the merged pass);
-    on_grad_done(param) is called by the autograd Functions right after they accumulated into param.grad
-    (ops.grad_done_hooks); when the declared count is reached the bucket's all-reduce is issued asynchronously on a
-    side stream (device tensors) / as an async gloo op (CPU tensors) and proceeds while the rest of the backward
-    pass runs.  The tail regions (everything else: GRU / RGCN / embeddings, 26 MB at ICEWS18 sizes) are issued
-    asynchronously on the same side stream in finish(), i.e. right behind the last backward kernel, so that all
-    regions are in flight together; finish() then waits for all of them.  (The tail's gradients are only complete
-    when the LAST backward kernel has run -- ent_embeds receives contributions from the very last scatter-add --
-    so there is nothing left to overlap it with but the early bucket's own transfer.)
+    entity score head, model.py:38, whose backward runs first); mid (optional, round 6) = the two encoders' parameters
+    (model.py:28-29), complete when the GRU parameter-gradient GEMMs have run, i.e. before the sequence-assembly / RGCN
+    backward and the embedding scatter-adds.  A step DECLARES how many in-place accumulations complete a bucket
+    (`begin_step(head_passes)`: 2 for the subject + object passes, 1 for the merged pass); on_grad_done(param) is called
+    by the autograd Functions right after they accumulated into param.grad (ops.grad_done_hooks) -- on the stream that
+    holds the accumulating kernels -- and when a bucket's declared count is reached its all-reduce is issued
+    asynchronously on a side stream (device tensors) / as an async gloo op (CPU tensors) and proceeds while the rest of
+    the backward pass runs.  The tail regions (everything else: RGCN / embeddings / relation head) are issued in finish(),
+    i.e. right behind the last backward kernel; finish() then waits for all of them.  (The tail's gradients are only
+    complete when the LAST backward kernel has run -- ent_embeds receives contributions from the very last scatter-add.)
+
+    Per-region sums of squares (round 6): `sumsq_fn(k, region)` -- when given -- is called for region k of `regions()`
+    right behind that region's all-reduce, in stream order on the reducer's stream, so that by the time the last bucket
+    arrives only a scalar combine is left of clip_grad_norm_ (train.py:140); `partials_ready` tells the optimizer whether
+    every region of this step went through it.  CPU tensors: `bucket_sumsq[k]` holds the region's sum of squares.
 
     Safety: a backward pass outside a declared step (smoke / eval with grad, an exception between
-    backward and step, more accumulations than declared) never launches early -- the counter only runs between
-    begin_step() and finish(), hook calls after the launch raise, and finish() falls back to the synchronous
-    exchange whenever the early launch did not happen."""
+    backward and step, more accumulations than declared) never launches early -- the counters only run between
+    begin_step() and finish(), hook calls after a bucket's launch raise, and finish() falls back to the synchronous
+    exchange for whatever was not launched early."""
 
-    def __init__(self, flat_grads, early_span, early_params, early_uses=2, group=None):
+    def __init__(self, flat_grads, early_span, early_params, early_uses=2, group=None, mid_span=None, mid_params=(),
+                 sumsq_fn=None):
         self.fg, self.group = flat_grads, group
-        self.lo, self.n = early_span
-        self.early_ids = {id(p) for p in early_params}
-        self.uses_per_pass = len(self.early_ids)
-        self.early_uses = early_uses * self.uses_per_pass
-        self.count, self.work, self.armed = 0, None, False
-        self.average = True                       # False: SUM (ranks hold disjoint shares of one batch, bench --scaling exact)
         f = flat_grads.flat
-        self.early = f[self.lo:self.lo + self.n]
-        self.rest = [f[:self.lo], f[self.lo + self.n:]]
+        self.buckets = [_Bucket('early', early_span, early_params, f)]
+        if mid_span is not None and mid_span[1] > 0:
+            self.buckets.append(_Bucket('mid', mid_span, mid_params, f))
+        self.buckets.sort(key=lambda b: b.lo)
+        for x, y in zip(self.buckets, self.buckets[1:]):
+            if x.lo + x.n > y.lo:
+                raise ValueError('OverlapReducer: overlapping buckets')
+        # the tail regions: what lies between / around the timed buckets, in flat order
+        self.rest, pos = [], 0
+        for bk in self.buckets:
+            if bk.lo > pos:
+                self.rest.append((pos, bk.lo - pos))
+            pos = bk.lo + bk.n
+        if pos < f.numel():
+            self.rest.append((pos, f.numel() - pos))
+        self.armed = False
+        self.average = True                       # False: SUM (ranks hold disjoint shares of one batch, bench --scaling exact)
         self.stream = torch.cuda.Stream() if f.is_cuda else None
+        self.sumsq_fn = sumsq_fn
+        self.partials_ready = False
+        self.bucket_sumsq = {}
+        self._done_regions = set()
+        self.begin_uses(early_uses)
+
+    # ---- compatibility with the two-bucket reducer of rounds 2-5 (tests, tools) -------------------------------
+    @property
+    def early(self):
+        return self._bucket('early').view
+
+    @property
+    def work(self):
+        return self._bucket('early').work
+
+    @work.setter
+    def work(self, v):
+        self._bucket('early').work = v
+
+    @property
+    def count(self):
+        return self._bucket('early').count
+
+    @count.setter
+    def count(self, v):
+        for bk in self.buckets:
+            bk.count = v
+
+    @property
+    def early_uses(self):
+        return self._bucket('early').expected
+
+    def _bucket(self, name):
+        for bk in self.buckets:
+            if bk.name == name:
+                return bk
+        raise KeyError(name)
+
+    def regions(self):
+        """[(offset, length)] of every region the exchange handles, in flat order (timed buckets and tails)."""
+        return sorted([(bk.lo, bk.n) for bk in self.buckets] + list(self.rest))
+
+    def begin_uses(self, passes):
+        for bk in self.buckets:
+            bk.expected = int(passes) * bk.uses_per_pass
 
     def begin_step(self, head_passes=2, average=True):
-        """Arms the early launch for ONE step: `head_passes` backward passes of the early bucket's parameters will
+        """Arms the early launches for ONE step: `head_passes` backward passes of the timed buckets' parameters will
         run before finish().  Clears any state a previous, unfinished step left behind."""
-        if self.work is not None:                 # an abandoned step's collective: complete it before re-arming
-            self._wait_early()
-        self.early_uses = int(head_passes) * self.uses_per_pass
+        for bk in self.buckets:
+            if bk.work is not None:               # an abandoned step's collective: complete it before re-arming
+                self._wait(bk)
+        self.begin_uses(head_passes)
         self.average = bool(average)
-        self.count, self.work, self.armed = 0, None, True
+        for bk in self.buckets:
+            bk.count, bk.work = 0, None
+        self.armed = True
+        self.partials_ready = False
+        self._done_regions = set()
 
     def set_uses(self, n):
         """Deprecated spelling of begin_step(head_passes=n) (kept for callers of round 2)."""
@@ -146,54 +232,90 @@ class OverlapReducer(object):
                 return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def _wait_early(self):
-        self.work.wait()                          # device: makes the current stream wait for the side stream
+    def _after(self, work, lo, n):
+        """Orders the caller behind `work` and runs the region's sum of squares right behind it."""
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                work.wait()                       # (device: the reducer's stream waits for the collective, the host does not)
+                if self.sumsq_fn is not None:
+                    self.sumsq_fn(self.regions().index((lo, n)), self.fg.flat[lo:lo + n])
+                    self._done_regions.add((lo, n))
+            return
+        work.wait()
+        t = self.fg.flat[lo:lo + n]
+        self.bucket_sumsq[self.regions().index((lo, n))] = float((t.double() * t.double()).sum())
+        self._done_regions.add((lo, n))
+
+    def _wait(self, bk):
+        self._after(bk.work, bk.lo, bk.n)
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
-        self.work = None
+        bk.work = None
+
+    def _wait_early(self):                        # (round 2-5 name)
+        self._wait(self._bucket('early'))
 
     def on_grad_done(self, param):
-        if id(param) not in self.early_ids or not self.armed or not self.active():
+        if not self.armed:
             return
-        if self.work is not None:
+        pid = id(param)
+        for bk in self.buckets:
+            if pid in bk.ids:
+                break
+        else:
+            return
+        if not self.active():
+            return
+        if bk.work is not None:
             # the bucket is being reduced on the side stream: one more in-place accumulation into it would race
-            raise RuntimeError('OverlapReducer: a backward pass accumulated into the score head\'s gradient after its '
+            raise RuntimeError('OverlapReducer: a backward pass accumulated into the %s bucket\'s gradient after its '
                                'all-reduce was launched (begin_step(head_passes=%d) declared too few passes)'
-                               % (self.early_uses // max(self.uses_per_pass, 1)))
-        self.count += 1
-        if self.count == self.early_uses:
-            self.work = self._async(self.early)
+                               % (bk.name, bk.expected // max(bk.uses_per_pass, 1)))
+        bk.count += 1
+        if bk.count == bk.expected:
+            bk.work = self._async(bk.view)
 
     def finish(self, fold_scale=False):
         """Call after backward(): completes the exchange; the flat buffer then holds the rank-combined gradient:
         the SUM when `average` is False, else the mean -- divided in place here, or (fold_scale=True, HipAdam) left
         as the sum with `pending_scale` = 1 / world for the optimizer kernel to apply (no extra pass over 81 MB)."""
-        armed, self.armed = self.armed, False
+        self.armed = False
         self.pending_scale = 1.0
         if not self.active():
-            self.count, self.work = 0, None
+            for bk in self.buckets:
+                bk.count, bk.work = 0, None
             return
         world = dist.get_world_size(self.group)
-        if self.work is not None and self.count != self.early_uses:      # cannot happen (the hook raises); belt and braces
-            raise RuntimeError('OverlapReducer: early bucket launched after %d of %d accumulations'
-                               % (self.count, self.early_uses))
-        # tail bucket(s): asynchronously as well, so that the two regions' transfers are both in flight
-        tails = [self._async(t) for t in self.rest if t.numel()]
-        if self.work is None:                     # never launched early (undeclared step, empty batches, fewer passes)
-            tails.append(self._async(self.early))
-        else:
-            self._wait_early()
-        for w in tails:
-            w.wait()
+        for bk in self.buckets:
+            if bk.work is not None and bk.count != bk.expected:           # cannot happen (the hook raises); belt and braces
+                raise RuntimeError('OverlapReducer: %s bucket launched after %d of %d accumulations'
+                                   % (bk.name, bk.count, bk.expected))
+        # tail region(s): asynchronously as well, so that all regions' transfers are in flight together
+        f = self.fg.flat
+        late = [(self._async(f[lo:lo + n]), lo, n) for lo, n in self.rest if n]
+        for bk in self.buckets:
+            if bk.work is None:                   # never launched early (undeclared step, empty batches, fewer passes)
+                late.append((self._async(bk.view), bk.lo, bk.n))
+            else:
+                self._wait(bk)
+        for w, lo, n in late:
+            self._after(w, lo, n)
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
+        self.partials_ready = self._done_regions == set(r for r in self.regions() if r[1]) and \
+            (self.sumsq_fn is not None or self.stream is None)
         if self.average:
             if fold_scale:
                 self.pending_scale = 1.0 / world
             else:
                 self.fg.flat.div_(world)
-        self.count, self.work = 0, None
-        del armed
+                self.bucket_sumsq = {k: v / float(world) ** 2 for k, v in self.bucket_sumsq.items()}
+        for bk in self.buckets:
+            bk.count, bk.work = 0, None
+
+    def total_norm(self):
+        """sqrt of the summed per-region sums of squares of the last finished step (CPU tensors)."""
+        return float(sum(self.bucket_sumsq.values())) ** 0.5
 
 
 def shard_indices(perm, step, rank, world, batch_size):
@@ -271,11 +393,15 @@ class HipAdam(object):
         import renet_hip as K
         self.K = K
         self._module = module          # (its `gemm_mode` attribute is read at every step)
-        # the score head's parameters FIRST in both flat buffers: the early bucket is then [0, n) and everything else one
-        # contiguous tail -- two collectives per step instead of three (round 5; profiles/r05_i_one_rank_rccl_trace.md)
+        # the score head's parameters FIRST in both flat buffers, the two encoders' right behind them: the early bucket is
+        # [0, n), the middle bucket [n, n + m) and everything else ONE contiguous tail -- three collectives per step
+        names = dict((id(p), n) for n, p in module.named_parameters())
         head = [p for n, p in module.named_parameters() if n in ('linear.weight', 'linear.bias')]
-        self.params = FlatParams(module, first=head)
-        self.grads = FlatGrads(module, first=head)     # same layout (flat_layout) as the parameters
+        mid = [p for n, p in module.named_parameters() if n.startswith(('encoder.', 'encoder_r.'))] if head else []
+        if os.environ.get('RENET_REDUCER_BUCKETS', '3') == '2':         # (the two-bucket exchange of rounds 2-5, for A/B runs)
+            mid = []
+        self.params = FlatParams(module, first=head + mid)
+        self.grads = FlatGrads(module, first=head + mid)     # same layout (flat_layout) as the parameters
         self.m = torch.zeros_like(self.params.flat)
         self.v = torch.zeros_like(self.params.flat)
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
@@ -286,14 +412,22 @@ class HipAdam(object):
         # bf16-storage mode: the GEMM wrappers may cache bf16 copies of these weights between steps
         self._weights = [p for p in self.params.params if p.dim() == 2]
         K.register_weights(self._weights)
-        names = [n for n, _ in module.named_parameters()]
-        if 'linear.weight' in names and 'linear.bias' in names:       # RENet: overlap the score head's bucket
-            early = [p for n, p in module.named_parameters() if n in ('linear.weight', 'linear.bias')]
-            self.reducer = OverlapReducer(self.grads, self.grads.span(('linear.weight', 'linear.bias'), module), early)
+        if head:                                                      # RENet: overlap the score head's / the encoders' buckets
+            mid_names = tuple(names[id(p)] for p in mid)
+            self._part = torch.zeros(self.PART_SLOTS * 4, device=self.m.device, dtype=torch.float32)
+            self.reducer = OverlapReducer(self.grads, self.grads.span(('linear.weight', 'linear.bias'), module), head,
+                                          mid_span=self.grads.span(mid_names, module) if mid else None, mid_params=mid,
+                                          sumsq_fn=self._region_sumsq if self.m.is_cuda else None)
             # registry keyed by parameter identity (a second optimizer must not steal a global hook);
             # close() / garbage collection of this optimizer unregisters
             import ops
-            self._hook = ops.register_grad_done_hook(early, self.reducer.on_grad_done)
+            self._hook = ops.register_grad_done_hook(head + mid, self.reducer.on_grad_done)
+
+    PART_SLOTS = 512          # sum-of-squares partials per region of the exchange (at most 4 regions: 2048 workgroup slots)
+
+    def _region_sumsq(self, k, region):
+        """Called by the reducer on ITS stream right behind region k's all-reduce: that region's partial sums of g^2."""
+        self.K.sumsq_partials(region, self._part, k * self.PART_SLOTS, self.PART_SLOTS)
 
     def close(self):
         """Unregisters the gradient hooks (the reducer, the flat buffers and the parameters are released with it)."""
@@ -337,8 +471,12 @@ class HipAdam(object):
             dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM)
             scale = 1.0 / dist.get_world_size()
         self.t += 1
+        pre = None
+        if self.reducer is not None and self.reducer.partials_ready and self.reducer.sumsq_fn is not None:
+            # every region's sum of squares was accumulated behind its all-reduce: only the scalar combine is left
+            pre = (self._part, self.PART_SLOTS * len(self.reducer.regions()))
         self.K.adam_step(self.params.flat, self.grads.flat, self.m, self.v, self.lr, self.betas[0], self.betas[1],
-                         self.eps, self.wd, self.max_norm, self.t, True, self.norm, grad_scale=scale)
+                         self.eps, self.wd, self.max_norm, self.t, True, self.norm, grad_scale=scale, presummed=pre)
         self.K.weights_changed()
         # f16x3 mode: the magnitude bounds of all registered weights, measured HERE on the step's stream (one launch), so
         # that no GEMM of the next step -- on whichever stream ops._Side puts it -- is the one that triggers the pass
@@ -369,7 +507,8 @@ class _StepScope(object):
             # the step was abandoned before step() (exception, early exit): complete a launched collective so that
             # no rank is left with a pending RCCL op, and disarm
             r.armed = False
-            if r.work is not None:
-                r._wait_early()
-            r.count = 0
+            for bk in r.buckets:
+                if bk.work is not None:
+                    r._wait(bk)
+                bk.count = 0
         return False

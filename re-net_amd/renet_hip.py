@@ -94,7 +94,7 @@ _SIGNATURES = {
                                         c_int, c_int, c_void_p]),
     'renet_step_workspace': (c_size_t, [c_void_p, c_void_p]),
     'renet_step_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    'renet_step_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'renet_step_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'renet_add_inplace': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     'renet_zero': (c_int, [c_void_p, c_size_t, c_void_p]),
     'renet_colsum_workspace': (c_size_t, [c_int, c_int]),
@@ -155,6 +155,10 @@ _SIGNATURES = {
     'renet_adam_step_scaled': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,
                                        c_float, c_float, c_float, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                        c_void_p]),
+    'renet_sumsq_partials': (c_int, [c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
+    'renet_adam_step_presummed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,
+                                          c_float, c_float, c_float, c_float, c_int, c_int, c_void_p, c_int, c_void_p,
+                                          c_void_p]),
     'renet_host_filter_edges': (ctypes.c_int64, [c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int64, c_void_p, c_void_p,
                                                  ctypes.c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'renet_host_filter_edges_sparse': (ctypes.c_int64, [c_void_p] * 7 + [ctypes.c_int64, ctypes.c_int64, c_void_p,
@@ -1488,10 +1492,24 @@ def segment_pool_bwd(dout, seg_ptr, arg, num_graphs, is_max, n):
     return dh
 
 
+def sumsq_partials(g, partial, slot0, n_slots):
+    """partial[slot0 : slot0 + n_slots) = per-workgroup sums of squares of the flat fp32 region g (current stream)."""
+    _check(lib().renet_sumsq_partials(_f32(g), g.numel(), partial.data_ptr() + 4 * slot0, int(n_slots), _stream()),
+           'sumsq_partials')
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, max_norm, step, zero_grad=True, norm_out=None,
-              grad_scale=1.0):
-    """Fused clip + Adam + zero_grad on flat fp32 buffers (in place); the gradient is g * grad_scale."""
+              grad_scale=1.0, presummed=None):
+    """Fused clip + Adam + zero_grad on flat fp32 buffers (in place); the gradient is g * grad_scale.
+    presummed = (partial, n): ||g||^2 is the sum of partial[0..n) (sumsq_partials per all-reduce bucket), no norm pass."""
     n = p.numel()
+    if presummed is not None:
+        part, n_part = presummed
+        _check(lib().renet_adam_step_presummed(_f32(p), _f32(g), _f32(m), _f32(v), n, float(lr), float(beta1), float(beta2),
+                                               float(eps), float(weight_decay), float(max_norm), float(grad_scale),
+                                               int(step), int(zero_grad), _f32(part), int(n_part), _f32(norm_out),
+                                               _stream()), 'adam_step_presummed')
+        return
     nbytes = lib().renet_adam_workspace(n)
     ws = torch.empty(nbytes // 4, device=p.device, dtype=torch.float32)
     _check(lib().renet_adam_step_scaled(_f32(p), _f32(g), _f32(m), _f32(v), n, float(lr), float(beta1), float(beta2),

@@ -200,8 +200,10 @@ def _side_stream(device):
     return st
 
 
-def _head_event(device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
+def _head_event(device, which=0):
+    """(event, stream) pair `which` of this device: 0 = the score head's gradients, 1 = the encoders' (the C side records
+    the event; the reducer's hooks run on the stream, which waits for nothing but that event)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
     ev = _events.get(key)
     if ev is None:
         ev = torch.cuda.Event()
@@ -288,16 +290,26 @@ class StepFn(Function):
         defer = bool(ops.DEFER_WEIGHT_GRADS and side is not None and not missing)
         lin_w, lin_b = params[14], params[15]
         hooked = bool(ops._grad_done_hooks.get(id(lin_w)) or ops._grad_done_hooks.get(id(lin_b))) and not missing
-        ev = hs = None
+        ev = hs = ev2 = hs2 = None
         if hooked:
             ev, hs = _head_event(dev)
+        gru_params = params[6:14]                    # encoder.*, encoder_r.* (the reducer's middle bucket)
+        hooked_gru = any(ops._grad_done_hooks.get(id(p)) for p in gru_params) and not missing
+        if hooked_gru:
+            ev2, hs2 = _head_event(dev, 1)
         g = g.contiguous()
         nl = ctypes.c_int(0)
         lib = K.lib()
         K._check(lib.renet_step_backward(ctypes.addressof(m), ctypes.addressof(b), ctypes.addressof(r), K._f32(g),
-                                         int(defer), ev.cuda_event if ev is not None else None, ctypes.addressof(nl)),
+                                         int(defer), ev.cuda_event if ev is not None else None,
+                                         ev2.cuda_event if ev2 is not None else None, ctypes.addressof(nl)),
                  'renet_step_backward')
         StepFn.last_launches[1] = nl.value
+        if hooked_gru:
+            hs2.wait_event(ev2)
+            with torch.cuda.stream(hs2):
+                for p in gru_params:
+                    ops.grad_done(p)
         if hooked:
             # the score head's gradients are complete at `ev`, early in the launch list: the reducer's all-reduce of that
             # bucket is ordered behind the event only (a stream that waited for nothing else), not behind the whole pass

@@ -200,3 +200,37 @@ def test_c_launch_list_counts_its_launches_and_costs_less_host_time(dev):
     twin = copy.deepcopy(net)                       # (the launch list's caches must not live inside the module)
     assert torch.equal(twin.ent_embeds, net.ent_embeds)
     opt.close()
+
+
+def test_three_bucket_reducer_through_rccl_changes_nothing_but_the_norms_rounding(dev):
+    """RENET_FORCE_REDUCER=1 in a one-rank RCCL group: the score head's and the encoders' buckets are all-reduced DURING the
+    backward pass of the C launch list (events after their last gradient kernels), each region's sum of squares is taken
+    behind its all-reduce, and the optimizer only combines them -- same losses, same gradient norm up to the order of
+    the partial sums, same parameters up to that factor's rounding (parallel.OverlapReducer, train.py:140-142)."""
+    import json
+    import socket
+    import subprocess
+    res = {}
+    for forced in ('1', '0'):
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, RENET_FORCE_REDUCER=forced, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        env.pop('RENET_REDUCER_BUCKETS', None)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'reducer_run.py'), str(port)], env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith('RESULT ')][-1]
+        res[forced] = json.loads(line[7:])
+    a, b = res['1'], res['0']
+    assert all('StepFn' in u for u in a['used'] + b['used'])
+    assert len(a['regions']) == 3 and a['regions'][0][0] == 0                    # head | encoders | rest
+    assert all(e == [True, True] for e in a['early']), a['early']               # both timed buckets left during backward
+    assert all(a['ready']) and not any(b['ready'])
+    assert all(e == [False, False] for e in b['early'])
+    assert a['losses'][0] == b['losses'][0]
+    for x, y in zip(a['losses'], b['losses']):
+        assert abs(x - y) <= 2e-6 * abs(y), (a['losses'], b['losses'])
+    for x, y in zip(a['norms'], b['norms']):
+        assert x > 0 and abs(x - y) <= 2e-6 * y, (a['norms'], b['norms'])
+    assert abs(a['pnorm'] - b['pnorm']) <= 1e-6 * b['pnorm'] and abs(a['pabs'] - b['pabs']) <= 1e-6 * b['pabs']

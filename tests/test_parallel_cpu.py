@@ -216,6 +216,73 @@ def test_renet_two_ranks_equal_accumulation_over_the_same_batches(tmp_path):
 
 
 # ---------------------------------------------------------------------------------------------
+# Round 6: the THREE-bucket exchange (score head | encoders | rest) against the two-bucket one on the same steps, and the
+# per-region sums of squares the optimizer combines into the clip norm (train.py:140).
+# ---------------------------------------------------------------------------------------------
+def _three_bucket_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cpu_abi_emulation
+    cpu_abi_emulation.install()
+    import ops
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    net, quads, gd, hs, ho, perm = _renet_setup()
+    named = list(net.named_parameters())
+    head = [p for n, p in named if n in ('linear.weight', 'linear.bias')]
+    mid = [p for n, p in named if n.startswith(('encoder.', 'encoder_r.'))]
+    mid_names = tuple(n for n, p in named if n.startswith(('encoder.', 'encoder_r.')))
+    flat = parallel.FlatGrads(net, first=head + mid)                 # HipAdam's layout: head, encoders, rest
+    res = {}
+    for buckets in (2, 3):
+        red = parallel.OverlapReducer(flat, flat.span(('linear.weight', 'linear.bias'), net), head,
+                                      mid_span=flat.span(mid_names, net) if buckets == 3 else None,
+                                      mid_params=mid if buckets == 3 else ())
+        log = []
+        orig = red.on_grad_done
+
+        def spy(p, red=red, orig=orig, log=log):
+            orig(p)
+            log.append(tuple(bk.work is not None for bk in red.buckets))
+        token = ops.register_grad_done_hook(head + mid, spy)
+        flats, norms, launched = [], [], []
+        for step, (pair, passes) in enumerate(((False, 2), (True, 2))):
+            idx = parallel.shard_indices(perm, step, rank, world, 96)
+            red.begin_step(head_passes=passes)
+            _renet_grads(net, quads, gd, hs, ho, idx, pair=pair)
+            launched.append(tuple(bk.work is not None for bk in red.buckets))     # BEFORE finish(): the early launches
+            red.finish()
+            assert red.partials_ready and len(red.bucket_sumsq) == len(red.regions())
+            flats.append(flat.flat.clone())
+            norms.append((red.total_norm(), float(torch.linalg.vector_norm(flat.flat.double()))))
+            flat.zero()
+        ops.unregister_grad_done_hook(token)
+        res[buckets] = {'flat': flats, 'norms': norms, 'launched': launched, 'regions': red.regions(), 'log': log}
+    torch.save(res, out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_bucket_exchange_equals_the_two_bucket_one(tmp_path):
+    world, port, out = 2, _free_port(), str(tmp_path / 'b%d.pt')
+    mp.spawn(_three_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+    got = [torch.load(out % r) for r in range(world)]
+    for r in range(world):
+        two, three = got[r][2], got[r][3]
+        assert len(three['regions']) == 3, three['regions']
+        assert three['regions'][0][0] == 0 and three['regions'][1][0] == three['regions'][0][1]      # head | encoders | rest
+        for a, b in zip(two['flat'], three['flat']):
+            assert float(a.abs().max()) > 0 and torch.equal(a, b)      # the SAME exchanged gradient, bit for bit
+        # both timed buckets were in flight before finish(): the encoders' all-reduce overlaps the rest of the backward pass
+        assert all(l == (True,) for l in two['launched']), two['launched']
+        assert all(l == (True, True) for l in three['launched']), three['launched']
+        for tn, ref in three['norms'] + two['norms']:
+            assert abs(tn - ref) <= 1e-9 * ref                       # sqrt(sum of the per-region sums of squares) = ||g||
+    assert torch.equal(got[0][3]['flat'][0], got[1][3]['flat'][0])     # and both ranks hold it
+
+
+# ---------------------------------------------------------------------------------------------
 # SURVEY 8e option (i): the EXACT split -- both ranks build the SAME reference batch, keep half of its sequences
 # (graph.shard_sequences) and SUM their gradients: == the single-process step on that batch.
 # ---------------------------------------------------------------------------------------------
