@@ -6,7 +6,7 @@ R=$PWD
 O=gpurun_out/r6final
 mkdir -p $O
 export TMPDIR=/tmp
-(timeout 1500 python -m pytest tests -m gpu -x -q) > $O/gpu_tests.log 2>&1; tail -4 $O/gpu_tests.log
+(timeout 1500 python -m pytest tests -m gpu -x -q -rs) > $O/gpu_tests.log 2>&1; tail -4 $O/gpu_tests.log
 (timeout 900 python bench.py --gpus 1 --steps 20 --warmup 3) > $O/bench_driver_cmd.log 2>&1; grep -v amdgpu.ids $O/bench_driver_cmd.log | tail -1 > $O/bench_line_driver_cmd.json; cut -c1-400 $O/bench_line_driver_cmd.json
 (timeout 900 python bench.py) > $O/bench.log 2>&1; grep -v amdgpu.ids $O/bench.log | tail -1 > $O/bench_line.json; cut -c1-300 $O/bench_line.json
 cp gpurun_out/bench_detail.json $O/bench_detail.json
