@@ -340,16 +340,6 @@ def main():
             return net.loss_prepared_pair(*preps)       # the four GRU recurrences of the two passes share one launch
 
         def train_step(self, *preps):
-            if os.environ.get('RENET_BENCH_HIPRIO') == '1':         # (experiment: the step on a high-priority stream)
-                if not hasattr(self, '_hi'):
-                    self._hi = torch.cuda.Stream(priority=-1)
-                    self._hi.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self._hi):
-                    with opt.step_scope(head_passes=1 if len(preps) == 1 else 2, average=self.average):
-                        loss = self.step_loss(*preps)
-                        loss.backward()
-                        opt.step()
-                return loss
             with opt.step_scope(head_passes=1 if len(preps) == 1 else 2, average=self.average):
                 loss = self.step_loss(*preps)
                 loss.backward()

@@ -27,20 +27,13 @@ SIDE_STREAM = os.environ.get('RENET_SIDE_STREAM', '1') != '0'
 _side_streams = {}
 
 
-def new_side_stream(device):
-    """The side stream of a device.  RENET_SIDE_PRIORITY=p creates it with stream priority p (1 = below the default stream:
-    its workgroups are dispatched behind those of the stream that carries the step's critical path; default 0)."""
-    pr = int(os.environ.get('RENET_SIDE_PRIORITY', '0'))
-    return torch.cuda.Stream(device=device, priority=pr)
-
-
 class _Side(object):
     def __init__(self, device):
         self.on = SIDE_STREAM and device.type == 'cuda' and K._timer is None
         if self.on:
             key = device.index if device.index is not None else torch.cuda.current_device()
             if key not in _side_streams:
-                _side_streams[key] = new_side_stream(device)
+                _side_streams[key] = torch.cuda.Stream(device=device)
             self.main = torch.cuda.current_stream(device)
             self.side = _side_streams[key]
             self.side.wait_stream(self.main)                       # fork

@@ -196,7 +196,7 @@ def _side_stream(device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     st = ops._side_streams.get(key)
     if st is None:
-        st = ops._side_streams[key] = ops.new_side_stream(device)
+        st = ops._side_streams[key] = torch.cuda.Stream(device=device)
     return st
 
 
