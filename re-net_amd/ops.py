@@ -151,15 +151,33 @@ _grad_done_hooks = {}          # id(param) -> {token: callback}
 _hook_tokens = {'next': 0}
 
 
-def register_grad_done_hook(params, callback):
+_hook_wanted = {}              # token -> predicate: does this hook want notifications right now (None: always)
+
+
+def register_grad_done_hook(params, callback, wanted=None):
+    """wanted: optional callable() -> bool; callers that pay for a notification (events, a hook stream: step_plan.StepFn) ask
+    hooks_wanted(param) first -- the reducer of a process without a process group wants none."""
     _hook_tokens['next'] += 1
     token = _hook_tokens['next']
     for p in params:
         _grad_done_hooks.setdefault(id(p), {})[token] = callback
+    _hook_wanted[token] = wanted
     return token
 
 
+def hooks_wanted(param):
+    cbs = _grad_done_hooks.get(id(param))
+    if not cbs:
+        return False
+    for token in cbs:
+        w = _hook_wanted.get(token)
+        if w is None or w():
+            return True
+    return False
+
+
 def unregister_grad_done_hook(token):
+    _hook_wanted.pop(token, None)
     for pid in list(_grad_done_hooks):
         _grad_done_hooks[pid].pop(token, None)
         if not _grad_done_hooks[pid]:

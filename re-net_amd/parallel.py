@@ -421,7 +421,8 @@ class HipAdam(object):
             # registry keyed by parameter identity (a second optimizer must not steal a global hook);
             # close() / garbage collection of this optimizer unregisters
             import ops
-            self._hook = ops.register_grad_done_hook(head + mid, self.reducer.on_grad_done)
+            self._hook = ops.register_grad_done_hook(head + mid, self.reducer.on_grad_done,
+                                                     wanted=lambda r=self.reducer: r.armed and r.active())
 
     PART_SLOTS = 512          # sum-of-squares partials per region of the exchange (at most 4 regions: 2048 workgroup slots)
 

@@ -289,12 +289,12 @@ class StepFn(Function):
         r.side_stream = side.cuda_stream if side is not None else None
         defer = bool(ops.DEFER_WEIGHT_GRADS and side is not None and not missing)
         lin_w, lin_b = params[14], params[15]
-        hooked = bool(ops._grad_done_hooks.get(id(lin_w)) or ops._grad_done_hooks.get(id(lin_b))) and not missing
+        hooked = (ops.hooks_wanted(lin_w) or ops.hooks_wanted(lin_b)) and not missing
         ev = hs = ev2 = hs2 = None
         if hooked:
             ev, hs = _head_event(dev)
         gru_params = params[6:14]                    # encoder.*, encoder_r.* (the reducer's middle bucket)
-        hooked_gru = any(ops._grad_done_hooks.get(id(p)) for p in gru_params) and not missing
+        hooked_gru = not missing and any(ops.hooks_wanted(p) for p in gru_params)
         if hooked_gru:
             ev2, hs2 = _head_event(dev, 1)
         g = g.contiguous()
