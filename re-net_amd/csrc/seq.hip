@@ -413,6 +413,141 @@ __device__ __forceinline__ void split3_f4(float4 v, sq_u32x2 (&out)[3]) {
     }
 }
 
+// Round 6 (late): FOUR rows per workgroup, whole 128-byte lines out.  The 16 rows of a T16 tile share every line of the
+// output (a row owns 32 bytes of each 512-byte tile); with one row per workgroup every store instruction wrote 16 separate
+// 32-byte pieces and the lines were only completed in L2 by the workgroups of the neighbouring rows (137 us in the step for
+// 2048 x 23033 against 68 us for the fp32 in-place kernel).  Here a workgroup keeps rows 4 j .. 4 j + 3 of a tile in
+// registers (4 x 12 float4 per thread), takes the four row statistics, and in the store phase stages each 2048-column
+// slab -- 128 tiles x 3 planes x (4 rows x 32 bytes) -- through LDS so that every lane stores 16 bytes and 8 lanes one
+// whole line.  Rows >= B of the last quad write zeros.
+constexpr int SP4_STRIDE = 144;                         // bytes between two tiles' 128-byte blocks in the staging buffer
+constexpr int SP4_PLANE = 128 * SP4_STRIDE;             // one plane of a slab
+
+template <int NQ4>
+__global__ __launch_bounds__(512) void softmax_ce_planes4_kernel(const float* __restrict__ logits,
+                                                                 const int32_t* __restrict__ target, int B, int C, int ld,
+                                                                 float grad_scale, float* __restrict__ row_loss,
+                                                                 __bf16* __restrict__ P, size_t plane, int ld16) {
+    __shared__ float red_m[8][4], red_s[8][4];
+    __shared__ __attribute__((aligned(16))) char stage[3 * SP4_PLANE];
+    // block L -> XCD L & 7: the four quads of a tile row take consecutive slots of one XCD (see softmax_ce_planes_kernel)
+    const int L = (int)blockIdx.x;
+    const int tile_row = (L >> 5) * 8 + (L & 7), quad = (L >> 3) & 3;
+    const int b0 = tile_row * 16 + quad * 4;
+    if (b0 >= B) return;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int voff = tid * 16, c0 = tid * 4;
+    float4 v[4][NQ4];
+    int tgt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = min(b0 + r, B - 1);               // (a dead row re-reads the last live one; its outputs are zeroed)
+        tgt[r] = target[b];
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(logits + (size_t)b * ld), (short)0, C * 4, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < NQ4; ++q) {
+            const sq_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rin, voff, 8192 * q, 0);
+            v[r][q] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+        }
+    }
+    float m[4], xt[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int tg = tgt[r] >> 2, tc = tgt[r] & 3;
+        const bool mine = tid == (tg & 511);
+        const int tq = tg >> 9;
+        m[r] = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < NQ4; ++q) {
+            const int lim = C - 2048 * q;
+            float4& x = v[r][q];
+            x.x = c0 < lim ? x.x : -INFINITY;
+            x.y = c0 + 1 < lim ? x.y : -INFINITY;
+            x.z = c0 + 2 < lim ? x.z : -INFINITY;
+            x.w = c0 + 3 < lim ? x.w : -INFINITY;
+            m[r] = fmaxf(fmaxf(m[r], fmaxf(x.x, x.y)), fmaxf(x.z, x.w));
+            if (mine && q == tq) xt[r] = tc == 0 ? x.x : tc == 1 ? x.y : tc == 2 ? x.z : x.w;
+        }
+        m[r] = wave_max(m[r]);
+        if (lane == 0) red_m[wave][r] = m[r];
+    }
+    __syncthreads();
+    float s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float mm = red_m[0][r];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) mm = fmaxf(mm, red_m[w][r]);
+        m[r] = mm;
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ4; ++q) {
+            float4& x = v[r][q];
+            x.x = expf(x.x - mm); x.y = expf(x.y - mm); x.z = expf(x.z - mm); x.w = expf(x.w - mm);
+            acc += (x.x + x.y) + (x.z + x.w);
+            if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) red_s[wave][r] = acc;
+    }
+    __syncthreads();
+    float inv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) acc += red_s[w][r];
+        s[r] = acc;
+        const bool live = b0 + r < B;
+        if (live && tid == ((tgt[r] >> 2) & 511)) row_loss[b0 + r] = logf(acc) + m[r] - xt[r];
+        inv[r] = live ? grad_scale / acc : 0.f;         // (a dead row: zeros)
+    }
+    // store phase.  T16 (common.h): rows 4 quad + r of tile column tc are the 128-byte block (quad ^ (tc & 1)) of the tile,
+    // row r at r * 32, its 8-column halves swapped when quad >= 2.
+    const int tcl = tid >> 2;                                           // this thread's tile within a slab of 128 tiles
+    const int hq = (quad >> 1) & 1;
+    char* wr = stage + tcl * SP4_STRIDE + ((((tid >> 1) & 1) ^ hq) * 16) + (tid & 1) * 8;
+    // read side: 16-byte piece `pc` of tile `rt`, plane `rp` for k = 0 .. 5: linear index tid + 512 k over (plane, tile, piece)
+    __amdgpu_buffer_rsrc_t rout[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        rout[p] = __builtin_amdgcn_make_buffer_rsrc(P + (size_t)p * plane + (size_t)tile_row * ld16 * 16, (short)0,
+                                                    ld16 * 32, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < NQ4; ++q) {
+        if (q) __syncthreads();                                         // the previous slab has been read
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tg = tgt[r] >> 2, tc = tgt[r] & 3;
+            float4 o = make_float4(v[r][q].x * inv[r], v[r][q].y * inv[r], v[r][q].z * inv[r], v[r][q].w * inv[r]);
+            if (tid == (tg & 511) && q == (tg >> 9) && b0 + r < B) {
+                const float one = grad_scale;
+                if (tc == 0) o.x -= one; else if (tc == 1) o.y -= one; else if (tc == 2) o.z -= one; else o.w -= one;
+            }
+            sq_u32x2 pk[3];
+            split3_f4(o, pk);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<sq_u32x2*>(wr + p * SP4_PLANE + r * 32) = pk[p];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int n = tid + 512 * k;
+            const int rp = n >> 10, rt = (n >> 3) & 127, pc = n & 7;
+            const sq_u32x4 d = *reinterpret_cast<const sq_u32x4*>(stage + rp * SP4_PLANE + rt * SP4_STRIDE + pc * 16);
+            const int tcg = q * 128 + rt;
+            if (tcg * 16 < ld16) {                                      // (columns in [C, ld16) were written as exact zeros)
+                const int vo = rt * 512 + ((quad ^ (rt & 1)) * 128) + pc * 16;
+                if (rp == 0) __builtin_amdgcn_raw_buffer_store_b128(d, rout[0], vo, 65536 * q, 0);
+                else if (rp == 1) __builtin_amdgcn_raw_buffer_store_b128(d, rout[1], vo, 65536 * q, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(d, rout[2], vo, 65536 * q, 0);
+            }
+            if (k & 1) __builtin_amdgcn_sched_barrier(0);               // two pieces in flight (register budget: 4 x 48 row values)
+        }
+    }
+}
+
 // Row in registers (the structure of softmax_ce_reg_kernel): 512 threads, thread t owns the float4 groups at columns
 // 4 t + 2048 q, q < NQ4 (<= 12: C <= 24 576); needs 16-byte aligned rows (ld % 4 == 0).
 template <int NQ4>
@@ -833,7 +968,19 @@ int renet_softmax_ce_planes(const float* logits, const int32_t* target, int B, i
     }
     const bool aligned = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(dl_planes) & 7) == 0 && (plane & 3) == 0;
-    if (aligned && C >= 2048 && ld16 <= 12 * 2048) {
+    static int rows4 = -1;                 // RENET_SOFTMAX_ROWS=1: one row per workgroup (the first planes writer), for A/B runs
+    if (rows4 < 0) {
+        const char* e_ = getenv("RENET_SOFTMAX_ROWS");
+        rows4 = (e_ && e_[0] == '1') ? 0 : 1;
+    }
+    if (aligned && rows4 && C >= 2048 && ld16 <= 12 * 2048 && (reinterpret_cast<uintptr_t>(dl_planes) & 15) == 0 &&
+        (plane & 7) == 0) {
+        const int quads = (B + 3) / 4;
+        const dim3 grid((unsigned)((quads + 31) & ~31)), blk(512);   // whole groups of 8 XCDs x 4 quads
+        if (ld16 <= 4 * 2048) RENET_LAUNCH((softmax_ce_planes4_kernel<4>), grid, blk, 0, st, logits, target, B, C, ld, grad_scale, row_loss, P, plane, ld16);
+        else if (ld16 <= 8 * 2048) RENET_LAUNCH((softmax_ce_planes4_kernel<8>), grid, blk, 0, st, logits, target, B, C, ld, grad_scale, row_loss, P, plane, ld16);
+        else RENET_LAUNCH((softmax_ce_planes4_kernel<12>), grid, blk, 0, st, logits, target, B, C, ld, grad_scale, row_loss, P, plane, ld16);
+    } else if (aligned && C >= 2048 && ld16 <= 12 * 2048) {
         const dim3 grid((unsigned)((B + 127) & ~127)), blk(512);     // whole groups of 8 XCDs x 16 rows (see the kernel)
         if (ld16 <= 4 * 2048) RENET_LAUNCH((softmax_ce_planes_kernel<4>), grid, blk, 0, st, logits, target, B, C, ld, grad_scale, row_loss, P, plane, ld16);
         else if (ld16 <= 8 * 2048) RENET_LAUNCH((softmax_ce_planes_kernel<8>), grid, blk, 0, st, logits, target, B, C, ld, grad_scale, row_loss, P, plane, ld16);

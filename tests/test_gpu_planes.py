@@ -136,7 +136,8 @@ def test_gemm_planes_ignores_what_lies_outside_the_logical_matrices(dev):
     assert torch.isnan(buf[:, 333:]).all()
 
 
-@pytest.mark.parametrize('b,c', [(64, 23033), (33, 4100), (17, 2048), (9, 24576), (5, 1000), (3, 30000)])
+@pytest.mark.parametrize('b,c', [(64, 23033), (33, 4100), (17, 2048), (9, 24576), (5, 1000), (3, 30000), (22, 12000),
+                                 (130, 9000)])
 def test_softmax_ce_planes_equals_the_fp32_kernel(dev, b, c):
     """Same losses as renet_softmax_ce; the planes sum to its gradient (each term the RNE of the running residual);
     padding columns zero.  Widths on both sides of the register kernel's range and unaligned rows."""
@@ -205,3 +206,30 @@ def test_score_head_on_planes_equals_the_in_loop_split_head(dev):
     assert abs(a[0] - b[0]) < 1e-6 * abs(b[0])
     for x, y, name in zip(a[1:], b[1:], ('ent', 'rel', 'weight', 'bias', 'h')):
         np.testing.assert_allclose(x, y, rtol=1e-4, atol=1e-6 * max(1.0, float(np.abs(y).max()) * 10), err_msg=name)
+
+
+_SOFTMAX_ROWS_CHECK = '''
+import sys
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, sys.argv[2])
+import torch
+import test_gpu_planes as T
+dev = torch.device('cuda:0')
+for b, c in ((64, 23033), (33, 4100), (9, 24576)):
+    T.test_softmax_ce_planes_equals_the_fp32_kernel.__wrapped__(dev, b, c) if hasattr(
+        T.test_softmax_ce_planes_equals_the_fp32_kernel, '__wrapped__') else T.test_softmax_ce_planes_equals_the_fp32_kernel(dev, b, c)
+print('ok')
+'''
+
+
+def test_softmax_ce_planes_one_row_per_workgroup_variant(dev):
+    """RENET_SOFTMAX_ROWS=1 selects the first planes writer (one row per workgroup, 32-byte pieces) instead of the default
+    four-row one (whole lines through LDS): the same checks in a child process (the switch is read once)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    pkg = os.path.join(os.path.dirname(here), 're-net_amd')
+    r = subprocess.run([sys.executable, '-c', _SOFTMAX_ROWS_CHECK, pkg, here], env=dict(os.environ, RENET_SOFTMAX_ROWS='1'),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), r.stdout + r.stderr
