@@ -97,7 +97,6 @@ Lay layout(const RenetStepModel& m, const RenetStepBatch& b) {
         L.featp1_ld = (3 * D + 1 + 255) & ~(size_t)255;
         L.featp1_plane = L.dl_rows * L.featp1_ld;
         L.featp1 = take(3 * L.featp1_plane * 2);
-        L.featp = take(3 * L.featp_plane * 2);
         L.logits_ld = (NE + 3) & ~(size_t)3;
         L.logits = take(fbytes(B, L.logits_ld));
     } else {
@@ -280,14 +279,15 @@ int renet_step_forward(const RenetStepModel* mp, const RenetStepBatch* bp, const
     CK(renet_softmax_ce(F(L.dl2), b.rel_label, B, m.C2, m.C2, r->scale_rel, row_loss + B, F(L.dl2), s.side));
     CK(renet_concat3_fwd(m.ent, b.s_idx, F(L.hs0), m.rel, b.r_idx, B, D, p, r->seed_head1, F(L.feat1), s.main));
     if (use_planes(m)) {
-        CK(renet_pack_planes(F(L.feat1), B, 3 * D, 3 * D, 0, W + L.featp, s.main));
+        // ONE split of feat, with the ones column the weight-gradient GEMM wants (its bias column): the logits GEMM reads
+        // the same planes with K = 3D -- the ones meet the zero k padding of the weight's planes and add exactly 0
+        CK(renet_pack_planes(F(L.feat1), B, 3 * D, 3 * D, 1, W + L.featp1, s.main));
         const int sk = auto_split_k_planes(B, NE, 3 * D);
-        CK(renet_gemm_planes(0, 0, B, NE, 3 * D, 1.f, nullptr, W + L.featp, (int)L.featp_ld, L.featp_plane, m.lin_w_planes,
+        CK(renet_gemm_planes(0, 0, B, NE, 3 * D, 1.f, nullptr, W + L.featp1, (int)L.featp1_ld, L.featp1_plane, m.lin_w_planes,
                              m.lin_w_ld, m.lin_w_plane, 0.f, F(L.logits), (int)L.logits_ld, m.lin_b, nullptr, sk,
                              sk > 1 ? wsm : nullptr, sk > 1 ? L.gemm_ws_bytes : 0, s.main));
         CK(renet_softmax_ce_planes(F(L.logits), b.ent_label, B, NE, (int)L.logits_ld, r->scale_ent, row_loss, W + L.dl1, L.dl_plane,
                                    (int)L.dl_ld, (int)L.dl_rows, s.main));
-        CK(renet_pack_planes(F(L.feat1), B, 3 * D, 3 * D, 1, W + L.featp1, s.main));
     } else {
         CK(gemm(s.main, wsm, L.gemm_ws_bytes, 0, 1, B, NE, 3 * D, F(L.feat1), 3 * D, m.lin_w, 3 * D, 0.f, F(L.dl1), NE, m.lin_b));
         CK(renet_softmax_ce(F(L.dl1), b.ent_label, B, NE, NE, r->scale_ent, row_loss, F(L.dl1), s.main));

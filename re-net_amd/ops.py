@@ -669,10 +669,13 @@ def _head_forward(a, ia, hmid, c, ic, weight, bias, target, drop_p, seed, grad_s
         b_, c_ = feat.shape[0], weight.shape[0]
         w_pl = K.weight_planes(weight)
         logits = torch.empty(b_, (c_ + 3) & ~3, device=feat.device, dtype=torch.float32)[:, :c_]
-        K.gemm_planes(K.pack_planes(feat), w_pl, tb=True, bias=bias, out=logits)
+        # feat is split ONCE, with a ones column: dW's GEMM then yields the bias gradient as one more output column
+        # (col_out); the logits GEMM reads the same planes with K = 3D (the ones meet the zero k padding of the weight's
+        # planes and add exactly 0)
+        feat_pl1 = K.pack_planes(feat, ones_col=True)
+        K.gemm_planes(K.PlanesMat(feat_pl1.p, feat_pl1.R, feat_pl1.C - 1), w_pl, tb=True, bias=bias, out=logits)
         row_loss, dl_pl = K.softmax_ce_planes(logits, target, grad_scale, row_loss=row_loss)
-        # feat with a ones column: dW's GEMM then yields the bias gradient as one more output column (col_out)
-        return row_loss, feat, feat.new_empty(0), dl_pl, K.pack_planes(feat, ones_col=True)
+        return row_loss, feat, feat.new_empty(0), dl_pl, feat_pl1
     feat_op = K.operand(feat)                                        # (bf16 mode: packed once, reused by dW)
     logits = K.gemm(feat_op, weight, tb=True, bias=bias)             # [B, C]
     if debug_tap is not None:

@@ -70,6 +70,8 @@ def main():
     print('profiled:   %.3f ms per step' % ((time.perf_counter() - t0) * 1e3 / 20))
     st = pstats.Stats(pr)
     st.sort_stats('cumulative').print_stats(top)
+    st.print_callers('item')
+    st.sort_stats('tottime').print_stats(18)
 
 
 if __name__ == '__main__':
